@@ -1,0 +1,151 @@
+/*
+ * xmhw_amd.h -- C ABI of the MI355X (gfx950) implementation of xmhw's
+ * threshold() hot path.
+ *
+ * The reference (coecms/xmhw v0.9.3) is pure Python and has NO native
+ * interface; this ABI is what a binding for the path would call.  Each entry
+ * point names the reference code it replaces (paths relative to the reference
+ * repository root).  Plain pointers and sizes only; no exceptions cross the
+ * ABI: every function returns XMHW_OK or an error code and
+ * xmhw_last_error() holds the message for the calling thread.
+ *
+ * Layout contract (the reference's land_check() output, identify.py:482-529):
+ *   ts      [T][ld]  time-major, cell-minor ("cell" = stacked lat x lon);
+ *                    element (t, c) at ts[t*ld + c], c < C <= ld
+ *   doy     [T]      int32 label of every time step (add_doy(),
+ *                    identify.py:28-79); HOST memory
+ *   thresh  [D][ldo] float64, row i <-> i-th smallest distinct doy label
+ *   seas    [D][ldo] float64
+ * "dev" pointers are device (HBM) addresses owned by the caller.
+ */
+#ifndef XMHW_AMD_H
+#define XMHW_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XMHW_OK 0
+#define XMHW_ERR_INVALID 1     /* bad argument (the reference raises XmhwException) */
+#define XMHW_ERR_HIP 2         /* HIP runtime error / no device                     */
+#define XMHW_ERR_UNSUPPORTED 3 /* configuration outside every kernel's limits       */
+#define XMHW_ERR_NOMEM 4
+
+/* kernel selector for xmhw_plan_set_kernel() / reported by xmhw_plan_info() */
+#define XMHW_KERNEL_AUTO 0
+#define XMHW_KERNEL_RING 1     /* register-ring sliding-window kernel (fast path)   */
+#define XMHW_KERNEL_GENERIC 2  /* one wave per (cell, doy), radix descent (any plan)*/
+
+/* ---- library / device ------------------------------------------------- */
+int xmhw_version(void);                 /* 1000*major + minor                     */
+const char *xmhw_arch(void);            /* "gfx950"                               */
+const char *xmhw_last_error(void);      /* message of the last failure (thread)   */
+int xmhw_device_count(int *count);
+int xmhw_set_device(int device);
+int xmhw_device_info(int device, char *name, int name_len, int *compute_units,
+                     uint64_t *hbm_bytes);
+
+/* ---- caller-owned device memory, streams, events ---------------------- */
+int xmhw_malloc(void **dev_ptr, size_t bytes);
+int xmhw_free(void *dev_ptr);
+int xmhw_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes, void *stream);
+int xmhw_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes, void *stream);
+int xmhw_memset(void *dev_dst, int value, size_t bytes, void *stream);
+int xmhw_stream_create(void **stream);
+int xmhw_stream_destroy(void *stream);
+int xmhw_stream_sync(void *stream);     /* NULL = default stream                  */
+int xmhw_event_create(void **event);
+int xmhw_event_destroy(void *event);
+int xmhw_event_record(void *event, void *stream);
+int xmhw_event_elapsed_ms(void *start, void *stop, float *ms); /* syncs on stop  */
+
+/* ---- plan: everything derived from the doy labels ---------------------- *
+ * Replaces the per-cell window_roll() bookkeeping (identify.py:184-209: which
+ * samples pool under which doy) and groupby("doy") (identify.py:233,263).
+ * Built on the host from doy[T]; device tables are uploaded on first use.   */
+typedef struct xmhw_plan xmhw_plan;
+
+int xmhw_plan_create(const int32_t *doy_host, int64_t T, int32_t window_half_width,
+                     xmhw_plan **plan);
+int xmhw_plan_destroy(xmhw_plan *plan);
+/* D = number of distinct doy labels, ntracks = runs of increasing doy ("years"),
+ * kernel = XMHW_KERNEL_* that AUTO resolves to for float32 input             */
+int xmhw_plan_info(const xmhw_plan *plan, int32_t *D, int32_t *ntracks,
+                   int32_t *kernel, int32_t *nsteps, int32_t *step_min);
+int xmhw_plan_doys(const xmhw_plan *plan, int32_t *doys_out /* [D] */);
+int xmhw_plan_set_kernel(xmhw_plan *plan, int32_t kernel);  /* tests / fallback */
+int xmhw_plan_set_chunks(xmhw_plan *plan, int32_t nchunks); /* 0 = auto         */
+/* host copy of the ring kernel's step table for inspection:
+ * table[nsteps][ntracks_padded] (see csrc/plan.h for the encoding)            */
+int xmhw_plan_table(const xmhw_plan *plan, int32_t years_per_lane, uint32_t *table_out,
+                    int32_t *ntracks_padded);
+
+/* ---- the hot path ------------------------------------------------------ *
+ * xmhw_clim_raw_*: for every cell, the pooled linear-interpolated quantile
+ * and the pooled mean per doy -- calculate_thresh()/calculate_seas() WITHOUT
+ * the Feb-29 step (identify.py:233-235, :263) over window_roll()'s pools.
+ * NaN samples are dropped from the pools (identify.py:208); an empty pool
+ * gives NaN.  negate != 0 computes on -ts (coldSpells, xmhw.py:153-154).
+ * q = pctile / 100.0 (identify.py:234).                                      */
+int xmhw_clim_raw_f32(xmhw_plan *plan, const float *ts_dev, int64_t C, int64_t ld,
+                      double q, int negate, double *thresh_dev, double *seas_dev,
+                      int64_t ldo, void *stream);
+int xmhw_clim_raw_f64(xmhw_plan *plan, const double *ts_dev, int64_t C, int64_t ld,
+                      double q, int negate, double *thresh_dev, double *seas_dev,
+                      int64_t ldo, void *stream);
+
+/* xmhw_clim_finish: the Feb-29 substitution (feb29(), identify.py:137-151,
+ * applied at :237-240/:265-268 when feb29_fix != 0, i.e. tstep False) and
+ * the circular running mean (runavg(), identify.py:154-181, when smooth != 0;
+ * smooth_width must be odd) on both arrays, per cell over the groups PRESENT
+ * (non-NaN) for that cell, as the reference's per-cell series are.
+ * in/out may not alias.                                                      */
+int xmhw_clim_finish(const xmhw_plan *plan, const double *thresh_in_dev,
+                     const double *seas_in_dev, int64_t C, int64_t ldo, int feb29_fix,
+                     int smooth, int smooth_width, double *thresh_out_dev,
+                     double *seas_out_dev, void *stream);
+
+/* One synchronous call = calc_clim() (xmhw.py:250-307) for all cells:
+ * raw + finish, device buffers, builds a throw-away plan from doy_host.
+ * D must equal the number of distinct labels in doy_host.                    */
+int xmhw_clim_f32(const float *ts_dev, const int32_t *doy_host, int64_t T, int64_t C,
+                  int32_t D, int32_t window_half_width, double q, int smooth,
+                  int smooth_width, int feb29_fix, int negate, double *thresh_dev,
+                  double *seas_dev, void *stream);
+int xmhw_clim_f64(const double *ts_dev, const int32_t *doy_host, int64_t T, int64_t C,
+                  int32_t D, int32_t window_half_width, double q, int smooth,
+                  int smooth_width, int feb29_fix, int negate, double *thresh_dev,
+                  double *seas_dev, void *stream);
+/* Same with HOST buffers (copies in and out; PCIe-inclusive).                */
+int xmhw_clim_host_f32(const float *ts_host, const int32_t *doy_host, int64_t T, int64_t C,
+                       int32_t D, int32_t window_half_width, double q, int smooth,
+                       int smooth_width, int feb29_fix, int negate, double *thresh_host,
+                       double *seas_host);
+int xmhw_clim_host_f64(const double *ts_host, const int32_t *doy_host, int64_t T, int64_t C,
+                       int32_t D, int32_t window_half_width, double q, int smooth,
+                       int smooth_width, int feb29_fix, int negate, double *thresh_host,
+                       double *seas_host);
+
+/* land_check()'s dropna (identify.py:522-525) on the stacked array:
+ * keep[c] = 0 if cell c is all-NaN (anynans != 0: has any NaN), else 1.      */
+int xmhw_land_mask_f32(const float *ts_dev, int64_t T, int64_t C, int64_t ld, int anynans,
+                       uint8_t *keep_dev, void *stream);
+int xmhw_land_mask_f64(const double *ts_dev, int64_t T, int64_t C, int64_t ld, int anynans,
+                       uint8_t *keep_dev, void *stream);
+
+/* Synthetic SST generated in HBM (bench + large parity runs):
+ * x[t,c] = 15 + A_c sin(2 pi (t - phi_c)/365.25) + 5e-4 t beta_c + N(0,1),
+ * counter-based on (seed, cell0 + c, t); a sample is NaN with probability
+ * nan_frac.                                                                  */
+int xmhw_synth_sst_f32(float *ts_dev, int64_t T, int64_t C, int64_t ld, int64_t cell0,
+                       uint64_t seed, double nan_frac, void *stream);
+int xmhw_synth_sst_f64(double *ts_dev, int64_t T, int64_t C, int64_t ld, int64_t cell0,
+                       uint64_t seed, double nan_frac, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XMHW_AMD_H */

@@ -1,0 +1,16 @@
+"""xmhw_amd -- MI355X (gfx950) implementation of xmhw's threshold() hot path.
+
+    from xmhw_amd import threshold        # same signature as xmhw.xmhw.threshold
+
+The device side is hand-written HIP behind a C ABI (include/xmhw_amd.h); this
+package holds only the host side of the path.  Importing it does not need a
+GPU; calling threshold() does, and fails loudly without the HIP extension.
+"""
+from .exception import XmhwException
+from .api import threshold, threshold_array, GridSeries, ClimDataset
+from .calendar import add_doy, get_calendar
+from .landmask import land_check
+
+__all__ = ["threshold", "threshold_array", "GridSeries", "ClimDataset", "XmhwException",
+           "add_doy", "get_calendar", "land_check"]
+__version__ = "0.1.0"

@@ -1,0 +1,463 @@
+// capi.cpp -- the C ABI declared in include/xmhw_amd.h.
+#include "../../include/xmhw_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "plan.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    return fail(XMHW_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                        \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);    \
+    } while (0)
+
+constexpr int kSubs = 8;
+
+}  // namespace
+
+struct xmhw_plan {
+    xmhw::Plan host;
+    // device state (lazy, per current device at first use)
+    std::mutex mu;
+    bool uploaded = false;
+    int32_t yps = 0;          // ring kernel years-per-lane (0: ring not available)
+    int32_t nchunks = 0;
+    uint32_t* d_table = nullptr;
+    xmhw::DevChunk* d_chunks = nullptr;
+    int32_t* d_row_ptr = nullptr;
+    int32_t* d_centres = nullptr;
+
+    ~xmhw_plan() {
+        if (d_table) (void)hipFree(d_table);
+        if (d_chunks) (void)hipFree(d_chunks);
+        if (d_row_ptr) (void)hipFree(d_row_ptr);
+        if (d_centres) (void)hipFree(d_centres);
+    }
+};
+
+namespace {
+
+int32_t resolve_kernel(const xmhw_plan* p, int elem_bytes) {
+    const int32_t yps = xmhw::ring_pick_yps(p->host.w, p->host.ntracks, elem_bytes);
+    if (p->host.kernel_choice == XMHW_KERNEL_GENERIC) return XMHW_KERNEL_GENERIC;
+    if (p->host.kernel_choice == XMHW_KERNEL_RING) return yps ? XMHW_KERNEL_RING : -1;
+    return yps ? XMHW_KERNEL_RING : XMHW_KERNEL_GENERIC;
+}
+
+int32_t auto_chunks(const xmhw_plan* p, int64_t C) {
+    if (p->host.nchunks_req > 0) return std::min(p->host.nchunks_req, p->host.D);
+    // enough waves to fill 256 CUs x 16 waves a few times over; each chunk
+    // re-reads 2w rows per track and cold-starts its bracket, so keep them long
+    const int64_t waves = (C + 7) / 8;
+    int64_t want = (4 * 4096 + waves - 1) / std::max<int64_t>(waves, 1);
+    want = std::max<int64_t>(1, std::min<int64_t>(want, p->host.D / 24));
+    return static_cast<int32_t>(std::max<int64_t>(want, 1));
+}
+
+int upload(xmhw_plan* p, int64_t C) {
+    std::lock_guard<std::mutex> lock(p->mu);
+    const int32_t nchunks = auto_chunks(p, C);
+    if (p->uploaded && nchunks == p->nchunks) return XMHW_OK;
+    const xmhw::Plan& h = p->host;
+    if (!p->uploaded) {
+        HIP_TRY(hipMalloc(&p->d_row_ptr, sizeof(int32_t) * h.row_ptr.size()));
+        HIP_TRY(hipMemcpy(p->d_row_ptr, h.row_ptr.data(), sizeof(int32_t) * h.row_ptr.size(),
+                          hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&p->d_centres, sizeof(int32_t) * h.centres.size()));
+        HIP_TRY(hipMemcpy(p->d_centres, h.centres.data(), sizeof(int32_t) * h.centres.size(),
+                          hipMemcpyHostToDevice));
+        p->yps = xmhw::ring_pick_yps(h.w, h.ntracks, 4);
+        if (p->yps) {
+            std::vector<uint32_t> tab = h.ring_table(kSubs, p->yps);
+            HIP_TRY(hipMalloc(&p->d_table, sizeof(uint32_t) * tab.size()));
+            HIP_TRY(hipMemcpy(p->d_table, tab.data(), sizeof(uint32_t) * tab.size(),
+                              hipMemcpyHostToDevice));
+        }
+    }
+    if (p->yps) {
+        std::vector<xmhw::Chunk> ch = h.make_chunks(nchunks);
+        std::vector<xmhw::DevChunk> dch(ch.size());
+        for (size_t i = 0; i < ch.size(); ++i) dch[i] = {ch[i].warm_start, ch[i].begin, ch[i].end};
+        if (p->d_chunks) { HIP_TRY(hipFree(p->d_chunks)); p->d_chunks = nullptr; }
+        HIP_TRY(hipMalloc(&p->d_chunks, sizeof(xmhw::DevChunk) * dch.size()));
+        HIP_TRY(hipMemcpy(p->d_chunks, dch.data(), sizeof(xmhw::DevChunk) * dch.size(),
+                          hipMemcpyHostToDevice));
+        p->nchunks = static_cast<int32_t>(dch.size());
+    } else {
+        p->nchunks = nchunks;
+    }
+    p->uploaded = true;
+    return XMHW_OK;
+}
+
+template <typename T>
+int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int negate,
+             double* thresh, double* seas, int64_t ldo, void* stream) {
+    if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
+    if (C < 0 || ld < C || ldo < C) return fail(XMHW_ERR_INVALID, "bad C/ld/ldo");
+    if (!(q >= 0.0 && q <= 1.0)) return fail(XMHW_ERR_INVALID, "quantile must be in [0, 1]");
+    if (C == 0) return XMHW_OK;
+    if (!ts || !thresh || !seas) return fail(XMHW_ERR_INVALID, "NULL device buffer");
+    const int32_t kernel = resolve_kernel(plan, sizeof(T));
+    if (kernel < 0)
+        return fail(XMHW_ERR_UNSUPPORTED, "ring kernel not available for this window/track count/dtype");
+    int rc = upload(plan, C);
+    if (rc != XMHW_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const xmhw::Plan& h = plan->host;
+    hipError_t e;
+    if (kernel == XMHW_KERNEL_RING) {
+        if constexpr (sizeof(T) == 4) {
+            e = xmhw::launch_ring_f32(reinterpret_cast<const float*>(ts), C, ld, plan->d_table,
+                                      h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps, q,
+                                      negate, thresh, seas, ldo, st);
+        } else {
+            return fail(XMHW_ERR_UNSUPPORTED, "ring kernel is float32 only");
+        }
+    } else {
+        e = xmhw::launch_generic<T>(ts, h.T, C, ld, plan->d_row_ptr, plan->d_centres, h.D, h.w, q,
+                                    negate, thresh, seas, ldo, st);
+    }
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return XMHW_OK;
+}
+
+int row_index(const xmhw::Plan& h, int32_t label) {
+    auto it = std::lower_bound(h.doys.begin(), h.doys.end(), label);
+    if (it == h.doys.end() || *it != label) return -1;
+    return static_cast<int>(it - h.doys.begin());
+}
+
+template <typename T>
+int clim_oneshot(const T* ts, const int32_t* doy, int64_t Tn, int64_t C, int32_t D, int32_t w,
+                 double q, int smooth, int smooth_w, int feb29_fix, int negate, double* thresh,
+                 double* seas, void* stream) {
+    if (smooth && (smooth_w <= 0 || smooth_w % 2 == 0))
+        return fail(XMHW_ERR_INVALID, "smoothPercentileWidth should be odd");
+    xmhw_plan* plan = nullptr;
+    int rc = xmhw_plan_create(doy, Tn, w, &plan);
+    if (rc != XMHW_OK) return rc;
+    if (plan->host.D != D) {
+        xmhw_plan_destroy(plan);
+        return fail(XMHW_ERR_INVALID, "D does not match the number of distinct doy labels");
+    }
+    double *rt = nullptr, *rs = nullptr;
+    const size_t bytes = sizeof(double) * static_cast<size_t>(D) * static_cast<size_t>(C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    auto cleanup = [&]() {
+        if (rt) (void)hipFree(rt);
+        if (rs) (void)hipFree(rs);
+        xmhw_plan_destroy(plan);
+    };
+    if (C == 0) { cleanup(); return XMHW_OK; }
+    const bool need_finish = smooth || feb29_fix;
+    if (need_finish) {
+        if (hipMalloc(&rt, bytes) != hipSuccess || hipMalloc(&rs, bytes) != hipSuccess) {
+            cleanup();
+            return fail(XMHW_ERR_NOMEM, "hipMalloc of the raw climatology failed");
+        }
+    }
+    rc = clim_raw<T>(plan, ts, C, C, q, negate, need_finish ? rt : thresh, need_finish ? rs : seas, C,
+                     stream);
+    if (rc == XMHW_OK && need_finish)
+        rc = xmhw_clim_finish(plan, rt, rs, C, C, feb29_fix, smooth, smooth_w, thresh, seas, stream);
+    hipError_t e = hipStreamSynchronize(st);
+    cleanup();
+    if (rc != XMHW_OK) return rc;
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+    return XMHW_OK;
+}
+
+template <typename T>
+int clim_host(const T* ts, const int32_t* doy, int64_t Tn, int64_t C, int32_t D, int32_t w, double q,
+              int smooth, int smooth_w, int feb29_fix, int negate, double* thresh, double* seas) {
+    if (C == 0) return XMHW_OK;
+    if (!ts || !thresh || !seas) return fail(XMHW_ERR_INVALID, "NULL host buffer");
+    T* d_ts = nullptr;
+    double *d_th = nullptr, *d_se = nullptr;
+    const size_t in_bytes = sizeof(T) * static_cast<size_t>(Tn) * static_cast<size_t>(C);
+    const size_t out_bytes = sizeof(double) * static_cast<size_t>(D) * static_cast<size_t>(C);
+    auto cleanup = [&]() {
+        if (d_ts) (void)hipFree(d_ts);
+        if (d_th) (void)hipFree(d_th);
+        if (d_se) (void)hipFree(d_se);
+    };
+    if (hipMalloc(&d_ts, in_bytes) != hipSuccess || hipMalloc(&d_th, out_bytes) != hipSuccess ||
+        hipMalloc(&d_se, out_bytes) != hipSuccess) {
+        cleanup();
+        return fail(XMHW_ERR_NOMEM, "hipMalloc failed");
+    }
+    hipError_t e = hipMemcpy(d_ts, ts, in_bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipMemcpy H2D"); }
+    int rc = clim_oneshot<T>(d_ts, doy, Tn, C, D, w, q, smooth, smooth_w, feb29_fix, negate, d_th, d_se,
+                             nullptr);
+    if (rc == XMHW_OK) {
+        e = hipMemcpy(thresh, d_th, out_bytes, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(seas, d_se, out_bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H");
+    }
+    cleanup();
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xmhw_version(void) { return 1000 * 0 + 1; }
+const char* xmhw_arch(void) { return "gfx950"; }
+const char* xmhw_last_error(void) { return g_err.c_str(); }
+
+int xmhw_device_count(int* count) {
+    if (!count) return fail(XMHW_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return hip_fail(e, "hipGetDeviceCount"); }
+    *count = n;
+    return XMHW_OK;
+}
+int xmhw_set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return XMHW_OK;
+}
+int xmhw_device_info(int device, char* name, int name_len, int* compute_units, uint64_t* hbm_bytes) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (name && name_len > 0) {
+        std::snprintf(name, static_cast<size_t>(name_len), "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return XMHW_OK;
+}
+
+int xmhw_malloc(void** dev_ptr, size_t bytes) {
+    if (!dev_ptr) return fail(XMHW_ERR_INVALID, "dev_ptr is NULL");
+    *dev_ptr = nullptr;
+    if (bytes == 0) return XMHW_OK;
+    hipError_t e = hipMalloc(dev_ptr, bytes);
+    if (e == hipErrorOutOfMemory) return fail(XMHW_ERR_NOMEM, "hipMalloc: out of memory");
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    return XMHW_OK;
+}
+int xmhw_free(void* dev_ptr) {
+    if (dev_ptr) HIP_TRY(hipFree(dev_ptr));
+    return XMHW_OK;
+}
+int xmhw_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+    if (bytes == 0) return XMHW_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return XMHW_OK;
+}
+int xmhw_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+    if (bytes == 0) return XMHW_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return XMHW_OK;
+}
+int xmhw_memset(void* dst, int value, size_t bytes, void* stream) {
+    if (bytes == 0) return XMHW_OK;
+    HIP_TRY(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)));
+    return XMHW_OK;
+}
+int xmhw_stream_create(void** stream) {
+    if (!stream) return fail(XMHW_ERR_INVALID, "stream is NULL");
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return XMHW_OK;
+}
+int xmhw_stream_destroy(void* stream) {
+    if (stream) HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    return XMHW_OK;
+}
+int xmhw_stream_sync(void* stream) {
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return XMHW_OK;
+}
+int xmhw_event_create(void** event) {
+    if (!event) return fail(XMHW_ERR_INVALID, "event is NULL");
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreate(&ev));
+    *event = ev;
+    return XMHW_OK;
+}
+int xmhw_event_destroy(void* event) {
+    if (event) HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(event)));
+    return XMHW_OK;
+}
+int xmhw_event_record(void* event, void* stream) {
+    HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
+    return XMHW_OK;
+}
+int xmhw_event_elapsed_ms(void* start, void* stop, float* ms) {
+    if (!ms) return fail(XMHW_ERR_INVALID, "ms is NULL");
+    HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(stop)));
+    HIP_TRY(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+    return XMHW_OK;
+}
+
+int xmhw_plan_create(const int32_t* doy_host, int64_t T, int32_t window_half_width, xmhw_plan** plan) {
+    if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
+    *plan = nullptr;
+    if (!doy_host) return fail(XMHW_ERR_INVALID, "doy is NULL");
+    xmhw_plan* p = new (std::nothrow) xmhw_plan();
+    if (!p) return fail(XMHW_ERR_NOMEM, "out of host memory");
+    if (!p->host.build(doy_host, T, window_half_width)) {
+        std::string msg = p->host.error;
+        delete p;
+        return fail(XMHW_ERR_INVALID, msg);
+    }
+    *plan = p;
+    return XMHW_OK;
+}
+int xmhw_plan_destroy(xmhw_plan* plan) {
+    delete plan;
+    return XMHW_OK;
+}
+int xmhw_plan_info(const xmhw_plan* plan, int32_t* D, int32_t* ntracks, int32_t* kernel, int32_t* nsteps,
+                   int32_t* step_min) {
+    if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
+    if (D) *D = plan->host.D;
+    if (ntracks) *ntracks = plan->host.ntracks;
+    if (kernel) *kernel = resolve_kernel(plan, 4);
+    if (nsteps) *nsteps = plan->host.nsteps;
+    if (step_min) *step_min = plan->host.step_min;
+    return XMHW_OK;
+}
+int xmhw_plan_doys(const xmhw_plan* plan, int32_t* doys_out) {
+    if (!plan || !doys_out) return fail(XMHW_ERR_INVALID, "NULL argument");
+    std::memcpy(doys_out, plan->host.doys.data(), sizeof(int32_t) * plan->host.doys.size());
+    return XMHW_OK;
+}
+int xmhw_plan_set_kernel(xmhw_plan* plan, int32_t kernel) {
+    if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
+    if (kernel < XMHW_KERNEL_AUTO || kernel > XMHW_KERNEL_GENERIC)
+        return fail(XMHW_ERR_INVALID, "unknown kernel selector");
+    plan->host.kernel_choice = kernel;
+    return XMHW_OK;
+}
+int xmhw_plan_set_chunks(xmhw_plan* plan, int32_t nchunks) {
+    if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
+    if (nchunks < 0) return fail(XMHW_ERR_INVALID, "nchunks must be >= 0");
+    plan->host.nchunks_req = nchunks;
+    return XMHW_OK;
+}
+int xmhw_plan_table(const xmhw_plan* plan, int32_t years_per_lane, uint32_t* table_out,
+                    int32_t* ntracks_padded) {
+    if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
+    if (years_per_lane <= 0) return fail(XMHW_ERR_INVALID, "years_per_lane must be > 0");
+    if (plan->host.ntracks > kSubs * years_per_lane)
+        return fail(XMHW_ERR_INVALID, "years_per_lane too small for the number of tracks");
+    if (ntracks_padded) *ntracks_padded = kSubs * years_per_lane;
+    if (table_out) {
+        std::vector<uint32_t> tab = plan->host.ring_table(kSubs, years_per_lane);
+        std::memcpy(table_out, tab.data(), sizeof(uint32_t) * tab.size());
+    }
+    return XMHW_OK;
+}
+
+int xmhw_clim_raw_f32(xmhw_plan* plan, const float* ts, int64_t C, int64_t ld, double q, int negate,
+                      double* thresh, double* seas, int64_t ldo, void* stream) {
+    return clim_raw<float>(plan, ts, C, ld, q, negate, thresh, seas, ldo, stream);
+}
+int xmhw_clim_raw_f64(xmhw_plan* plan, const double* ts, int64_t C, int64_t ld, double q, int negate,
+                      double* thresh, double* seas, int64_t ldo, void* stream) {
+    return clim_raw<double>(plan, ts, C, ld, q, negate, thresh, seas, ldo, stream);
+}
+
+int xmhw_clim_finish(const xmhw_plan* plan, const double* thresh_in, const double* seas_in, int64_t C,
+                     int64_t ldo, int feb29_fix, int smooth, int smooth_width, double* thresh_out,
+                     double* seas_out, void* stream) {
+    if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
+    if (smooth && (smooth_width <= 0 || smooth_width % 2 == 0))
+        return fail(XMHW_ERR_INVALID, "Running average window should be odd");
+    if (C < 0 || ldo < C) return fail(XMHW_ERR_INVALID, "bad C/ldo");
+    if (C == 0) return XMHW_OK;
+    if (!thresh_in || !seas_in || !thresh_out || !seas_out)
+        return fail(XMHW_ERR_INVALID, "NULL device buffer");
+    if (thresh_in == thresh_out || seas_in == seas_out)
+        return fail(XMHW_ERR_INVALID, "in and out may not alias");
+    const xmhw::Plan& h = plan->host;
+    hipError_t e = xmhw::launch_finish(thresh_in, seas_in, C, ldo, h.D, row_index(h, 59), row_index(h, 60),
+                                       row_index(h, 61), feb29_fix, smooth, smooth ? smooth_width : 1,
+                                       thresh_out, seas_out, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "clim_finish launch");
+    return XMHW_OK;
+}
+
+int xmhw_clim_f32(const float* ts, const int32_t* doy, int64_t T, int64_t C, int32_t D, int32_t w,
+                  double q, int smooth, int smooth_w, int feb29_fix, int negate, double* thresh,
+                  double* seas, void* stream) {
+    return clim_oneshot<float>(ts, doy, T, C, D, w, q, smooth, smooth_w, feb29_fix, negate, thresh, seas,
+                               stream);
+}
+int xmhw_clim_f64(const double* ts, const int32_t* doy, int64_t T, int64_t C, int32_t D, int32_t w,
+                  double q, int smooth, int smooth_w, int feb29_fix, int negate, double* thresh,
+                  double* seas, void* stream) {
+    return clim_oneshot<double>(ts, doy, T, C, D, w, q, smooth, smooth_w, feb29_fix, negate, thresh, seas,
+                                stream);
+}
+int xmhw_clim_host_f32(const float* ts, const int32_t* doy, int64_t T, int64_t C, int32_t D, int32_t w,
+                       double q, int smooth, int smooth_w, int feb29_fix, int negate, double* thresh,
+                       double* seas) {
+    return clim_host<float>(ts, doy, T, C, D, w, q, smooth, smooth_w, feb29_fix, negate, thresh, seas);
+}
+int xmhw_clim_host_f64(const double* ts, const int32_t* doy, int64_t T, int64_t C, int32_t D, int32_t w,
+                       double q, int smooth, int smooth_w, int feb29_fix, int negate, double* thresh,
+                       double* seas) {
+    return clim_host<double>(ts, doy, T, C, D, w, q, smooth, smooth_w, feb29_fix, negate, thresh, seas);
+}
+
+int xmhw_land_mask_f32(const float* ts, int64_t T, int64_t C, int64_t ld, int anynans, uint8_t* keep,
+                       void* stream) {
+    if (C < 0 || ld < C || T <= 0) return fail(XMHW_ERR_INVALID, "bad T/C/ld");
+    hipError_t e = xmhw::launch_land_mask<float>(ts, T, C, ld, anynans, keep, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "land_mask launch");
+    return XMHW_OK;
+}
+int xmhw_land_mask_f64(const double* ts, int64_t T, int64_t C, int64_t ld, int anynans, uint8_t* keep,
+                       void* stream) {
+    if (C < 0 || ld < C || T <= 0) return fail(XMHW_ERR_INVALID, "bad T/C/ld");
+    hipError_t e = xmhw::launch_land_mask<double>(ts, T, C, ld, anynans, keep, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "land_mask launch");
+    return XMHW_OK;
+}
+
+int xmhw_synth_sst_f32(float* ts, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
+                       double nan_frac, void* stream) {
+    if (C < 0 || ld < C || T <= 0) return fail(XMHW_ERR_INVALID, "bad T/C/ld");
+    hipError_t e = xmhw::launch_synth<float>(ts, T, C, ld, cell0, seed, nan_frac, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "synth launch");
+    return XMHW_OK;
+}
+int xmhw_synth_sst_f64(double* ts, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
+                       double nan_frac, void* stream) {
+    if (C < 0 || ld < C || T <= 0) return fail(XMHW_ERR_INVALID, "bad T/C/ld");
+    hipError_t e = xmhw::launch_synth<double>(ts, T, C, ld, cell0, seed, nan_frac, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "synth launch");
+    return XMHW_OK;
+}
+
+}  // extern "C"

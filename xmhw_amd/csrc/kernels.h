@@ -1,0 +1,37 @@
+// kernels.h -- host-callable launchers (defined in the .hip files).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xmhw {
+
+struct DevChunk { int32_t warm_start, begin, end; };
+
+// generic kernel (any plan): thread per (cell, row)
+template <typename T>
+hipError_t launch_generic(const T* ts, int64_t Tn, int64_t C, int64_t ld, const int32_t* row_ptr,
+                          const int32_t* centres, int32_t D, int32_t w, double q, int negate,
+                          double* thresh, double* seas, int64_t ldo, hipStream_t stream);
+
+// ring kernel (fast path).  Returns hipErrorInvalidValue if (w, yps) is not instantiated.
+bool ring_supported(int32_t w, int32_t yps, int elem_bytes);
+int32_t ring_pick_yps(int32_t w, int32_t ntracks, int elem_bytes);  // 0 if none
+hipError_t launch_ring_f32(const float* ts, int64_t C, int64_t ld, const uint32_t* table,
+                           int32_t step_min, const DevChunk* chunks, int32_t nchunks,
+                           int32_t w, int32_t yps, double q, int negate, double* thresh,
+                           double* seas, int64_t ldo, hipStream_t stream);
+
+// Feb-29 substitution + circular running mean, per cell over present groups
+hipError_t launch_finish(const double* th_in, const double* se_in, int64_t C, int64_t ldo, int32_t D,
+                         int32_t i59, int32_t i60, int32_t i61, int feb29_fix, int smooth,
+                         int32_t width, double* th_out, double* se_out, hipStream_t stream);
+
+template <typename T>
+hipError_t launch_land_mask(const T* ts, int64_t Tn, int64_t C, int64_t ld, int anynans,
+                            uint8_t* keep, hipStream_t stream);
+
+template <typename T>
+hipError_t launch_synth(T* ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
+                        double nan_frac, hipStream_t stream);
+
+}  // namespace xmhw

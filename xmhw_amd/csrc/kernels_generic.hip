@@ -1,0 +1,308 @@
+// kernels_generic.hip -- gfx950 kernels that work for ANY plan:
+//   * clim_generic: thread per (cell, row); exact selection by radix descent on
+//     order-preserving keys.  Fallback for plans the ring kernel does not cover
+//     and an independent on-device cross-check of it.
+//   * clim_finish: Feb-29 substitution + circular running mean.
+//   * land_mask, synth_sst.
+// All global accesses are coalesced along the stacked cell axis (lane = cell).
+#include "device_common.h"
+#include "kernels.h"
+
+namespace xmhw {
+
+// ---------------------------------------------------------------------------
+// clim_generic
+// Reference semantics: window_roll() pools (identify.py:204-208) -> per-doy
+// quantile (identify.py:233-235) and mean (identify.py:263).
+// Per thread: pass 0 counts valid samples and sums them; then the key of the
+// lo-th order statistic is built bit by bit (largest v with #{k < v} <= lo),
+// one pass over the pool per bit; a final pass finds the next order statistic.
+// The pool is re-read from L2 for every pass (lanes of a block share rows).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void clim_generic(const T* __restrict__ ts, int64_t Tn, int64_t C,
+                                                    int64_t ld, const int32_t* __restrict__ row_ptr,
+                                                    const int32_t* __restrict__ centres, int32_t w,
+                                                    double q, int negate, double* __restrict__ thresh,
+                                                    double* __restrict__ seas, int64_t ldo) {
+    using K = typename KeyOf<T>::type;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int32_t row = blockIdx.y;
+    if (c >= C) return;
+    const int32_t cb = row_ptr[row], ce = row_ptr[row + 1];
+    const T* col = ts + c;
+
+    uint32_t n = 0;
+    double sum = 0.0;
+    for (int32_t i = cb; i < ce; ++i) {
+        const int64_t t0 = centres[i];
+        for (int32_t k = -w; k <= w; ++k) {
+            const int64_t t = t0 + k;
+            if (t < 0 || t >= Tn) continue;
+            T v = col[t * ld];
+            if (negate) v = -v;
+            if (v == v) { ++n; sum += static_cast<double>(v); }
+        }
+    }
+    double th = make_nan(), se = make_nan();
+    if (n > 0) {
+        const double vi = static_cast<double>(n - 1) * q;
+        const double fl = floor(vi);
+        const uint32_t lo = static_cast<uint32_t>(fl);
+        const double g = vi - fl;
+        K v = 0;
+        for (int bit = KeyOf<T>::bits - 1; bit >= 0; --bit) {
+            const K cand = v | (static_cast<K>(1) << bit);
+            uint32_t cnt = 0;  // valid keys < cand   (key 0 = invalid: (0-1) wraps high)
+            for (int32_t i = cb; i < ce; ++i) {
+                const int64_t t0 = centres[i];
+                for (int32_t k = -w; k <= w; ++k) {
+                    const int64_t t = t0 + k;
+                    if (t < 0 || t >= Tn) continue;
+                    T x = col[t * ld];
+                    if (negate) x = -x;
+                    const K key = KeyOf<T>::key(x);
+                    cnt += (static_cast<K>(key - 1) < static_cast<K>(cand - 1)) ? 1u : 0u;
+                }
+            }
+            if (cnt <= lo) v = cand;
+        }
+        // v = key of a[lo].  a[lo+1]: v again if it is duplicated past lo, else the next key.
+        uint32_t cle = 0;
+        K mn = ~static_cast<K>(0);
+        for (int32_t i = cb; i < ce; ++i) {
+            const int64_t t0 = centres[i];
+            for (int32_t k = -w; k <= w; ++k) {
+                const int64_t t = t0 + k;
+                if (t < 0 || t >= Tn) continue;
+                T x = col[t * ld];
+                if (negate) x = -x;
+                const K key = KeyOf<T>::key(x);
+                if (key != 0 && key <= v) ++cle;
+                if (key > v && key < mn) mn = key;
+            }
+        }
+        K vhi = v;
+        if (lo + 1 < n && cle < lo + 2) vhi = mn;
+        th = numpy_lerp(KeyOf<T>::value(v), KeyOf<T>::value(vhi), g);
+        se = sum / static_cast<double>(n);
+    }
+    thresh[static_cast<int64_t>(row) * ldo + c] = th;
+    seas[static_cast<int64_t>(row) * ldo + c] = se;
+}
+
+template <typename T>
+hipError_t launch_generic(const T* ts, int64_t Tn, int64_t C, int64_t ld, const int32_t* row_ptr,
+                          const int32_t* centres, int32_t D, int32_t w, double q, int negate,
+                          double* thresh, double* seas, int64_t ldo, hipStream_t stream) {
+    if (C <= 0 || D <= 0) return hipSuccess;
+    dim3 grid(static_cast<unsigned>((C + 255) / 256), static_cast<unsigned>(D));
+    hipLaunchKernelGGL(clim_generic<T>, grid, dim3(256), 0, stream, ts, Tn, C, ld, row_ptr, centres, w,
+                       q, negate, thresh, seas, ldo);
+    return hipGetLastError();
+}
+template hipError_t launch_generic<float>(const float*, int64_t, int64_t, int64_t, const int32_t*,
+                                          const int32_t*, int32_t, int32_t, double, int, double*,
+                                          double*, int64_t, hipStream_t);
+template hipError_t launch_generic<double>(const double*, int64_t, int64_t, int64_t, const int32_t*,
+                                           const int32_t*, int32_t, int32_t, double, int, double*,
+                                           double*, int64_t, hipStream_t);
+
+// ---------------------------------------------------------------------------
+// clim_finish: feb29() (identify.py:137-151 applied at :237-240, :265-268)
+// and runavg() (identify.py:154-181) on a raw (D, C) climatology.
+// The reference runs both on the per-cell series of PRESENT groups, so for a
+// column with NaN rows (empty pools) the neighbours are the next present rows
+// (positional rolling); a column without NaN takes the direct path.
+// blockIdx.y selects the array (0 thresh, 1 seas); thread = cell.
+// ---------------------------------------------------------------------------
+struct FinishCol {
+    const double* in;
+    int64_t ld;
+    int32_t i60;
+    double f60;
+    bool sub60;
+    __device__ __forceinline__ double raw(int32_t d) const { return in[static_cast<int64_t>(d) * ld]; }
+    __device__ __forceinline__ double val(int32_t d) const { return (sub60 && d == i60) ? f60 : raw(d); }
+};
+
+__global__ __launch_bounds__(256) void clim_finish(const double* __restrict__ th_in,
+                                                   const double* __restrict__ se_in, int64_t C,
+                                                   int64_t ld, int32_t D, int32_t i59, int32_t i60,
+                                                   int32_t i61, int feb29_fix, int smooth, int32_t width,
+                                                   double* __restrict__ th_out,
+                                                   double* __restrict__ se_out) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double* in = (blockIdx.y == 0 ? th_in : se_in) + c;
+    double* out = (blockIdx.y == 0 ? th_out : se_out) + c;
+
+    int32_t nnan = 0;
+    for (int32_t d = 0; d < D; ++d) {
+        const double v = in[static_cast<int64_t>(d) * ld];
+        nnan += (v != v) ? 1 : 0;
+    }
+    FinishCol col{in, ld, i60, 0.0, false};
+    if (feb29_fix && i60 >= 0) {
+        const double v60 = col.raw(i60);
+        if (v60 == v60) {  // group 60 present for this cell: replace by the 3-point nan-mean
+            double s = v60;
+            int32_t m = 1;
+            if (i59 >= 0) { const double v = col.raw(i59); if (v == v) { s += v; ++m; } }
+            if (i61 >= 0) { const double v = col.raw(i61); if (v == v) { s += v; ++m; } }
+            // numpy mean of [v59, v60, v61] sums in index order
+            if (m == 3) s = (col.raw(i59) + v60) + col.raw(i61);
+            else if (m == 2 && i59 >= 0 && col.raw(i59) == col.raw(i59)) s = col.raw(i59) + v60;
+            col.f60 = s / static_cast<double>(m);
+            col.sub60 = true;
+        }
+    }
+    const int32_t h = (width - 1) / 2;
+    const double inv = static_cast<double>(width);
+    if (!smooth) {
+        for (int32_t d = 0; d < D; ++d) out[static_cast<int64_t>(d) * ld] = col.val(d);
+        return;
+    }
+    if (nnan == 0) {
+        // every group present: window of row d is rows (d-h .. d+h) mod D
+        int32_t trail = ((-h) % D + D) % D;
+        int32_t lead = trail;
+        double s = 0.0;
+        for (int32_t i = 0; i < width; ++i) {
+            s += col.val(lead);
+            if (i + 1 < width) lead = (lead + 1 == D) ? 0 : lead + 1;
+        }
+        for (int32_t d = 0; d < D; ++d) {
+            out[static_cast<int64_t>(d) * ld] = s / inv;
+            s -= col.val(trail);
+            trail = (trail + 1 == D) ? 0 : trail + 1;
+            lead = (lead + 1 == D) ? 0 : lead + 1;
+            s += col.val(lead);
+        }
+        return;
+    }
+    // some groups absent: roll over the present rows only
+    const int32_t np = D - nnan;
+    if (np == 0) {
+        for (int32_t d = 0; d < D; ++d) out[static_cast<int64_t>(d) * ld] = make_nan();
+        return;
+    }
+    auto next_present = [&](int32_t d) {
+        do { d = (d + 1 == D) ? 0 : d + 1; } while (col.raw(d) != col.raw(d));
+        return d;
+    };
+    auto prev_present = [&](int32_t d) {
+        do { d = (d == 0) ? D - 1 : d - 1; } while (col.raw(d) != col.raw(d));
+        return d;
+    };
+    int32_t first = 0;
+    while (col.raw(first) != col.raw(first)) ++first;
+    int32_t trail = first;
+    for (int32_t i = 0; i < h; ++i) trail = prev_present(trail);
+    int32_t lead = trail;
+    double s = 0.0;
+    for (int32_t i = 0; i < width; ++i) {
+        s += col.val(lead);
+        if (i + 1 < width) lead = next_present(lead);
+    }
+    int32_t cur = first;
+    for (int32_t d = 0; d < first; ++d) out[static_cast<int64_t>(d) * ld] = make_nan();
+    for (int32_t j = 0; j < np; ++j) {
+        out[static_cast<int64_t>(cur) * ld] = s / inv;
+        s -= col.val(trail);
+        trail = next_present(trail);
+        lead = next_present(lead);
+        s += col.val(lead);
+        const int32_t nxt = next_present(cur);
+        if (j + 1 < np)
+            for (int32_t d = cur + 1; d < nxt; ++d) out[static_cast<int64_t>(d) * ld] = make_nan();
+        else
+            for (int32_t d = cur + 1; d < D; ++d) out[static_cast<int64_t>(d) * ld] = make_nan();
+        cur = nxt;
+    }
+}
+
+hipError_t launch_finish(const double* th_in, const double* se_in, int64_t C, int64_t ldo, int32_t D,
+                         int32_t i59, int32_t i60, int32_t i61, int feb29_fix, int smooth,
+                         int32_t width, double* th_out, double* se_out, hipStream_t stream) {
+    if (C <= 0 || D <= 0) return hipSuccess;
+    dim3 grid(static_cast<unsigned>((C + 255) / 256), 2);
+    hipLaunchKernelGGL(clim_finish, grid, dim3(256), 0, stream, th_in, se_in, C, ldo, D, i59, i60, i61,
+                       feb29_fix, smooth, width, th_out, se_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// land_mask: land_check()'s dropna over the stacked cells (identify.py:522-525)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void land_mask(const T* __restrict__ ts, int64_t Tn, int64_t C,
+                                                 int64_t ld, int anynans, uint8_t* __restrict__ keep) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    int64_t nnan = 0;
+    for (int64_t t = 0; t < Tn; ++t) {
+        const T v = ts[t * ld + c];
+        nnan += (v != v) ? 1 : 0;
+    }
+    keep[c] = anynans ? (nnan == 0) : (nnan < Tn);
+}
+
+template <typename T>
+hipError_t launch_land_mask(const T* ts, int64_t Tn, int64_t C, int64_t ld, int anynans,
+                            uint8_t* keep, hipStream_t stream) {
+    if (C <= 0) return hipSuccess;
+    hipLaunchKernelGGL(land_mask<T>, dim3(static_cast<unsigned>((C + 255) / 256)), dim3(256), 0, stream,
+                       ts, Tn, C, ld, anynans, keep);
+    return hipGetLastError();
+}
+template hipError_t launch_land_mask<float>(const float*, int64_t, int64_t, int64_t, int, uint8_t*,
+                                            hipStream_t);
+template hipError_t launch_land_mask<double>(const double*, int64_t, int64_t, int64_t, int, uint8_t*,
+                                             hipStream_t);
+
+// ---------------------------------------------------------------------------
+// synth_sst: counter-based synthetic SST
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double u01(uint64_t h) {  // (0,1)
+    return (static_cast<double>(h >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void synth_sst(T* __restrict__ ts, int64_t Tn, int64_t C, int64_t ld,
+                                                 int64_t cell0, uint64_t seed, double nan_frac) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const uint64_t cell = static_cast<uint64_t>(cell0 + c);
+    const uint64_t hc = mix64(seed * 0x100000001B3ull + cell);
+    const double A = 2.0 + 8.0 * u01(mix64(hc ^ 0xA1));
+    const double phi = 365.0 * u01(mix64(hc ^ 0xB2));
+    const double beta = 2.0 * u01(mix64(hc ^ 0xC3)) - 1.0;
+    const int64_t t_begin = static_cast<int64_t>(blockIdx.y) * 256;
+    const int64_t t_end = (t_begin + 256 < Tn) ? t_begin + 256 : Tn;
+    for (int64_t t = t_begin; t < t_end; ++t) {
+        const uint64_t h1 = mix64(hc + 0x9E3779B97F4A7C15ull * static_cast<uint64_t>(t + 1));
+        const uint64_t h2 = mix64(h1 ^ 0xD4);
+        const double u1 = u01(h1), u2 = u01(h2);
+        const double eps = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        double v = 15.0 + A * sin(6.283185307179586 * (static_cast<double>(t) - phi) / 365.25) +
+                   0.0005 * static_cast<double>(t) * beta + eps;
+        if (nan_frac > 0.0 && u01(mix64(h2 ^ 0xE5)) < nan_frac) v = make_nan();
+        ts[t * ld + c] = static_cast<T>(v);
+    }
+}
+
+template <typename T>
+hipError_t launch_synth(T* ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
+                        double nan_frac, hipStream_t stream) {
+    if (C <= 0 || Tn <= 0) return hipSuccess;
+    dim3 grid(static_cast<unsigned>((C + 255) / 256), static_cast<unsigned>((Tn + 255) / 256));
+    hipLaunchKernelGGL(synth_sst<T>, grid, dim3(256), 0, stream, ts, Tn, C, ld, cell0, seed, nan_frac);
+    return hipGetLastError();
+}
+template hipError_t launch_synth<float>(float*, int64_t, int64_t, int64_t, int64_t, uint64_t, double,
+                                        hipStream_t);
+template hipError_t launch_synth<double>(double*, int64_t, int64_t, int64_t, int64_t, uint64_t, double,
+                                         hipStream_t);
+
+}  // namespace xmhw

@@ -1,0 +1,63 @@
+// plan.h -- host-side plan: everything the kernels need that depends only on
+// the doy labels (the reference's window_roll()/groupby("doy") bookkeeping,
+// xmhw/identify.py:184-209, :233, :263).  Pure C++, no HIP calls here.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace xmhw {
+
+// Ring-kernel step table -------------------------------------------------
+// The time axis is cut into TRACKS: maximal runs of strictly increasing doy
+// label (one calendar year each on a daily axis; one cycle on a tstep axis).
+// Inside a track consecutive time steps have increasing labels, so when the
+// kernel walks the rows (distinct labels, ascending) a track's pool window
+// [t-w, t+w] slides by exactly one sample per row at which the track has a
+// centre.  Per (step, track) one 32-bit entry:
+//   bit 0      counted: the track has a centre at this row -> its window is
+//              part of this row's pool
+//   bits 1..31 code: 0 = HOLD (track has no centre at this row but has one
+//              before and after, e.g. doy 60 in a non-leap year: keep the
+//              window, do not advance);
+//              1 = PUSH an invalid sample (outside [0,T) or padding);
+//              >=2 = PUSH sample t = code - 2.
+// Steps run from step_min = -(2w) (window warm-up before row 0) to D-1.
+constexpr uint32_t kCodeHold = 0;
+constexpr uint32_t kCodeInvalid = 1;
+constexpr uint32_t make_entry(uint32_t code, bool counted) { return (code << 1) | (counted ? 1u : 0u); }
+
+struct Chunk {
+    int32_t warm_start;  // first step executed (ring warm-up, no output)
+    int32_t begin;       // first row with output
+    int32_t end;         // one past the last row with output
+};
+
+struct Plan {
+    int64_t T = 0;
+    int32_t w = 0;
+    int32_t R = 1;  // 2w+1
+    int32_t D = 0;
+    std::vector<int32_t> doys;       // [D] distinct labels ascending
+    std::vector<int32_t> row_of_t;   // [T]
+    int32_t ntracks = 0;
+    std::vector<int64_t> track_begin, track_end;  // [ntracks] time ranges
+    // generic kernel: CSR of centres per row
+    std::vector<int32_t> row_ptr;    // [D+1]
+    std::vector<int32_t> centres;    // [T]
+    int32_t max_centres = 0;         // max centres in a row
+    int32_t step_min = 0;            // -(R-1)
+    int32_t nsteps = 0;              // D + R - 1
+    int32_t kernel_choice = 0;       // XMHW_KERNEL_* requested (0 auto)
+    int32_t nchunks_req = 0;         // 0 auto
+
+    std::string error;
+
+    bool build(const int32_t* doy, int64_t T, int32_t w);
+    // table[nsteps][ntp], ntp = subs * yps >= ntracks; track k -> lane group
+    // (sub = k / yps, slot = k % yps)
+    std::vector<uint32_t> ring_table(int32_t subs, int32_t yps) const;
+    std::vector<Chunk> make_chunks(int32_t nchunks) const;
+};
+
+}  // namespace xmhw

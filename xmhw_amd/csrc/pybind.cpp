@@ -1,0 +1,191 @@
+// pybind.cpp -- thin pybind11 layer over the C ABI (include/xmhw_amd.h).
+// No logic lives here: argument unpacking, error code -> exception.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/xmhw_amd.h"
+
+namespace py = pybind11;
+
+namespace {
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct InvalidError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+void check(int rc) {
+    if (rc == XMHW_OK) return;
+    std::string msg = xmhw_last_error();
+    if (rc == XMHW_ERR_INVALID) throw InvalidError(msg);
+    if (rc == XMHW_ERR_NOMEM) throw std::bad_alloc();
+    throw HipError(msg + " (code " + std::to_string(rc) + ")");
+}
+
+inline void* vp(uintptr_t p) { return reinterpret_cast<void*>(p); }
+inline xmhw_plan* pp(uintptr_t p) { return reinterpret_cast<xmhw_plan*>(p); }
+
+using i32arr = py::array_t<int32_t, py::array::c_style | py::array::forcecast>;
+
+}  // namespace
+
+PYBIND11_MODULE(_xmhw_hip, m) {
+    m.doc() = "C-ABI bindings of the gfx950 xmhw threshold() path";
+    py::register_exception<HipError>(m, "HipError");
+    py::register_exception<InvalidError>(m, "InvalidArgument");
+
+    m.attr("KERNEL_AUTO") = XMHW_KERNEL_AUTO;
+    m.attr("KERNEL_RING") = XMHW_KERNEL_RING;
+    m.attr("KERNEL_GENERIC") = XMHW_KERNEL_GENERIC;
+
+    m.def("version", &xmhw_version);
+    m.def("arch", []() { return std::string(xmhw_arch()); });
+    m.def("device_count", []() { int n = 0; check(xmhw_device_count(&n)); return n; });
+    m.def("set_device", [](int d) { check(xmhw_set_device(d)); });
+    m.def("device_info", [](int d) {
+        char name[256] = {0};
+        int cus = 0;
+        uint64_t bytes = 0;
+        check(xmhw_device_info(d, name, sizeof(name), &cus, &bytes));
+        py::dict r;
+        r["name"] = std::string(name);
+        r["compute_units"] = cus;
+        r["hbm_bytes"] = bytes;
+        return r;
+    });
+
+    m.def("malloc", [](size_t n) { void* p = nullptr; check(xmhw_malloc(&p, n)); return reinterpret_cast<uintptr_t>(p); });
+    m.def("free", [](uintptr_t p) { check(xmhw_free(vp(p))); });
+    m.def("memcpy_h2d", [](uintptr_t dst, py::buffer src, uintptr_t stream) {
+        py::buffer_info bi = src.request();
+        check(xmhw_memcpy_h2d(vp(dst), bi.ptr, static_cast<size_t>(bi.size) * bi.itemsize, vp(stream)));
+    }, py::arg("dst"), py::arg("src"), py::arg("stream") = 0);
+    m.def("memcpy_d2h", [](py::buffer dst, uintptr_t src, uintptr_t stream) {
+        py::buffer_info bi = dst.request(true);
+        check(xmhw_memcpy_d2h(bi.ptr, vp(src), static_cast<size_t>(bi.size) * bi.itemsize, vp(stream)));
+    }, py::arg("dst"), py::arg("src"), py::arg("stream") = 0);
+    m.def("memcpy_d2h_bytes", [](py::buffer dst, uintptr_t src, size_t nbytes, uintptr_t stream) {
+        py::buffer_info bi = dst.request(true);
+        if (nbytes > static_cast<size_t>(bi.size) * bi.itemsize) throw InvalidError("destination too small");
+        check(xmhw_memcpy_d2h(bi.ptr, vp(src), nbytes, vp(stream)));
+    }, py::arg("dst"), py::arg("src"), py::arg("nbytes"), py::arg("stream") = 0);
+    m.def("memset", [](uintptr_t dst, int v, size_t n, uintptr_t stream) { check(xmhw_memset(vp(dst), v, n, vp(stream))); },
+          py::arg("dst"), py::arg("value"), py::arg("nbytes"), py::arg("stream") = 0);
+    m.def("stream_create", []() { void* s = nullptr; check(xmhw_stream_create(&s)); return reinterpret_cast<uintptr_t>(s); });
+    m.def("stream_destroy", [](uintptr_t s) { check(xmhw_stream_destroy(vp(s))); });
+    m.def("stream_sync", [](uintptr_t s) { py::gil_scoped_release r; check(xmhw_stream_sync(vp(s))); }, py::arg("stream") = 0);
+    m.def("event_create", []() { void* e = nullptr; check(xmhw_event_create(&e)); return reinterpret_cast<uintptr_t>(e); });
+    m.def("event_destroy", [](uintptr_t e) { check(xmhw_event_destroy(vp(e))); });
+    m.def("event_record", [](uintptr_t e, uintptr_t s) { check(xmhw_event_record(vp(e), vp(s))); }, py::arg("event"), py::arg("stream") = 0);
+    m.def("event_elapsed_ms", [](uintptr_t a, uintptr_t b) { float ms = 0; check(xmhw_event_elapsed_ms(vp(a), vp(b), &ms)); return ms; });
+
+    m.def("plan_create", [](i32arr doy, int w) {
+        xmhw_plan* p = nullptr;
+        check(xmhw_plan_create(doy.data(), doy.size(), w, &p));
+        return reinterpret_cast<uintptr_t>(p);
+    });
+    m.def("plan_destroy", [](uintptr_t p) { check(xmhw_plan_destroy(pp(p))); });
+    m.def("plan_info", [](uintptr_t p) {
+        int32_t D, nt, k, ns, smin;
+        check(xmhw_plan_info(pp(p), &D, &nt, &k, &ns, &smin));
+        py::dict r;
+        r["D"] = D; r["ntracks"] = nt; r["kernel"] = k; r["nsteps"] = ns; r["step_min"] = smin;
+        return r;
+    });
+    m.def("plan_doys", [](uintptr_t p) {
+        int32_t D;
+        check(xmhw_plan_info(pp(p), &D, nullptr, nullptr, nullptr, nullptr));
+        py::array_t<int32_t> out(D);
+        check(xmhw_plan_doys(pp(p), out.mutable_data()));
+        return out;
+    });
+    m.def("plan_set_kernel", [](uintptr_t p, int k) { check(xmhw_plan_set_kernel(pp(p), k)); });
+    m.def("plan_set_chunks", [](uintptr_t p, int n) { check(xmhw_plan_set_chunks(pp(p), n)); });
+    m.def("plan_table", [](uintptr_t p, int yps) {
+        int32_t ns, ntp;
+        check(xmhw_plan_info(pp(p), nullptr, nullptr, nullptr, &ns, nullptr));
+        check(xmhw_plan_table(pp(p), yps, nullptr, &ntp));
+        py::array_t<uint32_t> out({static_cast<py::ssize_t>(ns), static_cast<py::ssize_t>(ntp)});
+        check(xmhw_plan_table(pp(p), yps, out.mutable_data(), &ntp));
+        return out;
+    });
+
+    m.def("clim_raw", [](uintptr_t plan, uintptr_t ts, int itemsize, int64_t C, int64_t ld, double q, int negate,
+                         uintptr_t th, uintptr_t se, int64_t ldo, uintptr_t stream) {
+        if (itemsize == 4)
+            check(xmhw_clim_raw_f32(pp(plan), static_cast<const float*>(vp(ts)), C, ld, q, negate,
+                                    static_cast<double*>(vp(th)), static_cast<double*>(vp(se)), ldo, vp(stream)));
+        else if (itemsize == 8)
+            check(xmhw_clim_raw_f64(pp(plan), static_cast<const double*>(vp(ts)), C, ld, q, negate,
+                                    static_cast<double*>(vp(th)), static_cast<double*>(vp(se)), ldo, vp(stream)));
+        else throw InvalidError("itemsize must be 4 or 8");
+    }, py::arg("plan"), py::arg("ts"), py::arg("itemsize"), py::arg("C"), py::arg("ld"), py::arg("q"),
+       py::arg("negate"), py::arg("thresh"), py::arg("seas"), py::arg("ldo"), py::arg("stream") = 0);
+
+    m.def("clim_finish", [](uintptr_t plan, uintptr_t th_in, uintptr_t se_in, int64_t C, int64_t ldo, int feb29_fix,
+                            int smooth, int width, uintptr_t th_out, uintptr_t se_out, uintptr_t stream) {
+        check(xmhw_clim_finish(pp(plan), static_cast<const double*>(vp(th_in)), static_cast<const double*>(vp(se_in)),
+                               C, ldo, feb29_fix, smooth, width, static_cast<double*>(vp(th_out)),
+                               static_cast<double*>(vp(se_out)), vp(stream)));
+    }, py::arg("plan"), py::arg("thresh_in"), py::arg("seas_in"), py::arg("C"), py::arg("ldo"),
+       py::arg("feb29_fix"), py::arg("smooth"), py::arg("width"), py::arg("thresh_out"), py::arg("seas_out"),
+       py::arg("stream") = 0);
+
+    m.def("clim_dev", [](uintptr_t ts, int itemsize, i32arr doy, int64_t C, int D, int w, double q, int smooth,
+                         int smooth_w, int feb29_fix, int negate, uintptr_t th, uintptr_t se, uintptr_t stream) {
+        py::gil_scoped_release r;
+        if (itemsize == 4)
+            check(xmhw_clim_f32(static_cast<const float*>(vp(ts)), doy.data(), doy.size(), C, D, w, q, smooth, smooth_w,
+                                feb29_fix, negate, static_cast<double*>(vp(th)), static_cast<double*>(vp(se)), vp(stream)));
+        else if (itemsize == 8)
+            check(xmhw_clim_f64(static_cast<const double*>(vp(ts)), doy.data(), doy.size(), C, D, w, q, smooth, smooth_w,
+                                feb29_fix, negate, static_cast<double*>(vp(th)), static_cast<double*>(vp(se)), vp(stream)));
+        else throw InvalidError("itemsize must be 4 or 8");
+    });
+
+    m.def("clim_host", [](py::array ts, i32arr doy, int D, int w, double q, int smooth, int smooth_w, int feb29_fix,
+                          int negate) {
+        if (ts.ndim() != 2) throw InvalidError("ts must be (T, C)");
+        if (!(ts.flags() & py::array::c_style)) throw InvalidError("ts must be C-contiguous");
+        if (ts.shape(0) != doy.size()) throw InvalidError("doy length must equal T");
+        const int64_t T = ts.shape(0), C = ts.shape(1);
+        py::array_t<double> th({static_cast<py::ssize_t>(D), static_cast<py::ssize_t>(C)});
+        py::array_t<double> se({static_cast<py::ssize_t>(D), static_cast<py::ssize_t>(C)});
+        int rc;
+        if (ts.dtype().is(py::dtype::of<float>())) {
+            py::gil_scoped_release r;
+            rc = xmhw_clim_host_f32(static_cast<const float*>(ts.data()), doy.data(), T, C, D, w, q, smooth, smooth_w,
+                                    feb29_fix, negate, th.mutable_data(), se.mutable_data());
+        } else if (ts.dtype().is(py::dtype::of<double>())) {
+            py::gil_scoped_release r;
+            rc = xmhw_clim_host_f64(static_cast<const double*>(ts.data()), doy.data(), T, C, D, w, q, smooth, smooth_w,
+                                    feb29_fix, negate, th.mutable_data(), se.mutable_data());
+        } else {
+            throw InvalidError("ts dtype must be float32 or float64");
+        }
+        check(rc);
+        return py::make_tuple(th, se);
+    });
+
+    m.def("land_mask", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, int anynans, uintptr_t keep,
+                          uintptr_t stream) {
+        if (itemsize == 4)
+            check(xmhw_land_mask_f32(static_cast<const float*>(vp(ts)), T, C, ld, anynans, static_cast<uint8_t*>(vp(keep)), vp(stream)));
+        else if (itemsize == 8)
+            check(xmhw_land_mask_f64(static_cast<const double*>(vp(ts)), T, C, ld, anynans, static_cast<uint8_t*>(vp(keep)), vp(stream)));
+        else throw InvalidError("itemsize must be 4 or 8");
+    }, py::arg("ts"), py::arg("itemsize"), py::arg("T"), py::arg("C"), py::arg("ld"), py::arg("anynans"),
+       py::arg("keep"), py::arg("stream") = 0);
+
+    m.def("synth_sst", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
+                          double nan_frac, uintptr_t stream) {
+        if (itemsize == 4)
+            check(xmhw_synth_sst_f32(static_cast<float*>(vp(ts)), T, C, ld, cell0, seed, nan_frac, vp(stream)));
+        else if (itemsize == 8)
+            check(xmhw_synth_sst_f64(static_cast<double*>(vp(ts)), T, C, ld, cell0, seed, nan_frac, vp(stream)));
+        else throw InvalidError("itemsize must be 4 or 8");
+    }, py::arg("ts"), py::arg("itemsize"), py::arg("T"), py::arg("C"), py::arg("ld"), py::arg("cell0"),
+       py::arg("seed"), py::arg("nan_frac") = 0.0, py::arg("stream") = 0);
+}

@@ -1,0 +1,37 @@
+"""land_check() of the reference (xmhw/identify.py:482-529) on plain arrays:
+stack the non-time dims (sorted by name) into 'cell', drop all-NaN cells
+(any-NaN with anynans), raise XmhwException on degenerate grids."""
+import numpy as np
+
+from .exception import XmhwException
+
+
+def stack_cells(values, dims, tdim):
+    """Return (stacked[T, Ncell] view/copy, stacked dim names, stacked shape)."""
+    dims = list(dims)
+    rest = [d for d in dims if d != tdim]
+    if len(rest) == 0:
+        raise XmhwException("Series has only time dimension use point=True option, exiting")
+    for d in rest:
+        if values.shape[dims.index(d)] == 0:
+            raise XmhwException(f"Dimension {d} has 0 lenght, exiting")
+    order = sorted(rest)
+    perm = [dims.index(tdim)] + [dims.index(d) for d in order]
+    v = np.transpose(values, perm)
+    sshape = v.shape[1:]
+    return v.reshape(v.shape[0], -1), order, tuple(sshape)
+
+
+def keep_mask(stacked, anynans=False):
+    nan = np.isnan(stacked)
+    drop = nan.any(axis=0) if anynans else nan.all(axis=0)
+    keep = ~drop
+    if not keep.any():
+        raise XmhwException("All points of grid are either land or NaN")
+    return keep
+
+
+def land_check(values, dims, tdim="time", anynans=False):
+    stacked, order, sshape = stack_cells(values, dims, tdim)
+    keep = keep_mask(stacked, anynans)
+    return np.ascontiguousarray(stacked[:, keep]), keep, order, sshape
