@@ -57,3 +57,17 @@ def test_fast_matches_dumb_tstep_and_cold():
     npt.assert_array_equal(d0, np.arange(1, n + 1))
     npt.assert_allclose(t1, t0, rtol=1e-13, equal_nan=True)
     npt.assert_allclose(s1, s0, rtol=1e-13, equal_nan=True)
+
+
+def test_percell_baseline_matches_dumb():
+    import oracle_percell as opc
+    time = np.arange("2001-01-01", "2005-01-01", dtype="datetime64[D]")
+    doy = ora.add_doy(time)
+    x = _series(time.shape[0], 5, 31, 0.05)
+    x[(doy >= 100) & (doy <= 140), 2] = np.nan
+    for kw in (dict(), dict(smoothPercentile=False, skipna=True), dict(coldSpells=True, pctile=10, windowHalfWidth=2)):
+        d0, t0, s0 = ora.threshold_cells(x, doy, **kw)
+        d1, t1, s1 = opc.threshold_cells_percell(x, doy, **kw)
+        npt.assert_array_equal(d0, d1)
+        npt.assert_array_equal(t1, t0)
+        npt.assert_array_equal(s1, s0)
