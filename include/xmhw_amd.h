@@ -83,6 +83,10 @@ int xmhw_plan_set_chunks(xmhw_plan *plan, int32_t nchunks); /* 0 = auto         
 int xmhw_plan_table(const xmhw_plan *plan, int32_t years_per_lane, uint32_t *table_out,
                     int32_t *ntracks_padded);
 
+/* debug: ring-kernel pass counters {rows, count passes, extractions, cold starts}
+ * summed over waves since the last read; enable != 0 allocates the counters    */
+int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out4);
+
 /* ---- the hot path ------------------------------------------------------ *
  * xmhw_clim_raw_*: for every cell, the pooled linear-interpolated quantile
  * and the pooled mean per doy -- calculate_thresh()/calculate_seas() WITHOUT

@@ -46,8 +46,10 @@ struct xmhw_plan {
     xmhw::DevChunk* d_chunks = nullptr;
     int32_t* d_row_ptr = nullptr;
     int32_t* d_centres = nullptr;
+    unsigned long long* d_stats = nullptr;  // debug: ring kernel pass counters (xmhw_plan_debug_stats)
 
     ~xmhw_plan() {
+        if (d_stats) (void)hipFree(d_stats);
         if (d_table) (void)hipFree(d_table);
         if (d_chunks) (void)hipFree(d_chunks);
         if (d_row_ptr) (void)hipFree(d_row_ptr);
@@ -130,7 +132,7 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
         if constexpr (sizeof(T) == 4) {
             e = xmhw::launch_ring_f32(reinterpret_cast<const float*>(ts), C, ld, plan->d_table,
                                       h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps, q,
-                                      negate, thresh, seas, ldo, st);
+                                      negate, thresh, seas, ldo, st, plan->d_stats);
         } else {
             return fail(XMHW_ERR_UNSUPPORTED, "ring kernel is float32 only");
         }
@@ -362,6 +364,20 @@ int xmhw_plan_set_chunks(xmhw_plan* plan, int32_t nchunks) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
     if (nchunks < 0) return fail(XMHW_ERR_INVALID, "nchunks must be >= 0");
     plan->host.nchunks_req = nchunks;
+    return XMHW_OK;
+}
+int xmhw_plan_debug_stats(xmhw_plan* plan, int enable, uint64_t* out4) {
+    if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
+    if (enable && !plan->d_stats) {
+        HIP_TRY(hipMalloc(&plan->d_stats, 4 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(plan->d_stats, 0, 4 * sizeof(unsigned long long)));
+    }
+    if (out4) {
+        if (!plan->d_stats) return fail(XMHW_ERR_INVALID, "stats not enabled");
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out4, plan->d_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(plan->d_stats, 0, 4 * sizeof(unsigned long long)));
+    }
     return XMHW_OK;
 }
 int xmhw_plan_table(const xmhw_plan* plan, int32_t years_per_lane, uint32_t* table_out,

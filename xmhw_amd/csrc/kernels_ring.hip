@@ -40,6 +40,17 @@ constexpr int kSubs = 8;
 constexpr int kCellsPerWave = 8;
 constexpr int kWavesPerBlock = 4;
 
+// Lane map: lane = (c >> 1) * 16 + sub * 2 + (c & 1), c = cell in wave (0..7).
+// The 8 subs of a cell sit in ONE 16-lane DPP row at stride 2, so the per-cell
+// all-reduce is three full-rate DPP row rotations (row_ror 8, 4, 2) instead of
+// LDS-pipe ds_bpermute (measured 24 cycles each vs 4.5, tools/ubench_valu.hip).
+// A ts row is still read as 8 x 4 = 32 contiguous bytes per wave.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), CTRL, 0xF, 0xF, false));
+}
+constexpr int kRor8 = 0x128, kRor4 = 0x124, kRor2 = 0x122;
+
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -48,17 +59,23 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
-// all-reduce over the 8 subs of a cell: lanes l ^ {8,16,32}
 __device__ __forceinline__ uint32_t sub_sum(uint32_t v) {
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
+    v += dpp_mov<kRor8>(v);
+    v += dpp_mov<kRor4>(v);
+    v += dpp_mov<kRor2>(v);
     return v;
 }
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const uint64_t b = static_cast<uint64_t>(__double_as_longlong(v));
+    const uint32_t lo = dpp_mov<CTRL>(static_cast<uint32_t>(b));
+    const uint32_t hi = dpp_mov<CTRL>(static_cast<uint32_t>(b >> 32));
+    return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
+}
 __device__ __forceinline__ double sub_sum(double v) {
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
+    v += dpp_mov_f64<kRor8>(v);
+    v += dpp_mov_f64<kRor4>(v);
+    v += dpp_mov_f64<kRor2>(v);
     return v;
 }
 // merge two ascending pairs, keep the two smallest
@@ -68,30 +85,76 @@ __device__ __forceinline__ void min2_merge(uint32_t& a1, uint32_t& a2, uint32_t 
     a2 = umin(hi, umin(a2, b2));
 }
 __device__ __forceinline__ void sub_min2(uint32_t& m1, uint32_t& m2) {
-#pragma unroll
-    for (int x = 8; x <= 32; x <<= 1) {
-        const uint32_t b1 = __shfl_xor(m1, x);
-        const uint32_t b2 = __shfl_xor(m2, x);
-        min2_merge(m1, m2, b1, b2);
-    }
+    min2_merge(m1, m2, dpp_mov<kRor8>(m1), dpp_mov<kRor8>(m2));
+    min2_merge(m1, m2, dpp_mov<kRor4>(m1), dpp_mov<kRor4>(m2));
+    min2_merge(m1, m2, dpp_mov<kRor2>(m1), dpp_mov<kRor2>(m2));
 }
 
 __device__ __forceinline__ double key_value(uint32_t k) {
     return k ? static_cast<double>(key_f32(k)) : 0.0;
 }
 
+// J smallest (position-wise, ties repeated) distances above a pivot, ascending.
+// insert(): one v_med3_u32 per rank + one v_min_u32.
+template <int J>
+struct TopJ {
+    uint32_t m[J];
+    __device__ __forceinline__ void reset() {
+#pragma unroll
+        for (int i = 0; i < J; ++i) m[i] = 0xFFFFFFFFu;
+    }
+    __device__ __forceinline__ void insert(uint32_t d) {
+#pragma unroll
+        for (int i = J - 1; i >= 1; --i) m[i] = umed3(m[i - 1], m[i], d);
+        m[0] = umin(m[0], d);
+    }
+    template <int CTRL>
+    __device__ __forceinline__ void merge_dpp() {
+        uint32_t b[J];
+#pragma unroll
+        for (int i = 0; i < J; ++i) b[i] = dpp_mov<CTRL>(m[i]);
+#pragma unroll
+        for (int i = 0; i < J; ++i) insert(b[i]);
+    }
+    __device__ __forceinline__ void sub_merge() {
+        merge_dpp<kRor8>();
+        merge_dpp<kRor4>();
+        merge_dpp<kRor2>();
+    }
+    __device__ __forceinline__ uint32_t at(uint32_t j) const {  // m[j], j uniform per cell
+        uint32_t r = m[0];
+#pragma unroll
+        for (int i = 1; i < J; ++i) r = (j == static_cast<uint32_t>(i)) ? m[i] : r;
+        return r;
+    }
+    __device__ __forceinline__ uint32_t count_below(uint32_t d) const {  // #{m[i] < d}
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < J; ++i) c += (m[i] < d) ? 1u : 0u;
+        return c;
+    }
+};
+
+constexpr int kTopJ = 5;          // extraction width
+constexpr int kCountBudget = 6;   // count passes before the first extraction
+
 template <int W, int YPS>
 __global__ __launch_bounds__(256) void clim_ring_f32(
     const float* __restrict__ ts, int64_t C, int64_t ld, const uint32_t* __restrict__ table,
     int32_t step_min, const DevChunk* __restrict__ chunks, double q, int negate,
-    double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo) {
+    double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
+    unsigned long long* __restrict__ stats) {
     constexpr int R = 2 * W + 1;
     constexpr int NTP = kSubs * YPS;
+    constexpr uint32_t NSLOT = static_cast<uint32_t>(NTP) * R;
+    constexpr int J = kTopJ;
+    constexpr uint32_t SLACK = J - 2;  // a[lo], a[lo+1] are among the J keys above pl iff lo - F(pl) <= J-2
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int sub = lane >> 3;
+    const int sub = (lane >> 1) & 7;
+    const int cw = (lane & 1) | ((lane >> 4) << 1);
     const int64_t cell =
-        (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave) * kCellsPerWave + (lane & 7);
+        (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave) * kCellsPerWave + cw;
     const bool cell_ok = cell < C;
     const DevChunk ch = chunks[blockIdx.y];
     const uint32_t* tab = table + sub * YPS;
@@ -135,9 +198,16 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
     }
 
     int m = (ch.warm_start - step_min) % R;
-    uint32_t p_prev = 0;
-    bool warm = false;
-    float rho = 8192.0f;
+    // Carried across rows, uniform over the 8 lanes of a cell:
+    //   pc / Fc   pivot with the raw count #{ring keys <= pc over ALL slots}, kept
+    //             exact by adding the per-step difference of the pushed / evicted
+    //             keys -> the first "probe" of a row costs 2 ops per pushed key
+    //   kpr       keys per rank observed on the previous row (local density and
+    //             seasonal drift together), used to aim the first real probe
+    uint32_t pc = 0, Fc = NSLOT;
+    bool have_c = false;
+    float kpr = 8192.0f;
+    uint32_t st_count = 0, st_extract = 0, st_rows = 0, st_cold = 0;  // debug counters (wave-uniform)
 
     for (int32_t s = ch.warm_start; s < ch.end; ++s) {
         // ---- prefetch: samples of step s+1, table entries of step s+2 ------------
@@ -153,14 +223,16 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
         // ---- advance the rings -----------------------------------------------------
         uint32_t kin[YPS], kout[YPS];
         bool hold[YPS], counted[YPS];
-        bool any_hold = false;
+        bool any_hold = false, all_counted = true;
 #pragma unroll
         for (int y = 0; y < YPS; ++y) {
             counted[y] = (e_cur[y] & 1u) != 0;
             hold[y] = (e_cur[y] >> 1) == kCodeHold;
             any_hold |= hold[y];
+            all_counted &= counted[y];
             float xv = x_cur[y];
             if (negate) xv = -xv;
+            x_cur[y] = xv;
             kin[y] = f32_key(xv);  // NaN / not loaded -> 0 (invalid)
         }
 #define XMHW_RING_CASE(K)                                                  \
@@ -182,15 +254,19 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
         }
 #undef XMHW_RING_CASE
         m = (m + 1 == R) ? 0 : m + 1;
+        uint32_t dF = 0;  // change of #{keys <= pc} in this lane (two's complement)
 #pragma unroll
         for (int y = 0; y < YPS; ++y) {
             if (!hold[y]) {
-                tsum[y] += key_value(kin[y]);
+                const float xin = (kin[y] != 0) ? x_cur[y] : 0.0f;
+                tsum[y] += static_cast<double>(xin);
                 tsum[y] -= key_value(kout[y]);
                 nval[y] += (kin[y] != 0 ? 1u : 0u) - (kout[y] != 0 ? 1u : 0u);
+                dF += (kin[y] <= pc ? 1u : 0u) - (kout[y] <= pc ? 1u : 0u);
             }
         }
-        if (__any(any_hold)) {
+        const bool wave_hold = __any(any_hold);
+        if (wave_hold) {
             // a held track did not advance: rotate its window one slot so that its
             // oldest sample sits where the next step's PUSH will land
 #pragma unroll
@@ -204,6 +280,7 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
 
         // ---- select + output (not during warm-up) ---------------------------------
         if (s >= ch.begin) {
+            const bool allc = __all(all_counted);  // wave-uniform: no masking needed
             uint32_t nl = 0, ncl = 0;
             double tl = 0.0;
 #pragma unroll
@@ -213,8 +290,9 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
                 tl += counted[y] ? tsum[y] : 0.0;
             }
             const uint32_t n = sub_sum(nl);
-            const uint32_t ninv = static_cast<uint32_t>(R) * sub_sum(ncl) - n;  // counted invalid keys
+            const uint32_t ninv = (allc ? NSLOT : static_cast<uint32_t>(R) * sub_sum(ncl)) - n;
             const double total = sub_sum(tl);
+            Fc += sub_sum(dF);  // raw count at the carried pivot, now for this row's rings
 
             const uint32_t nn = n ? n : 1u;
             const double vi = static_cast<double>(nn - 1) * q;
@@ -223,101 +301,169 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
             const uint32_t lo = static_cast<uint32_t>(fl);
             const bool need2 = lo + 1 < nn;
 
-            // F(p) = #{valid counted keys <= p}
+            // raw count #{counted ring keys <= p}; invalid keys (0) are <= any pivot
             auto count_le = [&](uint32_t p) -> uint32_t {
                 uint32_t c = 0;
+                if (allc) {
 #pragma unroll
-                for (int y = 0; y < YPS; ++y) {
-                    uint32_t cy = 0;
+                    for (int y = 0; y < YPS; ++y)
 #pragma unroll
-                    for (int k = 0; k < R; ++k) cy += (ring[y][k] <= p) ? 1u : 0u;
-                    c += counted[y] ? cy : 0u;
-                }
-                return sub_sum(c) - ninv;
-            };
-
-            if (!warm) {  // cold start of a chunk: begin at the pool mean
-                p_prev = f32_key(static_cast<float>(total / static_cast<double>(nn)));
-                if (p_prev == 0) p_prev = 0x80000000u;
-            }
-            uint32_t pl = 0, Fl = 0, ph = 0xFFFFFFFFu, Fh = nn;
-            bool lreal = false, hreal = false;
-            bool done = (n == 0);
-            float grow = 1.0f;
-            for (int it = 0;; ++it) {
-                if (!done && (Fl == lo || ph - pl <= 1u)) done = true;
-                if (__all(done)) break;
-                const uint32_t room = ph - pl;  // >= 2 for lanes not done
-                uint32_t off;
-                if (it == 0) {
-                    off = (p_prev - 1u) - pl;  // pl == 0 here
-                } else if (it < 7 && lreal && hreal) {
-                    const float frac = static_cast<float>(lo - Fl) / static_cast<float>(Fh - Fl);
-                    off = static_cast<uint32_t>(static_cast<float>(room) * frac);
-                } else if (it < 7 && lreal) {
-                    const float st = static_cast<float>(lo - Fl) * rho * grow;
-                    off = st < 2.0e9f ? static_cast<uint32_t>(st) : 2000000000u;
-                    grow *= 2.0f;
-                } else if (it < 7 && hreal) {
-                    const float st = static_cast<float>(Fh - lo) * rho * grow;
-                    const uint32_t back = st < 2.0e9f ? static_cast<uint32_t>(st) : 2000000000u;
-                    off = room > back ? room - back : 1u;
-                    grow *= 2.0f;
+                        for (int k = 0; k < R; ++k) c += (ring[y][k] <= p) ? 1u : 0u;
                 } else {
-                    off = room >> 1;
-                }
-                off = umax(1u, umin(off, room - 1u));
-                const uint32_t p = done ? pl : pl + off;
-                const uint32_t F = count_le(p);
-                if (!done) {
-                    if (F <= lo) {
-                        if (!lreal) grow = 1.0f;
-                        pl = p; Fl = F; lreal = true;
-                    } else {
-                        if (!hreal) grow = 1.0f;
-                        ph = p; Fh = F; hreal = true;
+#pragma unroll
+                    for (int y = 0; y < YPS; ++y) {
+                        uint32_t cy = 0;
+#pragma unroll
+                        for (int k = 0; k < R; ++k) cy += (ring[y][k] <= p) ? 1u : 0u;
+                        c += counted[y] ? cy : 0u;
                     }
                 }
+                return sub_sum(c);
+            };
+
+            // bracket: F(pl) = Fl <= lo < Fh = F(ph), F = #{valid counted keys <= .}
+            uint32_t pl = 0, Fl = 0, ph = 0xFFFFFFFFu, Fh = nn;
+            bool lreal = false, hreal = false;
+            float grow = 1.0f;
+            const bool use_c = have_c && allc;
+            uint32_t p0 = pc, F0 = 0;
+            if (use_c) F0 = Fc - ninv;  // free probe: the carried pivot
+            if (!__all(use_c || n == 0)) {
+                // cold start (first row of a chunk, masked row): one real pass at the
+                // carried pivot if there is one, else at the pool mean
+                uint32_t pm = f32_key(static_cast<float>(total / static_cast<double>(nn)));
+                if (pm == 0) pm = 0x80000000u;
+                if (!use_c) p0 = have_c ? pc : pm;
+                const uint32_t Fr = count_le(p0);
+                if (!use_c) F0 = Fr - ninv;
+                ++st_cold;
+            }
+            if (p0 != 0 && p0 != 0xFFFFFFFFu) {
+                if (F0 <= lo) { pl = p0; Fl = F0; lreal = true; }
+                else { ph = p0; Fh = F0; hreal = true; }
+            }
+            const uint32_t p_first = p0;
+            const int32_t rank_gap = static_cast<int32_t>(lo) - static_cast<int32_t>(F0);
+            // probes aim at the middle of the window of acceptable ranks
+            const float aim = static_cast<float>(lo) - 0.5f * static_cast<float>(SLACK) + 0.5f;
+
+            bool resolved = (n == 0);
+            uint32_t alo = 0, ahi = 0, pe = 0, Fe = 0;
+            int budget = kCountBudget;
+            for (;;) {
+                // ---- count passes until every cell can be settled by one extraction ----
+                for (int it = 0;; ++it) {
+                    const bool settle = resolved || (lo - Fl <= SLACK) || (ph - pl <= 1u);
+                    if (__all(settle) || it >= budget) break;
+                    const uint32_t room = ph - pl;
+                    uint32_t off;
+                    if (it < 5 && lreal && hreal) {
+                        float frac = (aim - static_cast<float>(Fl)) / static_cast<float>(Fh - Fl);
+                        frac = fminf(fmaxf(frac, 0.0f), 1.0f);
+                        off = static_cast<uint32_t>(static_cast<float>(room) * frac);
+                    } else if (it < 5 && lreal) {
+                        const float st = (aim - static_cast<float>(Fl)) * kpr * grow;
+                        off = st < 2.0e9f ? static_cast<uint32_t>(fmaxf(st, 1.0f)) : 2000000000u;
+                        grow *= 2.0f;
+                    } else if (it < 5 && hreal) {
+                        const float st = (static_cast<float>(Fh) - aim) * kpr * grow;
+                        const uint32_t back = st < 2.0e9f ? static_cast<uint32_t>(fmaxf(st, 1.0f)) : 2000000000u;
+                        off = room > back ? room - back : 1u;
+                        grow *= 2.0f;
+                    } else {
+                        off = room >> 1;
+                    }
+                    off = umax(1u, umin(off, room - 1u));
+                    const uint32_t p = settle ? pl : pl + off;
+                    const uint32_t F = count_le(p) - ninv;
+                    ++st_count;
+                    if (!settle) {
+                        if (F <= lo) {
+                            if (!lreal) grow = 1.0f;
+                            pl = p; Fl = F; lreal = true;
+                        } else {
+                            if (!hreal) grow = 1.0f;
+                            ph = p; Fh = F; hreal = true;
+                        }
+                    }
+                }
+                // ---- extraction: the J smallest keys above the pivot --------------------
+                const bool window = (lo - Fl <= SLACK);
+                const bool adjacent = !window && (ph - pl <= 1u);
+                const uint32_t px = adjacent ? ph : pl;
+                const uint32_t base = px + 1u;
+                TopJ<J> top;
+                top.reset();
+                if (allc) {
+#pragma unroll
+                    for (int y = 0; y < YPS; ++y)
+#pragma unroll
+                        for (int k = 0; k < R; ++k) top.insert(ring[y][k] - base);  // keys <= px wrap high
+                } else {
+#pragma unroll
+                    for (int y = 0; y < YPS; ++y)
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+                            const uint32_t d = ring[y][k] - base;
+                            top.insert(counted[y] ? d : 0xFFFFFFFFu);
+                        }
+                }
+                top.sub_merge();
+                ++st_extract;
+                if (!resolved) {
+                    if (window) {
+                        const uint32_t j = lo - Fl;
+                        alo = base + top.at(j);
+                        ahi = need2 ? base + top.at(j + 1u) : alo;
+                        pe = pl; Fe = Fl;
+                        resolved = true;
+                    } else if (adjacent) {
+                        // every key at sorted positions Fl .. Fh-1 equals ph
+                        alo = ph;
+                        ahi = (need2 && lo + 1u >= Fh) ? base + top.m[0] : ph;
+                        pe = ph; Fe = Fh;
+                        resolved = true;
+                    }
+                }
+                if (__all(resolved)) break;
+                // ---- repair (tie-heavy data): count at the largest extracted key ---------
+                const uint32_t dj = top.m[J - 1];
+                const uint32_t pj = base + dj;            // an element key, > pl
+                const uint32_t Fj = count_le(resolved ? pl : pj) - ninv;
+                ++st_count;
+                if (!resolved) {
+                    if (Fj <= lo) {
+                        pl = pj; Fl = Fj; lreal = true;
+                    } else {
+                        // no key lies strictly between pl and pj except the extracted ones
+                        ph = pj; Fh = Fj; hreal = true;
+                        Fl = Fl + top.count_below(dj);
+                        pl = pj - 1u;
+                    }
+                }
+                budget = 2;
             }
 
-            // extract the two smallest keys above the pivot
-            const bool type_a = (Fl == lo);
-            const uint32_t pe = type_a ? pl : ph;
-            const uint32_t base = pe + 1u;
-            uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
-#pragma unroll
-            for (int y = 0; y < YPS; ++y) {
-                uint32_t a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu;
-#pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    const uint32_t d = ring[y][k] - base;  // keys <= pe wrap to huge distances
-                    a2 = umed3(a1, a2, d);
-                    a1 = umin(a1, d);
-                }
-                if (!counted[y]) { a1 = 0xFFFFFFFFu; a2 = 0xFFFFFFFFu; }
-                min2_merge(m1, m2, a1, a2);
-            }
-            sub_min2(m1, m2);
-            const uint32_t k1 = base + m1, k2 = base + m2;
-            uint32_t alo, ahi;
-            if (type_a) {
-                alo = k1;
-                ahi = need2 ? k2 : k1;
-            } else {
-                alo = ph;
-                ahi = (need2 && lo + 1u >= Fh) ? k1 : ph;
-            }
+            ++st_rows;
             double th = make_nan(), se = make_nan();
             if (n > 0) {
                 th = numpy_lerp(static_cast<double>(key_f32(alo)), static_cast<double>(key_f32(ahi)), g);
                 se = total / static_cast<double>(n);
-                p_prev = alo;
-                warm = true;
-                if (ahi > alo) {
-                    const uint32_t gap = ahi - alo;
-                    rho = 0.75f * rho + 0.25f * static_cast<float>(gap < (1u << 24) ? gap : (1u << 24));
-                    rho = rho < 1.0f ? 1.0f : rho;
+                // calibrate keys-per-rank on what this row needed, carry the pivot
+                if (rank_gap > 1 || rank_gap < -1) {
+                    const float obs = (static_cast<float>(alo) - static_cast<float>(p_first)) /
+                                      static_cast<float>(rank_gap);
+                    if (obs >= 1.0f && obs < 1.0e8f) kpr = 0.5f * kpr + 0.5f * obs;
                 }
+            }
+            if (n > 0 && allc) {
+                pc = pe;
+                Fc = Fe + ninv;
+                have_c = true;
+            } else {
+                have_c = false;
+                pc = 0;
+                Fc = 0;
             }
             if (sub == 0 && cell_ok) {
                 thresh[static_cast<int64_t>(s) * ldo + cell] = th;
@@ -333,6 +479,12 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
             x_cur[y] = x_nxt[y];
         }
     }
+    if (stats != nullptr && lane == 0) {
+        atomicAdd(&stats[0], static_cast<unsigned long long>(st_rows));
+        atomicAdd(&stats[1], static_cast<unsigned long long>(st_count));
+        atomicAdd(&stats[2], static_cast<unsigned long long>(st_extract));
+        atomicAdd(&stats[3], static_cast<unsigned long long>(st_cold));
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -340,7 +492,7 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
 // ---------------------------------------------------------------------------
 namespace {
 typedef void (*RingKernel)(const float*, int64_t, int64_t, const uint32_t*, int32_t, const DevChunk*,
-                           double, int, double*, double*, int64_t);
+                           double, int, double*, double*, int64_t, unsigned long long*);
 struct RingEntry { int w, yps; RingKernel fn; };
 #define XMHW_RK(W, Y) {W, Y, clim_ring_f32<W, Y>}
 const RingEntry kRing[] = {
@@ -370,7 +522,7 @@ int32_t ring_pick_yps(int32_t w, int32_t ntracks, int elem_bytes) {
 hipError_t launch_ring_f32(const float* ts, int64_t C, int64_t ld, const uint32_t* table,
                            int32_t step_min, const DevChunk* chunks, int32_t nchunks, int32_t w,
                            int32_t yps, double q, int negate, double* thresh, double* seas,
-                           int64_t ldo, hipStream_t stream) {
+                           int64_t ldo, hipStream_t stream, unsigned long long* stats) {
     RingKernel fn = find_ring(w, yps);
     if (!fn) return hipErrorInvalidValue;
     if (C <= 0 || nchunks <= 0) return hipSuccess;
@@ -378,7 +530,7 @@ hipError_t launch_ring_f32(const float* ts, int64_t C, int64_t ld, const uint32_
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block),
               static_cast<unsigned>(nchunks));
     hipLaunchKernelGGL(fn, grid, dim3(64 * kWavesPerBlock), 0, stream, ts, C, ld, table, step_min,
-                       chunks, q, negate, thresh, seas, ldo);
+                       chunks, q, negate, thresh, seas, ldo, stats);
     return hipGetLastError();
 }
 

@@ -112,6 +112,12 @@ PYBIND11_MODULE(_xmhw_hip, m) {
         return out;
     });
 
+    m.def("plan_debug_stats", [](uintptr_t p, int enable, bool read) {
+        py::array_t<uint64_t> out(4);
+        check(xmhw_plan_debug_stats(pp(p), enable, read ? out.mutable_data() : nullptr));
+        return out;
+    });
+
     m.def("clim_raw", [](uintptr_t plan, uintptr_t ts, int itemsize, int64_t C, int64_t ld, double q, int negate,
                          uintptr_t th, uintptr_t se, int64_t ldo, uintptr_t stream) {
         if (itemsize == 4)
