@@ -1,0 +1,110 @@
+"""threshold() end to end on the GPU (host logic + HIP path) against the oracle,
+and the remaining C-ABI entry points: one-shot host call, land mask, synthetic
+generator, error codes."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+import xmhw_oracle as ora
+import oracle_fast as fast
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def h():
+    from xmhw_amd._lib import require_gpu, hip
+    require_gpu()
+    return hip()
+
+
+def _grid(oisst, sst=None):
+    from xmhw_amd import GridSeries
+    return GridSeries(oisst["sst"] if sst is None else sst, ("time", "lat", "lon"),
+                      {"time": oisst["time64"], "lat": oisst["lat"], "lon": oisst["lon"]},
+                      time_encoding={"calendar": "proleptic_gregorian"})
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(smoothPercentile=False, skipna=True),
+                                dict(coldSpells=True, pctile=10), dict(windowHalfWidth=2, smoothPercentileWidth=7),
+                                dict(climatologyPeriod=[2004, 2004], windowHalfWidth=1, smoothPercentileWidth=5)])
+def test_threshold_grid_vs_oracle(h, oisst, kw):
+    from xmhw_amd import threshold
+    ds = threshold(_grid(oisst), **kw)
+    ref = ora.threshold_grid(oisst["sst"], oisst["time64"], **kw)
+    keep = ref["keep"].reshape(8, 4)
+    rows, cols = keep.any(axis=1), keep.any(axis=0)
+    npt.assert_array_equal(ds.coords["doy"], ref["doy"])
+    npt.assert_allclose(ds["thresh"], ref["thresh"][:, rows][:, :, cols], rtol=1e-12, equal_nan=True)
+    npt.assert_allclose(ds["seas"], ref["seas"][:, rows][:, :, cols], rtol=1e-12, equal_nan=True)
+
+
+def test_threshold_point_and_nan_holes(h, oisst):
+    from xmhw_amd import threshold, GridSeries
+    x = oisst["sst"][:, 1, 2].copy()
+    x[100:130] = np.nan
+    ds = threshold(GridSeries(x, ("time",), {"time": oisst["time64"]}), skipna=True)
+    ref = ora.threshold_grid(x, oisst["time64"], dims=("time",), skipna=True)
+    npt.assert_allclose(ds["thresh"], ref["thresh"], rtol=1e-12, equal_nan=True)
+    npt.assert_allclose(ds["seas"], ref["seas"], rtol=1e-12, equal_nan=True)
+
+
+def test_one_shot_host_entry_and_errors(h, oisst):
+    ts, keep, _, _ = ora.land_check(oisst["sst"], ("time", "lat", "lon"))
+    doy = ora.add_doy(oisst["time64"]).astype(np.int32)
+    th, se = h.clim_host(np.ascontiguousarray(ts), doy, 366, 5, 0.9, 1, 31, 1, 0)
+    _, t0, s0 = fast.threshold_cells_fast(ts, doy)
+    npt.assert_allclose(th, t0, rtol=1e-12)
+    npt.assert_allclose(se, s0, rtol=1e-12)
+    th64, _ = h.clim_host(np.ascontiguousarray(ts.astype(np.float64)), doy, 366, 5, 0.9, 1, 31, 1, 0)
+    npt.assert_allclose(th64, t0, rtol=1e-12)
+    with pytest.raises(h.InvalidArgument):          # even smoothing width (xmhw.py:103-104)
+        h.clim_host(np.ascontiguousarray(ts), doy, 366, 5, 0.9, 1, 30, 1, 0)
+    with pytest.raises(h.InvalidArgument):          # wrong D
+        h.clim_host(np.ascontiguousarray(ts), doy, 365, 5, 0.9, 0, 31, 1, 0)
+    with pytest.raises(h.InvalidArgument):          # quantile outside [0, 1]
+        h.clim_host(np.ascontiguousarray(ts), doy, 366, 5, 1.5, 0, 31, 1, 0)
+
+
+def test_land_mask_kernel(h, oisst):
+    from xmhw_amd.device import DeviceBuffer
+    sst = oisst["sst"].reshape(731, 32).copy()
+    sst[245, 6] = np.nan
+    d = DeviceBuffer.from_array(sst)
+    for anynans in (0, 1):
+        k = DeviceBuffer(32)
+        h.land_mask(d.ptr, 4, 731, 32, 32, anynans, k.ptr)
+        h.stream_sync(0)
+        keep = k.to_array((32,), np.uint8).astype(bool)
+        nan = np.isnan(sst)
+        want = ~(nan.any(axis=0) if anynans else nan.all(axis=0))
+        npt.assert_array_equal(keep, want)
+
+
+def test_synth_generator_is_deterministic_and_plausible(h):
+    from xmhw_amd.device import DeviceBuffer
+    T, C = 2000, 300
+    a, b = DeviceBuffer(4 * T * C), DeviceBuffer(4 * T * 100)
+    h.synth_sst(a.ptr, 4, T, C, C, 0, 42, 0.05)
+    h.synth_sst(b.ptr, 4, T, 100, 100, 200, 42, 0.05)      # cells 200..299 generated alone
+    h.stream_sync(0)
+    xa = a.to_array((T, C), np.float32)
+    xb = b.to_array((T, 100), np.float32)
+    npt.assert_array_equal(xa[:, 200:], xb)                # counter-based: any subset reproduces
+    frac = np.isnan(xa).mean()
+    assert 0.04 < frac < 0.06
+    assert 5 < np.nanmean(xa) < 25 and 1.5 < np.nanstd(xa) < 9
+
+
+def test_many_cells_not_multiple_of_tile(h):
+    """ragged cell counts (not a multiple of the 8-cell wave / 32-cell block tile)."""
+    from xmhw_amd.device import calc_clim_device
+    time = np.arange("2001-01-01", "2007-01-01", dtype="datetime64[D]")
+    doy = ora.add_doy(time)
+    rng = np.random.default_rng(4)
+    for C in (1, 7, 9, 33, 65):
+        x = (15 + rng.normal(size=(time.shape[0], C))).astype(np.float32)
+        _, t1, s1 = calc_clim_device(x, doy, 90, 5, True, 31, False)
+        _, t0, s0 = fast.threshold_cells_fast(x, doy)
+        npt.assert_allclose(t1, t0, rtol=1e-12)
+        npt.assert_allclose(s1, s0, rtol=1e-12)

@@ -1,0 +1,116 @@
+"""CPU tests of the host-side plan (C ABI, no GPU): the ring kernel's step
+table must reproduce window_roll()'s pools (identify.py:184-209) exactly when
+replayed with the kernel's ring semantics."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import xmhw_oracle as ora
+from oracle_fast import pool_index
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _plan(doy, w):
+    from xmhw_amd.device import Plan
+    return Plan(doy, w)
+
+
+def replay(table, step_min, R, D):
+    """Replay the table with the kernel's ring rules; return per row the sorted
+    multiset of time indices pooled (counted tracks, valid samples)."""
+    nsteps, ntp = table.shape
+    ring = -np.ones((ntp, R), dtype=np.int64)
+    pools = []
+    for i in range(nsteps):
+        s = step_min + i
+        m = (s - step_min) % R
+        counted = (table[i] & 1).astype(bool)
+        code = table[i] >> 1
+        for k in range(ntp):
+            if code[k] == 0:                      # HOLD: rotate, oldest lands on next slot
+                ring[k] = np.roll(ring[k], 1)
+            else:
+                ring[k, m] = code[k] - 2 if code[k] >= 2 else -1
+        if s >= 0:
+            sel = ring[counted]
+            pools.append(np.sort(sel[sel >= 0]))
+    assert len(pools) == D
+    return pools
+
+
+def _check(doy, w, yps):
+    p = _plan(doy, w)
+    tab = p.table(yps)
+    assert tab.shape == (p.nsteps, 8 * yps)
+    got = replay(tab, p.step_min, 2 * w + 1, p.D)
+    doys, want = pool_index(doy, w)
+    np.testing.assert_array_equal(p.doys, doys)
+    for r in range(p.D):
+        np.testing.assert_array_equal(got[r], np.sort(want[r]), err_msg=f"row {r} (doy {doys[r]})")
+    return p
+
+
+def test_daily_with_leap_years():
+    time = np.arange("2003-01-01", "2011-01-01", dtype="datetime64[D]")
+    p = _check(ora.add_doy(time), 5, 1)
+    assert p.D == 366 and p.ntracks == 8 and p.kernel == "ring"
+
+
+def test_partial_first_and_last_year():
+    time = np.arange("2001-07-15", "2006-03-10", dtype="datetime64[D]")
+    p = _check(ora.add_doy(time), 5, 1)
+    assert p.ntracks == 6
+
+
+def test_tstep_axis_and_small_windows():
+    doy = np.tile(np.arange(1, 74), 7)
+    _check(doy, 2, 1)
+    _check(doy, 1, 2)
+    _check(np.tile(np.arange(1, 13), 3), 1, 1)
+
+
+def test_no_leap_year_has_365_rows():
+    time = np.arange("2001-01-01", "2004-01-01", dtype="datetime64[D]")
+    p = _check(ora.add_doy(time), 3, 1)
+    assert p.D == 365 and 60 not in p.doys          # quirk Q5
+
+
+def test_irregular_axis_gap_in_record():
+    time = np.concatenate([np.arange("2001-01-01", "2002-05-01", dtype="datetime64[D]"),
+                           np.arange("2002-09-01", "2005-01-01", dtype="datetime64[D]")])
+    _check(ora.add_doy(time), 4, 1)
+
+
+def test_too_many_tracks_falls_back_to_generic():
+    doy = np.tile(np.arange(1, 4), 100)              # 100 tracks > 8 * max yps
+    p = _plan(doy, 5)
+    assert p.kernel == "generic"
+
+
+def test_bad_arguments():
+    from xmhw_amd.exception import XmhwException
+    with pytest.raises(XmhwException):
+        _plan(np.arange(1, 10), -1)
+    with pytest.raises(XmhwException):
+        _plan(np.zeros(0, dtype=np.int32), 5)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "xmhw_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(xmhw_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 35
+    lib = ctypes.CDLL(os.path.join(ROOT, "xmhw_amd", "libxmhw_amd.so"))
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.xmhw_arch.restype = ctypes.c_char_p
+    assert lib.xmhw_arch() == b"gfx950"
+    assert lib.xmhw_version() >= 1
+    # error path without touching a GPU: NULL plan
+    lib.xmhw_last_error.restype = ctypes.c_char_p
+    assert lib.xmhw_plan_info(None, None, None, None, None, None) == 1
+    assert b"NULL" in lib.xmhw_last_error()

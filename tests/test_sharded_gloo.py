@@ -1,0 +1,79 @@
+"""N>1 host logic on CPU: world_size-2 gloo process group, the device stage
+replaced by the oracle (test hook).  The sharded result must be bit-identical
+to the unsharded one."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import oracle_fast as fast
+    from xmhw_amd import GridSeries
+    from xmhw_amd.sharded import threshold_sharded, slab_bounds
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def compute(ts, doy, pctile, w, smooth, width, tstep, cold=False):
+        return fast.threshold_cells_fast(ts, doy, pctile=pctile, windowHalfWidth=w, smoothPercentile=smooth,
+                                         smoothPercentileWidth=width, tstep=tstep, coldSpells=cold)
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "oisst_2003_2004.npz"))
+    time = np.datetime64("2003-01-01") + g["time"].astype("timedelta64[D]")
+    temp = GridSeries(g["sst"], ("time", "lat", "lon"), {"time": time, "lat": g["lat"], "lon": g["lon"]})
+    ds = threshold_sharded(temp, _compute=compute, smoothPercentileWidth=11)
+    assert slab_bounds(12, world)[rank] == ((0, 6), (6, 12))[rank]
+    if rank == 0:
+        np.savez(os.path.join(outdir, "sharded.npz"), thresh=ds["thresh"], seas=ds["seas"])
+    else:
+        assert ds is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_equals_single(tmp_path):
+    import torch.multiprocessing as mp
+    import oracle_fast as fast
+    from xmhw_amd import GridSeries, threshold
+
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "sharded.npz")
+
+    def compute(ts, doy, pctile, w, smooth, width, tstep, cold=False):
+        return fast.threshold_cells_fast(ts, doy, pctile=pctile, windowHalfWidth=w, smoothPercentile=smooth,
+                                         smoothPercentileWidth=width, tstep=tstep, coldSpells=cold)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "oisst_2003_2004.npz"))
+    time = np.datetime64("2003-01-01") + g["time"].astype("timedelta64[D]")
+    temp = GridSeries(g["sst"], ("time", "lat", "lon"), {"time": time, "lat": g["lat"], "lon": g["lon"]})
+    ref = threshold(temp, _compute=compute, smoothPercentileWidth=11)
+    np.testing.assert_array_equal(got["thresh"], ref["thresh"])
+    np.testing.assert_array_equal(got["seas"], ref["seas"])
+
+
+def test_slab_bounds_cover_and_balance():
+    from xmhw_amd.sharded import slab_bounds
+    for C in (0, 1, 7, 8, 1036800, 1036801):
+        for w in (1, 2, 3, 8):
+            b = slab_bounds(C, w)
+            assert b[0][0] == 0 and b[-1][1] == C
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1

@@ -356,35 +356,25 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
                     const bool settle = resolved || (lo - Fl <= SLACK) || (ph - pl <= 1u);
                     if (__all(settle) || it >= budget) break;
                     const uint32_t room = ph - pl;
-                    uint32_t off;
-                    if (it < 5 && lreal && hreal) {
-                        float frac = (aim - static_cast<float>(Fl)) / static_cast<float>(Fh - Fl);
-                        frac = fminf(fmaxf(frac, 0.0f), 1.0f);
-                        off = static_cast<uint32_t>(static_cast<float>(room) * frac);
-                    } else if (it < 5 && lreal) {
-                        const float st = (aim - static_cast<float>(Fl)) * kpr * grow;
-                        off = st < 2.0e9f ? static_cast<uint32_t>(fmaxf(st, 1.0f)) : 2000000000u;
-                        grow *= 2.0f;
-                    } else if (it < 5 && hreal) {
-                        const float st = (static_cast<float>(Fh) - aim) * kpr * grow;
-                        const uint32_t back = st < 2.0e9f ? static_cast<uint32_t>(fmaxf(st, 1.0f)) : 2000000000u;
-                        off = room > back ? room - back : 1u;
-                        grow *= 2.0f;
-                    } else {
-                        off = room >> 1;
-                    }
+                    // one formula for all cases: step = ranks-to-go x keys-per-rank, taken from
+                    // the known end of the bracket; both ends known -> secant slope
+                    const bool both = lreal && hreal;
+                    const float roomf = static_cast<float>(room);
+                    const float slope = both ? roomf * __builtin_amdgcn_rcpf(static_cast<float>(Fh - Fl))
+                                             : kpr * grow;
+                    const float ranks = lreal ? aim - static_cast<float>(Fl) : static_cast<float>(Fh) - aim;
+                    float stf = fminf(fmaxf(ranks * slope, 1.0f), 2.0e9f);
+                    stf = lreal ? stf : roomf - stf;
+                    stf = fminf(fmaxf(stf, 1.0f), 4.0e9f);
+                    uint32_t off = (it < 5) ? static_cast<uint32_t>(stf) : (room >> 1);
+                    grow = both ? grow : grow * 2.0f;
                     off = umax(1u, umin(off, room - 1u));
                     const uint32_t p = settle ? pl : pl + off;
                     const uint32_t F = count_le(p) - ninv;
                     ++st_count;
                     if (!settle) {
-                        if (F <= lo) {
-                            if (!lreal) grow = 1.0f;
-                            pl = p; Fl = F; lreal = true;
-                        } else {
-                            if (!hreal) grow = 1.0f;
-                            ph = p; Fh = F; hreal = true;
-                        }
+                        if (F <= lo) { pl = p; Fl = F; lreal = true; }
+                        else { ph = p; Fh = F; hreal = true; }
                     }
                 }
                 // ---- extraction: the J smallest keys above the pivot --------------------
@@ -451,8 +441,8 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
                 se = total / static_cast<double>(n);
                 // calibrate keys-per-rank on what this row needed, carry the pivot
                 if (rank_gap > 1 || rank_gap < -1) {
-                    const float obs = (static_cast<float>(alo) - static_cast<float>(p_first)) /
-                                      static_cast<float>(rank_gap);
+                    const float obs = (static_cast<float>(alo) - static_cast<float>(p_first)) *
+                                      __builtin_amdgcn_rcpf(static_cast<float>(rank_gap));
                     if (obs >= 1.0f && obs < 1.0e8f) kpr = 0.5f * kpr + 0.5f * obs;
                 }
             }
