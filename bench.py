@@ -67,8 +67,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cells", type=int, default=1440 * 720, help="cells per GPU")
-    ap.add_argument("--years", type=int, nargs=2, default=[1982, 2021])
+    ap.add_argument("--config", default="0.25deg",
+                    choices=["0.25deg", "1deg", "0.25deg_nan", "0.05deg_tstep"],
+                    help="BASELINE.json preset: 0.25deg = configs[2] (default, the metric's config); "
+                         "1deg = configs[1]; 0.25deg_nan = configs[3] (5%% NaN); "
+                         "0.05deg_tstep = configs[4] per-GPU share (810,000 cells, 6-hourly, tstep)")
+    ap.add_argument("--cells", type=int, default=0, help="cells per GPU (0: the preset's)")
+    ap.add_argument("--years", type=int, nargs=2, default=None)
     ap.add_argument("--slabs", type=int, default=0, help="launches per step (0: 1 at N=1, 8 at N>1)")
     ap.add_argument("--nan-frac", type=float, default=0.0)
     ap.add_argument("--kernel", default="auto")
@@ -99,9 +104,27 @@ def main():
     h = hip()
     h.set_device(local)
 
-    doy = daily_doy(*args.years)
+    presets = {
+        "0.25deg": dict(cells=1440 * 720, years=(1982, 2021), nan=0.0, tstep=False, name="0.25deg global"),
+        "1deg": dict(cells=360 * 180, years=(1991, 2020), nan=0.0, tstep=False, name="1deg global"),
+        "0.25deg_nan": dict(cells=1440 * 720, years=(1982, 2021), nan=0.05, tstep=False,
+                            name="0.25deg global, 5% NaN"),
+        "0.05deg_tstep": dict(cells=810000, years=(2001, 2020), nan=0.0, tstep=True,
+                              name="0.05deg tile share, 6-hourly no-leap (tstep)"),
+    }
+    ps = presets[args.config]
+    years = tuple(args.years) if args.years else ps["years"]
+    if args.nan_frac == 0.0:
+        args.nan_frac = ps["nan"]
+    tstep = ps["tstep"]
+    if tstep:   # 1460 steps per year, no leap days (docs/frequency.rst:42-50), add_doy tstep branch
+        nyr = years[1] - years[0] + 1
+        doy = np.tile(np.arange(1, 1461, dtype=np.int64), nyr)
+    else:
+        doy = daily_doy(*years)
+    args.years = list(years)
     T = int(doy.shape[0])
-    C = int(args.cells)
+    C = int(args.cells) or ps["cells"]
     w, pctile, width = 5, 90, 31
     q = pctile / 100.0
     plan = Plan(doy, w, kernel=args.kernel, nchunks=args.chunks)
@@ -135,7 +158,7 @@ def main():
             clim_raw(plan, ts.data_ptr() + 4 * a, 4, n, q, False, raw_th[i].data_ptr(),
                      raw_se[i].data_ptr(), ld=C, ldo=n, stream=stream)
             h.event_record(ev[i][1], stream)
-            clim_finish(plan, raw_th[i].data_ptr(), raw_se[i].data_ptr(), n, True, True, width,
+            clim_finish(plan, raw_th[i].data_ptr(), raw_se[i].data_ptr(), n, not tstep, True, width,
                         out[i][0].data_ptr(), out[i][1].data_ptr(), ldo=n, stream=stream)
             if world > 1:
                 works.append(dist.gather(out[i], gathered[i] if rank == 0 else None, dst=0, async_op=True))
@@ -187,7 +210,7 @@ def main():
         "dtype": "f32 in / f64 out",
         "data": "synthetic",
         "config": {
-            "workload": f"0.25deg global {C} cells/GPU, {args.years[0]}-{args.years[1]} daily (T={T}), "
+            "workload": f"{ps['name']} {C} cells/GPU, {args.years[0]}-{args.years[1]} (T={T}), "
                         f"windowHalfWidth={w}, pctile={pctile}, smoothPercentileWidth={width}, "
                         f"nan_frac={args.nan_frac}",
             "cells_per_gpu": C, "T": T, "D": D, "kernel": plan.kernel, "slabs": len(slabs),
@@ -209,7 +232,7 @@ def main():
         sample = ts[:, torch.from_numpy(idx).to(dev)].cpu().numpy()
         got = np.concatenate([o.cpu().numpy() for o in out], axis=2)[:, :, idx]
         _, th0, se0 = fast.threshold_cells_fast(sample, doy, pctile=pctile, windowHalfWidth=w,
-                                                smoothPercentileWidth=width)
+                                                smoothPercentileWidth=width, tstep=tstep)
         err_th = float(np.nanmax(np.abs(got[0] - th0) / np.abs(th0)))
         err_se = float(np.nanmax(np.abs(got[1] - se0) / np.abs(se0)))
         result["parity"] = {"cells": int(idx.size), "max_rel_err_thresh": err_th,
@@ -218,7 +241,7 @@ def main():
         if world == 1 and not args.no_cpu:
             ncpu = min(args.cpu_cells, C)
             cs = ts[:, :ncpu].cpu().numpy()
-            kw = dict(pctile=pctile, windowHalfWidth=w, smoothPercentileWidth=width)
+            kw = dict(pctile=pctile, windowHalfWidth=w, smoothPercentileWidth=width, tstep=tstep)
             cps, cores, ncell, th_c, se_c = cpu_baseline(cs, doy, kw, ncpu)
             g = np.concatenate([o.cpu().numpy() for o in out], axis=2)[:, :, :ncell]
             result["cpu_baseline"] = {
