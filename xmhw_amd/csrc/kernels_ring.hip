@@ -98,6 +98,7 @@ __device__ __forceinline__ double key_value(uint32_t k) {
 // insert(): one v_med3_u32 per rank + one v_min_u32.
 template <int J>
 struct TopJ {
+    static_assert(J >= 2 && J <= 8, "merge network is built for 2..8 keys");
     uint32_t m[J];
     __device__ __forceinline__ void reset() {
 #pragma unroll
@@ -108,13 +109,31 @@ struct TopJ {
         for (int i = J - 1; i >= 1; --i) m[i] = umed3(m[i - 1], m[i], d);
         m[0] = umin(m[0], d);
     }
+    // keep the J smallest of my list and the partner lane's list: min(a[i], b[J-1-i]) holds
+    // exactly those J keys as a bitonic sequence; a half-cleaner network sorts it again
     template <int CTRL>
     __device__ __forceinline__ void merge_dpp() {
         uint32_t b[J];
 #pragma unroll
         for (int i = 0; i < J; ++i) b[i] = dpp_mov<CTRL>(m[i]);
 #pragma unroll
-        for (int i = 0; i < J; ++i) insert(b[i]);
+        for (int i = 0; i < J; ++i) m[i] = umin(m[i], b[J - 1 - i]);
+        // the J keys form an up-down sequence; embedded at offset 8-J of an 8-key bitonic
+        // merge network (virtual -inf in front) the compare-exchanges that touch the
+        // padding are no-ops and are skipped statically (J=5: 5 compare-exchanges)
+        constexpr int OFF = 8 - J;
+#pragma unroll
+        for (int d = 4; d >= 1; d >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if ((k & d) == 0 && k >= OFF && k + d < 8) {
+                    const uint32_t lo_ = umin(m[k - OFF], m[k - OFF + d]);
+                    const uint32_t hi_ = umax(m[k - OFF], m[k - OFF + d]);
+                    m[k - OFF] = lo_;
+                    m[k - OFF + d] = hi_;
+                }
+            }
+        }
     }
     __device__ __forceinline__ void sub_merge() {
         merge_dpp<kRor8>();
