@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--nan-frac", type=float, default=0.0)
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--chunks", type=int, default=0)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="input dtype (output is always f64)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-cells", type=int, default=512)
     ap.add_argument("--parity-cells", type=int, default=512)
@@ -134,10 +135,11 @@ def main():
     slabs = [(bounds[i], bounds[i + 1]) for i in range(nslab) if bounds[i + 1] > bounds[i]]
 
     # ---- inputs resident in HBM: synthetic SST generated on the device --------------
-    ts = torch.empty((T, C), dtype=torch.float32, device=dev)
+    isz = 4 if args.dtype == "f32" else 8
+    ts = torch.empty((T, C), dtype=torch.float32 if isz == 4 else torch.float64, device=dev)
     seed = 20260101 + 2
     stream = torch.cuda.current_stream().cuda_stream
-    h.synth_sst(ts.data_ptr(), 4, T, C, C, rank * C, seed, args.nan_frac, stream)
+    h.synth_sst(ts.data_ptr(), isz, T, C, C, rank * C, seed, args.nan_frac, stream)
     raw_th = [torch.empty((D, b - a), dtype=torch.float64, device=dev) for a, b in slabs]
     raw_se = [torch.empty((D, b - a), dtype=torch.float64, device=dev) for a, b in slabs]
     out = [torch.empty((2, D, b - a), dtype=torch.float64, device=dev) for a, b in slabs]
@@ -155,7 +157,7 @@ def main():
         for i, (a, b) in enumerate(slabs):
             n = b - a
             h.event_record(ev[i][0], stream)
-            clim_raw(plan, ts.data_ptr() + 4 * a, 4, n, q, False, raw_th[i].data_ptr(),
+            clim_raw(plan, ts.data_ptr() + isz * a, isz, n, q, False, raw_th[i].data_ptr(),
                      raw_se[i].data_ptr(), ld=C, ldo=n, stream=stream)
             h.event_record(ev[i][1], stream)
             clim_finish(plan, raw_th[i].data_ptr(), raw_se[i].data_ptr(), n, not tstep, True, width,
@@ -191,7 +193,7 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     value = world * C * args.steps / dt
     # ---- roofline of the dominant kernel (ring): algorithmic bytes / launch time --------
-    bytes_per_cell = T * 4 + 2 * D * 8
+    bytes_per_cell = T * isz + 2 * D * 8
     cells_per_launch = float(np.mean([b - a for a, b in slabs]))
     ring_avg_ms = float(np.mean(ring_ms))
     achieved = cells_per_launch * bytes_per_cell / (ring_avg_ms * 1e-3) / 1e9
@@ -207,7 +209,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 in / f64 out",
+        "dtype": f"{args.dtype} in / f64 out",
         "data": "synthetic",
         "config": {
             "workload": f"{ps['name']} {C} cells/GPU, {args.years[0]}-{args.years[1]} (T={T}), "
@@ -217,7 +219,7 @@ def main():
             "gather": "rccl gather to rank 0, pipelined per slab" if world > 1 else "none",
         },
         "roofline": {
-            "bound": "hbm", "kernel": "clim_ring_f32", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": "clim_ring_" + args.dtype, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_cell": bytes_per_cell, "cells_per_launch": cells_per_launch,
             "avg_launch_ms": ring_avg_ms,

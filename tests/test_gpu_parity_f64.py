@@ -1,0 +1,98 @@
+"""Parity of the float64 ring kernel (kernels_ring64.hip) against the oracle and
+against the generic kernel, on the same families of inputs as the float32 tests."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+import xmhw_oracle as ora
+import oracle_fast as fast
+from test_gpu_parity import _series, _daily
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from xmhw_amd._lib import require_gpu
+    require_gpu()
+    import xmhw_amd.device as d
+    return d
+
+
+def _check(dev, x, doy, nchunks=0, rtol=1e-12, **kw):
+    assert x.dtype == np.float64
+    args = (kw.get("pctile", 90), kw.get("windowHalfWidth", 5), kw.get("smoothPercentile", True),
+            kw.get("smoothPercentileWidth", 31), kw.get("tstep", False), kw.get("coldSpells", False))
+    d1, t1, s1 = dev.calc_clim_device(x, doy, *args, kernel="ring", nchunks=nchunks)
+    d0, t0, s0 = fast.threshold_cells_fast(x, doy, **kw)
+    npt.assert_array_equal(d1, d0)
+    npt.assert_array_equal(np.isnan(t1), np.isnan(t0))
+    npt.assert_allclose(t1, t0, rtol=rtol, atol=0, equal_nan=True)
+    npt.assert_allclose(s1, s0, rtol=rtol, atol=0, equal_nan=True)
+    return t1, t0
+
+
+@pytest.mark.parametrize("nanfrac", [0.0, 0.05])
+def test_daily_random_f64(dev, nanfrac):
+    time, doy = _daily(2001, 2012)
+    x = _series(time.shape[0], 101, 11, nanfrac, dtype=np.float64)
+    t1, t0 = _check(dev, x, doy, smoothPercentile=False)
+    if nanfrac == 0.0:
+        m = np.ones(366, bool); m[59] = False
+        npt.assert_array_equal(t1[m], t0[m])          # exact selection + numpy's lerp
+    _check(dev, x, doy)
+
+
+def test_forty_tracks_f64(dev):
+    time, doy = _daily(1982, 2021)                     # 40 tracks -> 3 tracks per lane
+    x = _series(time.shape[0], 37, 2, 0.01, dtype=np.float64)
+    _check(dev, x, doy, smoothPercentile=False)
+
+
+def test_ties_and_absent_groups_f64(dev):
+    time, doy = _daily(1995, 2004)
+    x = _series(time.shape[0], 40, 5, 0.02, dtype=np.float64, quant=0.25)
+    x[(doy >= 150) & (doy <= 230), 3] = np.nan
+    x[:, 9] = np.nan
+    x[:, 2] = 1.5
+    _check(dev, x, doy, smoothPercentile=False)
+    _check(dev, x, doy, pctile=50, windowHalfWidth=2, smoothPercentileWidth=5)
+
+
+def test_tstep_cold_f64(dev):
+    n, ny = 73, 9
+    doy = np.tile(np.arange(1, n + 1), ny)
+    x = _series(n * ny, 33, 3, 0.03, dtype=np.float64)
+    _check(dev, x, doy, tstep=True, windowHalfWidth=2, smoothPercentileWidth=5, coldSpells=True, pctile=10)
+
+
+@pytest.mark.parametrize("nchunks", [1, 3, 7])
+def test_chunks_and_generic_identical_f64(dev, nchunks):
+    time, doy = _daily(2003, 2014)
+    x = _series(time.shape[0], 30, 21, 0.04, dtype=np.float64)
+    d, t1, s1 = dev.calc_clim_device(x, doy, 90, 5, False, 31, False, kernel="ring", nchunks=nchunks)
+    d, t0, s0 = dev.calc_clim_device(x, doy, 90, 5, False, 31, False, kernel="generic")
+    npt.assert_array_equal(t1, t0)
+    npt.assert_allclose(s1, s0, rtol=1e-13, equal_nan=True)
+
+
+def test_partial_years_and_extremes_f64(dev):
+    time = np.arange("2001-07-15", "2009-03-10", dtype="datetime64[D]")
+    doy = ora.add_doy(time)
+    x = _series(time.shape[0], 21, 9, 0.01, dtype=np.float64)
+    _check(dev, x, doy, smoothPercentile=False)
+    time, doy = _daily(2001, 2004)
+    x = _series(time.shape[0], 8, 17, dtype=np.float64)
+    x[5, 0] = np.inf; x[100, 0] = -np.inf; x[7, 1] = 0.0; x[8, 1] = -0.0
+    x[:, 3] = 5e-320                                   # subnormal
+    x[:, 4] = -np.inf                                  # a cell that is -inf throughout
+    d1, t1, s1 = dev.calc_clim_device(x, doy, 90, 5, False, 31, True, kernel="ring")
+    d0, t0, s0 = fast.threshold_cells_fast(x, doy, smoothPercentile=False, tstep=True)
+    fin = np.isfinite(t0)
+    npt.assert_allclose(t1[fin], t0[fin], rtol=1e-12)
+    npt.assert_array_equal(t1[:, 4], t0[:, 4])
+    npt.assert_array_equal(np.isfinite(t1), fin)
+    # low percentile with -inf present: the inclusive extraction bound must admit -inf
+    d1, t1, s1 = dev.calc_clim_device(x, doy, 0, 5, False, 31, True, kernel="ring")
+    d0, t0, s0 = fast.threshold_cells_fast(x, doy, pctile=0, smoothPercentile=False, tstep=True)
+    npt.assert_array_equal(t1[:, [0, 4]], t0[:, [0, 4]])

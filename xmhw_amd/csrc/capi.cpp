@@ -43,6 +43,8 @@ struct xmhw_plan {
     int32_t yps = 0;          // ring kernel years-per-lane (0: ring not available)
     int32_t nchunks = 0;
     uint32_t* d_table = nullptr;
+    int32_t yps64 = 0;        // float64 ring kernel tracks-per-lane (16 lanes per cell)
+    uint32_t* d_table64 = nullptr;
     xmhw::DevChunk* d_chunks = nullptr;
     int32_t* d_row_ptr = nullptr;
     int32_t* d_centres = nullptr;
@@ -51,6 +53,7 @@ struct xmhw_plan {
     ~xmhw_plan() {
         if (d_stats) (void)hipFree(d_stats);
         if (d_table) (void)hipFree(d_table);
+        if (d_table64) (void)hipFree(d_table64);
         if (d_chunks) (void)hipFree(d_chunks);
         if (d_row_ptr) (void)hipFree(d_row_ptr);
         if (d_centres) (void)hipFree(d_centres);
@@ -60,7 +63,8 @@ struct xmhw_plan {
 namespace {
 
 int32_t resolve_kernel(const xmhw_plan* p, int elem_bytes) {
-    const int32_t yps = xmhw::ring_pick_yps(p->host.w, p->host.ntracks, elem_bytes);
+    const int32_t yps = elem_bytes == 8 ? xmhw::ring64_pick_yps(p->host.w, p->host.ntracks)
+                                        : xmhw::ring_pick_yps(p->host.w, p->host.ntracks, elem_bytes);
     if (p->host.kernel_choice == XMHW_KERNEL_GENERIC) return XMHW_KERNEL_GENERIC;
     if (p->host.kernel_choice == XMHW_KERNEL_RING) return yps ? XMHW_KERNEL_RING : -1;
     return yps ? XMHW_KERNEL_RING : XMHW_KERNEL_GENERIC;
@@ -95,8 +99,15 @@ int upload(xmhw_plan* p, int64_t C) {
             HIP_TRY(hipMemcpy(p->d_table, tab.data(), sizeof(uint32_t) * tab.size(),
                               hipMemcpyHostToDevice));
         }
+        p->yps64 = xmhw::ring64_pick_yps(h.w, h.ntracks);
+        if (p->yps64) {
+            std::vector<uint32_t> tab = h.ring_table(16, p->yps64);
+            HIP_TRY(hipMalloc(&p->d_table64, sizeof(uint32_t) * tab.size()));
+            HIP_TRY(hipMemcpy(p->d_table64, tab.data(), sizeof(uint32_t) * tab.size(),
+                              hipMemcpyHostToDevice));
+        }
     }
-    if (p->yps) {
+    if (p->yps || p->yps64) {
         std::vector<xmhw::Chunk> ch = h.make_chunks(nchunks);
         std::vector<xmhw::DevChunk> dch(ch.size());
         for (size_t i = 0; i < ch.size(); ++i) dch[i] = {ch[i].warm_start, ch[i].begin, ch[i].end};
@@ -134,7 +145,9 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
                                       h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps, q,
                                       negate, thresh, seas, ldo, st, plan->d_stats);
         } else {
-            return fail(XMHW_ERR_UNSUPPORTED, "ring kernel is float32 only");
+            e = xmhw::launch_ring_f64(reinterpret_cast<const double*>(ts), C, ld, plan->d_table64,
+                                      h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps64, q,
+                                      negate, thresh, seas, ldo, st, plan->d_stats);
         }
     } else {
         e = xmhw::launch_generic<T>(ts, h.T, C, ld, plan->d_row_ptr, plan->d_centres, h.D, h.w, q,

@@ -22,6 +22,14 @@ hipError_t launch_ring_f32(const float* ts, int64_t C, int64_t ld, const uint32_
                            double* seas, int64_t ldo, hipStream_t stream,
                            unsigned long long* stats = nullptr);
 
+// float64 ring kernel: 16 lanes per cell, yps tracks per lane (kernels_ring64.hip)
+int32_t ring64_pick_yps(int32_t w, int32_t ntracks);  // 0 if none
+hipError_t launch_ring_f64(const double* ts, int64_t C, int64_t ld, const uint32_t* table,
+                           int32_t step_min, const DevChunk* chunks, int32_t nchunks,
+                           int32_t w, int32_t yps, double q, int negate, double* thresh,
+                           double* seas, int64_t ldo, hipStream_t stream,
+                           unsigned long long* stats = nullptr);
+
 // Feb-29 substitution + circular running mean, per cell over present groups
 hipError_t launch_finish(const double* th_in, const double* se_in, int64_t C, int64_t ldo, int32_t D,
                          int32_t i59, int32_t i60, int32_t i61, int feb29_fix, int smooth,
