@@ -140,6 +140,20 @@ int xmhw_land_mask_f32(const float *ts_dev, int64_t T, int64_t C, int64_t ld, in
 int xmhw_land_mask_f64(const double *ts_dev, int64_t T, int64_t C, int64_t ld, int anynans,
                        uint8_t *keep_dev, void *stream);
 
+/* land_check()'s compaction on resident data: out[r][c] = in[r][index[c]] for the
+ * n ocean cells listed in index_dev (ascending stacked-cell numbers, int64), and
+ * the inverse for the results (what unstack('cell') does, xmhw.py:210-214):
+ * out[r][index[c]] = in[r][c], every other element of out[rows][ld_out] = NaN.  */
+int xmhw_gather_cells_f32(const float *in_dev, int64_t rows, int64_t ld_in,
+                          const int64_t *index_dev, int64_t n, float *out_dev, int64_t ld_out,
+                          void *stream);
+int xmhw_gather_cells_f64(const double *in_dev, int64_t rows, int64_t ld_in,
+                          const int64_t *index_dev, int64_t n, double *out_dev, int64_t ld_out,
+                          void *stream);
+int xmhw_scatter_cells_f64(const double *in_dev, int64_t rows, int64_t ld_in,
+                           const int64_t *index_dev, int64_t n, double *out_dev, int64_t ld_out,
+                           void *stream);
+
 /* Synthetic SST generated in HBM (bench + large parity runs):
  * x[t,c] = 15 + A_c sin(2 pi (t - phi_c)/365.25) + 5e-4 t beta_c + N(0,1),
  * counter-based on (seed, cell0 + c, t); a sample is NaN with probability

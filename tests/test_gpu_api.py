@@ -108,3 +108,35 @@ def test_many_cells_not_multiple_of_tile(h):
         _, t0, s0 = fast.threshold_cells_fast(x, doy)
         npt.assert_allclose(t1, t0, rtol=1e-12)
         npt.assert_allclose(s1, s0, rtol=1e-12)
+
+
+def test_resident_pipeline_mask_compact_clim_scatter(h, oisst):
+    """land_check + calc_clim + unstack entirely on the device: mask -> gather ->
+    raw + finish -> scatter, against the oracle's threshold_grid()."""
+    from xmhw_amd.device import DeviceBuffer, Plan, clim_raw, clim_finish
+    sst = oisst["sst"].reshape(731, 32)
+    T, C = sst.shape
+    d_in = DeviceBuffer.from_array(sst)
+    d_keep = DeviceBuffer(C)
+    h.land_mask(d_in.ptr, 4, T, C, C, 0, d_keep.ptr)
+    h.stream_sync(0)
+    keep = d_keep.to_array((C,), np.uint8).astype(bool)
+    idx = np.nonzero(keep)[0].astype(np.int64)
+    n = idx.size
+    d_idx = DeviceBuffer.from_array(idx)
+    d_ts = DeviceBuffer(4 * T * n)
+    h.gather_cells(d_in.ptr, 4, T, C, d_idx.ptr, n, d_ts.ptr, n)
+    doy = ora.add_doy(oisst["time64"])
+    plan = Plan(doy, 5)
+    D = plan.D
+    raw_t, raw_s, fin_t, fin_s = (DeviceBuffer(8 * D * n) for _ in range(4))
+    clim_raw(plan, d_ts, 4, n, 0.9, False, raw_t, raw_s)
+    clim_finish(plan, raw_t, raw_s, n, True, True, 31, fin_t, fin_s)
+    out_t, out_s = DeviceBuffer(8 * D * C), DeviceBuffer(8 * D * C)
+    h.scatter_cells(fin_t.ptr, D, n, d_idx.ptr, n, out_t.ptr, C)
+    h.scatter_cells(fin_s.ptr, D, n, d_idx.ptr, n, out_s.ptr, C)
+    h.stream_sync(0)
+    ref = ora.threshold_grid(oisst["sst"], oisst["time64"])
+    npt.assert_array_equal(keep, ref["keep"])
+    npt.assert_allclose(out_t.to_array((D, C), np.float64).reshape(D, 8, 4), ref["thresh"], rtol=1e-12, equal_nan=True)
+    npt.assert_allclose(out_s.to_array((D, C), np.float64).reshape(D, 8, 4), ref["seas"], rtol=1e-12, equal_nan=True)

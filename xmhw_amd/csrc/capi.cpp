@@ -474,6 +474,31 @@ int xmhw_land_mask_f64(const double* ts, int64_t T, int64_t C, int64_t ld, int a
     return XMHW_OK;
 }
 
+int xmhw_gather_cells_f32(const float* in, int64_t rows, int64_t ld_in, const int64_t* index, int64_t n,
+                          float* out, int64_t ld_out, void* stream) {
+    if (rows < 0 || n < 0 || ld_out < n) return fail(XMHW_ERR_INVALID, "bad rows/n/ld_out");
+    hipError_t e = xmhw::launch_gather_cells<float>(in, rows, ld_in, index, n, out, ld_out,
+                                                    static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "gather_cells launch");
+    return XMHW_OK;
+}
+int xmhw_gather_cells_f64(const double* in, int64_t rows, int64_t ld_in, const int64_t* index, int64_t n,
+                          double* out, int64_t ld_out, void* stream) {
+    if (rows < 0 || n < 0 || ld_out < n) return fail(XMHW_ERR_INVALID, "bad rows/n/ld_out");
+    hipError_t e = xmhw::launch_gather_cells<double>(in, rows, ld_in, index, n, out, ld_out,
+                                                     static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "gather_cells launch");
+    return XMHW_OK;
+}
+int xmhw_scatter_cells_f64(const double* in, int64_t rows, int64_t ld_in, const int64_t* index, int64_t n,
+                           double* out, int64_t ld_out, void* stream) {
+    if (rows < 0 || n < 0 || ld_in < n) return fail(XMHW_ERR_INVALID, "bad rows/n/ld_in");
+    hipError_t e = xmhw::launch_scatter_cells(in, rows, ld_in, index, n, out, ld_out, ld_out,
+                                              static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "scatter_cells launch");
+    return XMHW_OK;
+}
+
 int xmhw_synth_sst_f32(float* ts, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
                        double nan_frac, void* stream) {
     if (C < 0 || ld < C || T <= 0) return fail(XMHW_ERR_INVALID, "bad T/C/ld");

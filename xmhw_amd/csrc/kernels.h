@@ -40,6 +40,13 @@ hipError_t launch_land_mask(const T* ts, int64_t Tn, int64_t C, int64_t ld, int 
                             uint8_t* keep, hipStream_t stream);
 
 template <typename T>
+hipError_t launch_gather_cells(const T* in, int64_t rows, int64_t ld_in, const int64_t* index, int64_t n,
+                               T* out, int64_t ld_out, hipStream_t stream);
+hipError_t launch_scatter_cells(const double* in, int64_t rows, int64_t ld_in, const int64_t* index,
+                                int64_t n, double* out, int64_t ld_out, int64_t ncols_out,
+                                hipStream_t stream);
+
+template <typename T>
 hipError_t launch_synth(T* ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
                         double nan_frac, hipStream_t stream);
 

@@ -262,6 +262,66 @@ template hipError_t launch_land_mask<double>(const double*, int64_t, int64_t, in
                                              hipStream_t);
 
 // ---------------------------------------------------------------------------
+// gather_cells / scatter_cells: land_check()'s compaction (identify.py:522-525
+// drops land cells from the stacked axis) and the inverse placement that
+// unstack('cell') does for the results (xmhw.py:210-214), on resident data.
+// Row-wise copies: lanes run along the compacted axis, so the compacted side is
+// fully coalesced and the grid side is as contiguous as the ocean mask is.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gather_cells(const T* __restrict__ in, int64_t rows, int64_t ld_in,
+                                                    const int64_t* __restrict__ index, int64_t n,
+                                                    T* __restrict__ out, int64_t ld_out) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const int64_t src = index[c];
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) out[r * ld_out + c] = in[r * ld_in + src];
+}
+
+__global__ __launch_bounds__(256) void scatter_cells(const double* __restrict__ in, int64_t rows,
+                                                     int64_t ld_in, const int64_t* __restrict__ index,
+                                                     int64_t n, double* __restrict__ out, int64_t ld_out) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const int64_t dst = index[c];
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) out[r * ld_out + dst] = in[r * ld_in + c];
+}
+
+__global__ __launch_bounds__(256) void fill_nan(double* __restrict__ out, int64_t count) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = make_nan();
+}
+
+template <typename T>
+hipError_t launch_gather_cells(const T* in, int64_t rows, int64_t ld_in, const int64_t* index, int64_t n,
+                               T* out, int64_t ld_out, hipStream_t stream) {
+    if (n <= 0 || rows <= 0) return hipSuccess;
+    dim3 grid(static_cast<unsigned>((n + 255) / 256), static_cast<unsigned>(rows < 1024 ? rows : 1024));
+    hipLaunchKernelGGL(gather_cells<T>, grid, dim3(256), 0, stream, in, rows, ld_in, index, n, out, ld_out);
+    return hipGetLastError();
+}
+template hipError_t launch_gather_cells<float>(const float*, int64_t, int64_t, const int64_t*, int64_t,
+                                               float*, int64_t, hipStream_t);
+template hipError_t launch_gather_cells<double>(const double*, int64_t, int64_t, const int64_t*, int64_t,
+                                                double*, int64_t, hipStream_t);
+
+hipError_t launch_scatter_cells(const double* in, int64_t rows, int64_t ld_in, const int64_t* index,
+                                int64_t n, double* out, int64_t ld_out, int64_t ncols_out,
+                                hipStream_t stream) {
+    if (rows <= 0) return hipSuccess;
+    // every grid cell that is not an ocean cell is NaN in the result (land)
+    const int64_t total = rows * ld_out;
+    (void)ncols_out;
+    hipLaunchKernelGGL(fill_nan, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, stream, out,
+                       total);
+    if (n > 0) {
+        dim3 grid(static_cast<unsigned>((n + 255) / 256), static_cast<unsigned>(rows < 1024 ? rows : 1024));
+        hipLaunchKernelGGL(scatter_cells, grid, dim3(256), 0, stream, in, rows, ld_in, index, n, out, ld_out);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // synth_sst: counter-based synthetic SST
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double u01(uint64_t h) {  // (0,1)

@@ -185,6 +185,24 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     }, py::arg("ts"), py::arg("itemsize"), py::arg("T"), py::arg("C"), py::arg("ld"), py::arg("anynans"),
        py::arg("keep"), py::arg("stream") = 0);
 
+    m.def("gather_cells", [](uintptr_t in, int itemsize, int64_t rows, int64_t ld_in, uintptr_t index, int64_t n,
+                             uintptr_t out, int64_t ld_out, uintptr_t stream) {
+        if (itemsize == 4)
+            check(xmhw_gather_cells_f32(static_cast<const float*>(vp(in)), rows, ld_in, static_cast<const int64_t*>(vp(index)),
+                                        n, static_cast<float*>(vp(out)), ld_out, vp(stream)));
+        else if (itemsize == 8)
+            check(xmhw_gather_cells_f64(static_cast<const double*>(vp(in)), rows, ld_in, static_cast<const int64_t*>(vp(index)),
+                                        n, static_cast<double*>(vp(out)), ld_out, vp(stream)));
+        else throw InvalidError("itemsize must be 4 or 8");
+    }, py::arg("in"), py::arg("itemsize"), py::arg("rows"), py::arg("ld_in"), py::arg("index"), py::arg("n"),
+       py::arg("out"), py::arg("ld_out"), py::arg("stream") = 0);
+    m.def("scatter_cells", [](uintptr_t in, int64_t rows, int64_t ld_in, uintptr_t index, int64_t n, uintptr_t out,
+                              int64_t ld_out, uintptr_t stream) {
+        check(xmhw_scatter_cells_f64(static_cast<const double*>(vp(in)), rows, ld_in, static_cast<const int64_t*>(vp(index)),
+                                     n, static_cast<double*>(vp(out)), ld_out, vp(stream)));
+    }, py::arg("in"), py::arg("rows"), py::arg("ld_in"), py::arg("index"), py::arg("n"), py::arg("out"),
+       py::arg("ld_out"), py::arg("stream") = 0);
+
     m.def("synth_sst", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
                           double nan_frac, uintptr_t stream) {
         if (itemsize == 4)
