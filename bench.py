@@ -198,6 +198,17 @@ def main():
     ring_avg_ms = float(np.mean(ring_ms))
     achieved = cells_per_launch * bytes_per_cell / (ring_avg_ms * 1e-3) / 1e9
 
+    # HBM traffic per launch from the committed PMC measurement of this kernel (profiles/),
+    # scaled to this run's cells per launch; null if no measurement matches the workload
+    traffic = None
+    try:
+        meas = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))["kernels"]
+        mk = meas.get("clim_ring_" + args.dtype)
+        if mk and mk.get("T") == T and plan.kernel == "ring":
+            traffic = mk["hbm_bytes_per_launch"] * cells_per_launch / mk["cells_per_launch"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
+
     result = {
         "metric": "grid-cells/sec for threshold() on 40yr daily SST",
         "value": value,
@@ -220,7 +231,9 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "kernel": "clim_ring_" + args.dtype, "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "profiles/hbm_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None,
+            "algorithmic_bytes_per_launch": cells_per_launch * bytes_per_cell,
             "algorithmic_bytes_per_cell": bytes_per_cell, "cells_per_launch": cells_per_launch,
             "avg_launch_ms": ring_avg_ms,
         },

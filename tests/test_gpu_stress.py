@@ -1,0 +1,75 @@
+"""Randomised stress: the ring kernels (float32 and float64) must agree bit for
+bit with the generic kernel on the raw percentile for random calendars, windows,
+percentiles, NaN fractions and quantisations (tie density); a subset is also
+checked against the CPU oracle.  Seeds are fixed: failures are reproducible."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+import xmhw_oracle as ora
+import oracle_fast as fast
+
+pytestmark = pytest.mark.gpu
+
+RING_WINDOWS_F32 = {1: 40, 2: 40, 3: 32, 5: 48}     # w -> max tracks instantiated
+RING_WINDOWS_F64 = {1: 16, 2: 32, 3: 32, 5: 48}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from xmhw_amd._lib import require_gpu
+    require_gpu()
+    import xmhw_amd.device as d
+    return d
+
+
+def _case(rng, dtype, windows):
+    w = int(rng.choice(list(windows)))
+    kind = rng.choice(["daily", "daily_partial", "tstep"])
+    if kind == "tstep":
+        n = int(rng.integers(2 * w + 2, 80))
+        ny = int(rng.integers(2, min(windows[w], 12) + 1))
+        doy = np.tile(np.arange(1, n + 1), ny)
+        tstep = True
+    else:
+        y0 = int(rng.integers(1980, 2010))
+        ny = int(rng.integers(2, min(windows[w] - 2, 9) + 1))
+        if kind == "daily":
+            time = np.arange(f"{y0}-01-01", f"{y0 + ny}-01-01", dtype="datetime64[D]")
+        else:
+            a = np.datetime64(f"{y0}-01-01") + int(rng.integers(0, 300))
+            time = np.arange(a, a + int(rng.integers(400, 365 * ny)), dtype="datetime64[D]")
+        doy = ora.add_doy(time)
+        tstep = False
+    T = doy.shape[0]
+    C = int(rng.integers(1, 70))
+    t = np.arange(T)[:, None]
+    x = 15 + rng.uniform(0, 10, C) * np.sin(2 * np.pi * (t - rng.uniform(0, 365, C)) / 365.25) \
+        + rng.normal(size=(T, C)) * rng.uniform(0.01, 3)
+    quant = rng.choice([0, 0, 0.01, 0.5, 2.0])
+    if quant:
+        x = np.round(x / quant) * quant
+    x = x.astype(dtype)
+    nanfrac = rng.choice([0.0, 0.0, 0.02, 0.3, 0.9])
+    if nanfrac:
+        x[rng.random((T, C)) < nanfrac] = np.nan
+    pct = float(rng.choice([0, 1, 10, 50, 75, 90, 95, 99, 100]))
+    return x, doy, w, pct, tstep, bool(rng.integers(0, 2))
+
+
+@pytest.mark.parametrize("dtype,windows,seed", [(np.float32, RING_WINDOWS_F32, 1), (np.float64, RING_WINDOWS_F64, 2)])
+def test_ring_equals_generic_on_random_cases(dev, dtype, windows, seed):
+    rng = np.random.default_rng(seed)
+    for i in range(60):
+        x, doy, w, pct, tstep, cold = _case(rng, dtype, windows)
+        args = (pct, w, False, 31, tstep, cold)
+        d1, t1, s1 = dev.calc_clim_device(x, doy, *args, kernel="ring", nchunks=int(rng.integers(0, 4)))
+        d0, t0, s0 = dev.calc_clim_device(x, doy, *args, kernel="generic")
+        msg = f"case {i}: T={x.shape[0]} C={x.shape[1]} w={w} pct={pct} tstep={tstep} cold={cold}"
+        npt.assert_array_equal(t1, t0, err_msg=msg)
+        npt.assert_allclose(s1, s0, rtol=1e-12, atol=1e-300, equal_nan=True, err_msg=msg)
+        if i % 6 == 0:
+            _, to, so = fast.threshold_cells_fast(x, doy, pctile=pct, windowHalfWidth=w, smoothPercentile=False,
+                                                  tstep=tstep, coldSpells=cold)
+            npt.assert_allclose(t1, to, rtol=1e-12, equal_nan=True, err_msg=msg)
+            npt.assert_allclose(s1, so, rtol=1e-11, atol=1e-13, equal_nan=True, err_msg=msg)
