@@ -140,3 +140,19 @@ def test_resident_pipeline_mask_compact_clim_scatter(h, oisst):
     npt.assert_array_equal(keep, ref["keep"])
     npt.assert_allclose(out_t.to_array((D, C), np.float64).reshape(D, 8, 4), ref["thresh"], rtol=1e-12, equal_nan=True)
     npt.assert_allclose(out_s.to_array((D, C), np.float64).reshape(D, 8, 4), ref["seas"], rtol=1e-12, equal_nan=True)
+
+
+def test_cell_batches_give_identical_results(h):
+    """calc_clim_device in several cell batches == one batch (cells are independent)."""
+    from xmhw_amd.device import calc_clim_device
+    time = np.arange("2001-01-01", "2006-01-01", dtype="datetime64[D]")
+    doy = ora.add_doy(time)
+    rng = np.random.default_rng(8)
+    x = (15 + rng.normal(size=(time.shape[0], 45))).astype(np.float32)
+    x[rng.random(x.shape) < 0.02] = np.nan
+    one = calc_clim_device(x, doy, 90, 5, True, 31, False)
+    many = calc_clim_device(x, doy, 90, 5, True, 31, False, max_batch_bytes=7 * x.shape[0] * 4)
+    for a, b in zip(one, many):
+        npt.assert_array_equal(a, b)
+    empty = calc_clim_device(x[:, :0], doy, 90, 5, True, 31, False)
+    assert empty[1].shape == (366, 0)

@@ -104,33 +104,58 @@ def clim_finish(plan, th_in, se_in, C, feb29_fix, smooth, width, th_out, se_out,
 
 
 def calc_clim_device(ts, doy, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
-                     tstep, coldSpells=False, kernel="auto", nchunks=0):
+                     tstep, coldSpells=False, kernel="auto", nchunks=0, max_batch_bytes=32 << 30):
     """calc_clim() (xmhw/xmhw.py:250-307) for all cells of a dense host (T, C)
-    array on the GPU.  Returns (doys[D] int64, thresh[D, C], seas[D, C])."""
+    array on the GPU.  Returns (doys[D] int64, thresh[D, C], seas[D, C]).
+
+    Cells are independent, so the array is processed in contiguous cell batches of at
+    most ``max_batch_bytes`` of input (one plan, device buffers reused); the result is
+    identical to a single call.  PCIe-inclusive: the input is copied to the device.
+    """
     ts = np.asarray(ts)
     if ts.dtype not in (np.float32, np.float64):
         ts = ts.astype(np.float64)
-    ts = np.ascontiguousarray(ts)
+    if ts.ndim != 2:
+        raise XmhwException("calc_clim_device expects a (time, cell) array")
     T, C = ts.shape
     h = hip()
     plan = Plan(doy, windowHalfWidth, kernel=kernel, nchunks=nchunks)
+    bufs = []
     try:
         D = plan.D
-        d_ts = DeviceBuffer.from_array(ts)
-        raw_th, raw_se = DeviceBuffer(8 * D * C), DeviceBuffer(8 * D * C)
-        clim_raw(plan, d_ts, ts.dtype.itemsize, C, pctile / 100.0, coldSpells, raw_th, raw_se)
+        th = np.empty((D, C), dtype=np.float64)
+        se = np.empty((D, C), dtype=np.float64)
+        if C == 0:
+            return plan.doys.copy(), th, se
+        isz = ts.dtype.itemsize
+        cb = int(max(1, min(C, max_batch_bytes // max(1, T * isz))))
         feb29_fix = tstep is False
-        if feb29_fix or smoothPercentile:
-            out_th, out_se = DeviceBuffer(8 * D * C), DeviceBuffer(8 * D * C)
-            clim_finish(plan, raw_th, raw_se, C, feb29_fix, smoothPercentile, smoothPercentileWidth,
-                        out_th, out_se)
+        finish = feb29_fix or smoothPercentile
+        d_ts = DeviceBuffer(isz * T * cb)
+        raw_th, raw_se = DeviceBuffer(8 * D * cb), DeviceBuffer(8 * D * cb)
+        bufs += [d_ts, raw_th, raw_se]
+        if finish:
+            out_th, out_se = DeviceBuffer(8 * D * cb), DeviceBuffer(8 * D * cb)
+            bufs += [out_th, out_se]
         else:
             out_th, out_se = raw_th, raw_se
-        h.stream_sync(0)
-        th = out_th.to_array((D, C), np.float64)
-        se = out_se.to_array((D, C), np.float64)
-        for b in (d_ts, raw_th, raw_se, out_th, out_se):
-            b.free()
+        for lo in range(0, C, cb):
+            n = min(cb, C - lo)
+            slab = np.ascontiguousarray(ts[:, lo:lo + n])
+            h.memcpy_h2d(d_ts.ptr, slab)
+            clim_raw(plan, d_ts, isz, n, pctile / 100.0, coldSpells, raw_th, raw_se)
+            if finish:
+                clim_finish(plan, raw_th, raw_se, n, feb29_fix, smoothPercentile, smoothPercentileWidth,
+                            out_th, out_se)
+            h.stream_sync(0)
+            bt = np.empty((D, n), dtype=np.float64)
+            bs = np.empty((D, n), dtype=np.float64)
+            h.memcpy_d2h(bt, out_th.ptr)
+            h.memcpy_d2h(bs, out_se.ptr)
+            th[:, lo:lo + n] = bt
+            se[:, lo:lo + n] = bs
         return plan.doys.copy(), th, se
     finally:
+        for b in bufs:
+            b.free()
         plan.destroy()
