@@ -149,8 +149,8 @@ def main():
                     for a, b in slabs]
     torch.cuda.synchronize()
 
-    ev = [(h.event_create(), h.event_create()) for _ in slabs]
-    ring_ms = []
+    ev = [(h.event_create(), h.event_create(), h.event_create()) for _ in slabs]
+    ring_ms, finish_ms = [], []
 
     def step(timed):
         works = []
@@ -162,6 +162,7 @@ def main():
             h.event_record(ev[i][1], stream)
             clim_finish(plan, raw_th[i].data_ptr(), raw_se[i].data_ptr(), n, not tstep, True, width,
                         out[i][0].data_ptr(), out[i][1].data_ptr(), ldo=n, stream=stream)
+            h.event_record(ev[i][2], stream)
             if world > 1:
                 works.append(dist.gather(out[i], gathered[i] if rank == 0 else None, dst=0, async_op=True))
         for wk in works:
@@ -170,6 +171,7 @@ def main():
             torch.cuda.synchronize()
             for i in range(len(slabs)):
                 ring_ms.append(h.event_elapsed_ms(ev[i][0], ev[i][1]))
+                finish_ms.append(h.event_elapsed_ms(ev[i][1], ev[i][2]))
 
     for _ in range(args.warmup):
         step(False)
@@ -237,6 +239,7 @@ def main():
             "algorithmic_bytes_per_cell": bytes_per_cell, "cells_per_launch": cells_per_launch,
             "avg_launch_ms": ring_avg_ms,
         },
+        "finish_kernel_avg_launch_ms": float(np.mean(finish_ms)),
     }
 
     # ---- parity subset + CPU baseline (rank 0, N=1) ------------------------------------
