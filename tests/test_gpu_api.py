@@ -156,3 +156,32 @@ def test_cell_batches_give_identical_results(h):
         npt.assert_array_equal(a, b)
     empty = calc_clim_device(x[:, :0], doy, 90, 5, True, 31, False)
     assert empty[1].shape == (366, 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_strided_slabs_ld_and_ldo(h, dtype):
+    """A slab of a wider resident array: ld > C on input, ldo > C on output (what
+    bench.py does per slab and per rank)."""
+    from xmhw_amd.device import DeviceBuffer, Plan, clim_raw, clim_finish
+    time = np.arange("2001-01-01", "2005-01-01", dtype="datetime64[D]")
+    doy = ora.add_doy(time)
+    T, Cfull, a, n = time.shape[0], 50, 13, 21
+    rng = np.random.default_rng(5)
+    x = (15 + rng.normal(size=(T, Cfull))).astype(dtype)
+    plan = Plan(doy, 5)
+    D, isz = plan.D, x.dtype.itemsize
+    d_x = DeviceBuffer.from_array(x)
+    ldo = 32
+    raw_t, raw_s, out_t, out_s = (DeviceBuffer(8 * D * ldo) for _ in range(4))
+    for b in (raw_t, raw_s, out_t, out_s):
+        h.memset(b.ptr, 0xFF, 8 * D * ldo)
+    clim_raw(plan, d_x.ptr + isz * a, isz, n, 0.9, False, raw_t, raw_s, ld=Cfull, ldo=ldo)
+    clim_finish(plan, raw_t, raw_s, n, True, True, 31, out_t, out_s, ldo=ldo)
+    h.stream_sync(0)
+    got_t = out_t.to_array((D, ldo), np.float64)
+    got_s = out_s.to_array((D, ldo), np.float64)
+    _, t0, s0 = fast.threshold_cells_fast(x[:, a:a + n], doy)
+    npt.assert_allclose(got_t[:, :n], t0, rtol=1e-12)
+    npt.assert_allclose(got_s[:, :n], s0, rtol=1e-12)
+    # the padding columns of the output rows were not touched
+    assert np.isnan(got_t[:, n:]).all() and (got_t[:, n:].view(np.uint64) == 0xFFFFFFFFFFFFFFFF).all()
