@@ -21,7 +21,7 @@ namespace r64 {
 constexpr int kWavesPerBlock = 4;
 constexpr int kSubs = 16;
 constexpr int kCells = 4;
-constexpr int kTopJ = 4;
+constexpr int kTopJ = 6;
 constexpr int kCountBudget = 6;
 constexpr uint64_t kKeyNegInf = 0x000FFFFFFFFFFFFFull;  // f64_key(-inf): smallest valid key
 
