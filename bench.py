@@ -203,11 +203,24 @@ def main():
     # HBM traffic per launch from the committed PMC measurement of this kernel (profiles/),
     # scaled to this run's cells per launch; null if no measurement matches the workload
     traffic = None
+    valu = None
     try:
-        meas = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))["kernels"]
-        mk = meas.get("clim_ring_" + args.dtype)
+        prof = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        mk = prof["kernels"].get("clim_ring_" + args.dtype)
         if mk and mk.get("T") == T and plan.kernel == "ring":
             traffic = mk["hbm_bytes_per_launch"] * cells_per_launch / mk["cells_per_launch"]
+            if "valu_insts_per_wave_row" in mk:
+                # the resource that actually binds the kernel: VALU issue.
+                # wave-instructions per launch from the committed PMC count, peak = 256 CUs x
+                # 4 SIMDs x clock / measured issue cycles of the ops the kernel is made of
+                rows = D + 10                              # + ring warm-up steps
+                insts = mk["valu_insts_per_wave_row"] * rows * cells_per_launch / mk["cells_per_wave"]
+                peak = 256 * 4 * 2.4e9 / prof["valu_issue_cycles_per_inst"]
+                ach = insts / (ring_avg_ms * 1e-3)
+                valu = {"bound": "valu-issue", "achieved": ach / 1e9, "peak": peak / 1e9,
+                        "unit": "G wave-instructions/s", "frac": ach / peak,
+                        "valu_insts_per_cell_row": mk["valu_insts_per_wave_row"] / mk["cells_per_wave"],
+                        "source": "profiles/r1_pmc_sq.txt, profiles/r1_ubench_valu.txt"}
     except (OSError, KeyError, ValueError):
         traffic = None
 
@@ -239,6 +252,7 @@ def main():
             "algorithmic_bytes_per_cell": bytes_per_cell, "cells_per_launch": cells_per_launch,
             "avg_launch_ms": ring_avg_ms,
         },
+        "roofline_binding_resource": valu,
         "finish_kernel_avg_launch_ms": float(np.mean(finish_ms)),
     }
 
