@@ -154,6 +154,26 @@ int xmhw_scatter_cells_f64(const double *in_dev, int64_t rows, int64_t ld_in,
                            const int64_t *index_dev, int64_t n, double *out_dev, int64_t ld_out,
                            void *stream);
 
+/* ---- detect() front end (next row of the path) ---------------------- *
+ * For every cell: bthresh[t] = ts[t] > thresh[row_of_t[t]] (define_events(),
+ * identify.py:366-372; NaN compares false; negate != 0 works on -ts, xmhw.py:413-414),
+ * then mhw_filter() (identify.py:415-479) with join_gaps()/join_events() (identify.py:273-325,
+ * :532-536).  row_of_t_host[T]: index of each step's doy label among the rows of thresh (HOST).
+ * Outputs are int32 [T][ldo] with -1 where the reference has NaN: events = label (start
+ * position) of the event covering a step; start = start label stored at the END step of the
+ * first member of a joined event; end = end step stored at the end step of its last member.
+ * bthresh_dev may be NULL.                                                              */
+int xmhw_detect_events_f32(const float *ts_dev, int64_t T, int64_t C, int64_t ld,
+                           const double *thresh_dev, int64_t ldt, const int32_t *row_of_t_host,
+                           int32_t min_duration, int32_t join_gaps, int32_t max_gap, int32_t negate,
+                           int32_t *events_dev, int32_t *start_dev, int32_t *end_dev,
+                           uint8_t *bthresh_dev, int64_t ldo, void *stream);
+int xmhw_detect_events_f64(const double *ts_dev, int64_t T, int64_t C, int64_t ld,
+                           const double *thresh_dev, int64_t ldt, const int32_t *row_of_t_host,
+                           int32_t min_duration, int32_t join_gaps, int32_t max_gap, int32_t negate,
+                           int32_t *events_dev, int32_t *start_dev, int32_t *end_dev,
+                           uint8_t *bthresh_dev, int64_t ldo, void *stream);
+
 /* Synthetic SST generated in HBM (bench + large parity runs):
  * x[t,c] = 15 + A_c sin(2 pi (t - phi_c)/365.25) + 5e-4 t beta_c + N(0,1),
  * counter-based on (seed, cell0 + c, t); a sample is NaN with probability

@@ -204,6 +204,32 @@ int clim_oneshot(const T* ts, const int32_t* doy, int64_t Tn, int64_t C, int32_t
 }
 
 template <typename T>
+int detect_events(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* thresh, int64_t ldt,
+                  const int32_t* row_of_t, int32_t min_duration, int32_t join_gaps, int32_t max_gap,
+                  int32_t negate, int32_t* events, int32_t* start, int32_t* end, uint8_t* bthresh,
+                  int64_t ldo, void* stream) {
+    if (Tn <= 0 || C < 0 || ld < C || ldt < C || ldo < C) return fail(XMHW_ERR_INVALID, "bad T/C/ld/ldt/ldo");
+    if (min_duration < 1 || max_gap < 0) return fail(XMHW_ERR_INVALID, "minDuration must be >= 1 and maxGap >= 0");
+    if (C == 0) return XMHW_OK;
+    if (!ts || !thresh || !row_of_t || !events || !start || !end)
+        return fail(XMHW_ERR_INVALID, "NULL buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int32_t* d_rows = nullptr;
+    HIP_TRY(hipMalloc(&d_rows, sizeof(int32_t) * static_cast<size_t>(Tn)));
+    hipError_t e = hipMemcpyAsync(d_rows, row_of_t, sizeof(int32_t) * static_cast<size_t>(Tn),
+                                  hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = xmhw::launch_detect<T>(ts, Tn, C, ld, thresh, ldt, d_rows, min_duration, join_gaps, max_gap, negate,
+                                   events, start, end, bthresh, ldo, st);
+    // the row table must outlive the kernel: synchronise before releasing it
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_rows);
+    if (e != hipSuccess) return hip_fail(e, "detect_events launch");
+    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
+    return XMHW_OK;
+}
+
+template <typename T>
 int clim_host(const T* ts, const int32_t* doy, int64_t Tn, int64_t C, int32_t D, int32_t w, double q,
               int smooth, int smooth_w, int feb29_fix, int negate, double* thresh, double* seas) {
     if (C == 0) return XMHW_OK;
@@ -497,6 +523,21 @@ int xmhw_scatter_cells_f64(const double* in, int64_t rows, int64_t ld_in, const 
                                               static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail(e, "scatter_cells launch");
     return XMHW_OK;
+}
+
+int xmhw_detect_events_f32(const float* ts, int64_t T, int64_t C, int64_t ld, const double* thresh, int64_t ldt,
+                           const int32_t* row_of_t, int32_t min_duration, int32_t join_gaps, int32_t max_gap,
+                           int32_t negate, int32_t* events, int32_t* start, int32_t* end, uint8_t* bthresh,
+                           int64_t ldo, void* stream) {
+    return detect_events<float>(ts, T, C, ld, thresh, ldt, row_of_t, min_duration, join_gaps, max_gap, negate,
+                                events, start, end, bthresh, ldo, stream);
+}
+int xmhw_detect_events_f64(const double* ts, int64_t T, int64_t C, int64_t ld, const double* thresh, int64_t ldt,
+                           const int32_t* row_of_t, int32_t min_duration, int32_t join_gaps, int32_t max_gap,
+                           int32_t negate, int32_t* events, int32_t* start, int32_t* end, uint8_t* bthresh,
+                           int64_t ldo, void* stream) {
+    return detect_events<double>(ts, T, C, ld, thresh, ldt, row_of_t, min_duration, join_gaps, max_gap, negate,
+                                 events, start, end, bthresh, ldo, stream);
 }
 
 int xmhw_synth_sst_f32(float* ts, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,

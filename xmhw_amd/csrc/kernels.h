@@ -46,6 +46,13 @@ hipError_t launch_scatter_cells(const double* in, int64_t rows, int64_t ld_in, c
                                 int64_t n, double* out, int64_t ld_out, int64_t ncols_out,
                                 hipStream_t stream);
 
+// detect() front end: exceedance + event filter + gap joining, thread per cell
+template <typename T>
+hipError_t launch_detect(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* thresh, int64_t ldt,
+                         const int32_t* row_of_t, int32_t min_duration, int32_t join_gaps, int32_t max_gap,
+                         int32_t negate, int32_t* events, int32_t* start, int32_t* end, uint8_t* bthresh,
+                         int64_t ldo, hipStream_t stream);
+
 template <typename T>
 hipError_t launch_synth(T* ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
                         double nan_frac, hipStream_t stream);
