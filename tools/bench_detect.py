@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Measurement of the detect() front-end kernel on one MI355X:
+synthetic SST resident in HBM -> threshold() climatology (ring + finish) -> detect_events.
+Prints one JSON line: cells/s, achieved HBM GB/s (algorithmic bytes = T*(4 in + 13 out) + D*8 per
+cell) and the loop-oracle CPU baseline on a small sample.   python tools/bench_detect.py [cells]"""
+import json, os, sys, time
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np
+from xmhw_amd._lib import hip
+from xmhw_amd.device import Plan, DeviceBuffer, clim_raw, clim_finish
+from xmhw_amd.calendar import add_doy
+
+h = hip()
+C = int(sys.argv[1]) if len(sys.argv) > 1 else 259200
+steps = 5
+t = np.arange("1982-01-01", "2022-01-01", dtype="datetime64[D]")
+doy = add_doy(t); T = len(doy)
+plan = Plan(doy, 5)
+D = plan.D
+rows = np.searchsorted(plan.doys, doy).astype(np.int32)
+ts = DeviceBuffer(4 * T * C)
+h.synth_sst(ts.ptr, 4, T, C, C, 0, 20260105, 0.0, 0)
+raw_t, raw_s, th, se = (DeviceBuffer(8 * D * C) for _ in range(4))
+clim_raw(plan, ts, 4, C, 0.9, False, raw_t, raw_s)
+clim_finish(plan, raw_t, raw_s, C, True, True, 31, th, se)
+ev, st, en = (DeviceBuffer(4 * T * C) for _ in range(3))
+b = DeviceBuffer(T * C)
+h.stream_sync(0)
+e0, e1 = h.event_create(), h.event_create()
+ms = []
+for i in range(steps + 1):
+    h.event_record(e0, 0)
+    h.detect_events(ts.ptr, 4, T, C, C, th.ptr, C, rows, 5, 1, 2, 0, ev.ptr, st.ptr, en.ptr, b.ptr, C)
+    h.event_record(e1, 0)
+    if i: ms.append(h.event_elapsed_ms(e0, e1))
+ms = float(np.mean(ms))
+bytes_cell = T * (4 + 13) + D * 8
+# parity + CPU baseline on a sample
+import detect_oracle as det
+n = 64
+idx = DeviceBuffer.from_array(np.arange(n, dtype=np.int64))
+def sample(buf, itemsize, rows_, dtype):
+    """first n columns of a resident (rows_, C) array via the gather kernel"""
+    out = DeviceBuffer(itemsize * rows_ * n)
+    if itemsize == 8 and dtype == np.float64:
+        h.gather_cells(buf.ptr, 8, rows_, C, idx.ptr, n, out.ptr, n)
+    else:
+        h.gather_cells(buf.ptr, 4, rows_, C, idx.ptr, n, out.ptr, n)
+    h.stream_sync(0)
+    return out.to_array((rows_, n), dtype)
+x = sample(ts, 4, T, np.float32)
+res = {"stage": "detect front end (exceedance + mhw_filter + join_gaps)", "cells": C, "T": T,
+       "ms_per_launch": ms, "cells_per_s": C / (ms * 1e-3),
+       "roofline": {"bound": "hbm", "achieved": C * bytes_cell / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "frac": C * bytes_cell / (ms * 1e-3) / 8e12, "algorithmic_bytes_per_cell": bytes_cell}}
+if x is not None:
+    thh = sample(th, 8, D, np.float64)
+    evh = sample(ev, 4, T, np.float32).view(np.int32)
+    t0 = time.perf_counter()
+    ok = True
+    for c in range(n):
+        _, s_, e_, v_ = det.detect_front(x[:, c], thh[:, c], rows, 5, True, 2)
+        v_ = np.where(np.isnan(v_), -1, v_).astype(np.int32)
+        ok &= bool(np.array_equal(v_, evh[:, c]))
+    dt = time.perf_counter() - t0
+    res["parity_events_bit_exact"] = ok
+    res["cpu_baseline"] = {"value": n / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+                           "sample": f"{n} cells, loop oracle (oracle/detect_oracle.py), one core"}
+print(json.dumps(res))

@@ -29,45 +29,58 @@ __global__ __launch_bounds__(256) void detect_events(
     bool have_prev = false;    // a selected event exists before the current one
     int64_t prev_end = -1;
     int32_t group_start = 0;
-    for (int64_t t = 0; t < Tn; ++t) {
-        T x = ts[t * ld + c];
-        if (negate) x = -x;
-        const double th = thresh[static_cast<int64_t>(row_of_t[t]) * ldt + c];
-        const bool b = static_cast<double>(x) > th;   // NaN on either side -> false
-        if (bthresh) bthresh[t * ldo + c] = b ? 1 : 0;
-        start[t * ldo + c] = -1;
-        end[t * ldo + c] = -1;
-        int32_t ev = -1;
-        if (b) {
-            if (!in_run) {
-                in_run = true;
-                p = prev_nonexc >= 0 ? prev_nonexc : 0;   // fillna(0)
-                run_first = t;
-            }
-            if (t - p != 0) ev = static_cast<int32_t>(p + 1);
+    constexpr int U = 8;  // steps loaded ahead of the state machine (memory-level parallelism)
+    for (int64_t t0 = 0; t0 < Tn; t0 += U) {
+        T xs[U];
+        double ths[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t t = t0 + u < Tn ? t0 + u : Tn - 1;
+            xs[u] = ts[t * ld + c];
+            ths[u] = thresh[static_cast<int64_t>(row_of_t[t]) * ldt + c];
         }
-        events[t * ldo + c] = ev;
-        if (in_run && (!b || t == Tn - 1)) {
-            const int64_t te = b ? t : t - 1;
-            if (te - p >= min_duration) {
-                const int32_t S = static_cast<int32_t>(p + 1);
-                const bool joined = join_gaps && have_prev && (S - prev_end <= max_gap + 1);
-                if (joined) {
-                    end[prev_end * ldo + c] = -1;
-                    for (int64_t k = prev_end + 1; k <= te; ++k) events[k * ldo + c] = group_start;
-                } else {
-                    group_start = S;
-                    start[te * ldo + c] = S;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t t = t0 + u;
+            if (t >= Tn) break;
+            T x = xs[u];
+            if (negate) x = -x;
+            const bool b = static_cast<double>(x) > ths[u];   // NaN on either side -> false
+            if (bthresh) bthresh[t * ldo + c] = b ? 1 : 0;
+            start[t * ldo + c] = -1;
+            end[t * ldo + c] = -1;
+            int32_t ev = -1;
+            if (b) {
+                if (!in_run) {
+                    in_run = true;
+                    p = prev_nonexc >= 0 ? prev_nonexc : 0;   // fillna(0)
+                    run_first = t;
                 }
-                end[te * ldo + c] = static_cast<int32_t>(te);
-                prev_end = te;
-                have_prev = true;
-            } else {
-                for (int64_t k = run_first; k <= te; ++k) events[k * ldo + c] = -1;
+                if (t - p != 0) ev = static_cast<int32_t>(p + 1);
             }
-            in_run = false;
+            events[t * ldo + c] = ev;
+            if (in_run && (!b || t == Tn - 1)) {
+                const int64_t te = b ? t : t - 1;
+                if (te - p >= min_duration) {
+                    const int32_t S = static_cast<int32_t>(p + 1);
+                    const bool joined = join_gaps && have_prev && (S - prev_end <= max_gap + 1);
+                    if (joined) {
+                        end[prev_end * ldo + c] = -1;
+                        for (int64_t k = prev_end + 1; k <= te; ++k) events[k * ldo + c] = group_start;
+                    } else {
+                        group_start = S;
+                        start[te * ldo + c] = S;
+                    }
+                    end[te * ldo + c] = static_cast<int32_t>(te);
+                    prev_end = te;
+                    have_prev = true;
+                } else {
+                    for (int64_t k = run_first; k <= te; ++k) events[k * ldo + c] = -1;
+                }
+                in_run = false;
+            }
+            if (!b) prev_nonexc = t;
         }
-        if (!b) prev_nonexc = t;
     }
 }
 
