@@ -40,7 +40,13 @@ def gather_blocks(th, se, ncells, group=None, dst=0, device=None):
     bounds = slab_bounds(ncells, world)
     width = max(hi - lo for lo, hi in bounds)
     D = th.shape[0]
-    dev = device or torch.device("cpu")
+    if device is None:
+        # RCCL ("nccl") moves device memory only; gloo (CPU tests) takes host tensors
+        if dist.get_backend(group) == "nccl":
+            device = torch.device("cuda", torch.cuda.current_device())
+        else:
+            device = torch.device("cpu")
+    dev = device
     block = torch.full((2, D, width), float("nan"), dtype=torch.float64, device=dev)
     n_r = bounds[rank][1] - bounds[rank][0]
     if n_r:
