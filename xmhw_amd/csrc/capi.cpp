@@ -9,6 +9,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "kernels.h"
@@ -86,26 +87,21 @@ int upload(xmhw_plan* p, int64_t C) {
     if (p->uploaded && nchunks == p->nchunks) return XMHW_OK;
     const xmhw::Plan& h = p->host;
     if (!p->uploaded) {
-        HIP_TRY(hipMalloc(&p->d_row_ptr, sizeof(int32_t) * h.row_ptr.size()));
-        HIP_TRY(hipMemcpy(p->d_row_ptr, h.row_ptr.data(), sizeof(int32_t) * h.row_ptr.size(),
-                          hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc(&p->d_centres, sizeof(int32_t) * h.centres.size()));
-        HIP_TRY(hipMemcpy(p->d_centres, h.centres.data(), sizeof(int32_t) * h.centres.size(),
-                          hipMemcpyHostToDevice));
+        // every table is allocated at most once: a failed upload can be retried without leaking
+        auto put = [](auto** dst, const auto& v) -> hipError_t {
+            using E = typename std::remove_reference<decltype(v)>::type::value_type;
+            if (*dst == nullptr) {
+                hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), sizeof(E) * v.size());
+                if (e != hipSuccess) { *dst = nullptr; return e; }
+            }
+            return hipMemcpy(*dst, v.data(), sizeof(E) * v.size(), hipMemcpyHostToDevice);
+        };
+        HIP_TRY(put(&p->d_row_ptr, h.row_ptr));
+        HIP_TRY(put(&p->d_centres, h.centres));
         p->yps = xmhw::ring_pick_yps(h.w, h.ntracks, 4);
-        if (p->yps) {
-            std::vector<uint32_t> tab = h.ring_table(kSubs, p->yps);
-            HIP_TRY(hipMalloc(&p->d_table, sizeof(uint32_t) * tab.size()));
-            HIP_TRY(hipMemcpy(p->d_table, tab.data(), sizeof(uint32_t) * tab.size(),
-                              hipMemcpyHostToDevice));
-        }
+        if (p->yps) HIP_TRY(put(&p->d_table, h.ring_table(kSubs, p->yps)));
         p->yps64 = xmhw::ring64_pick_yps(h.w, h.ntracks);
-        if (p->yps64) {
-            std::vector<uint32_t> tab = h.ring_table(16, p->yps64);
-            HIP_TRY(hipMalloc(&p->d_table64, sizeof(uint32_t) * tab.size()));
-            HIP_TRY(hipMemcpy(p->d_table64, tab.data(), sizeof(uint32_t) * tab.size(),
-                              hipMemcpyHostToDevice));
-        }
+        if (p->yps64) HIP_TRY(put(&p->d_table64, h.ring_table(16, p->yps64)));
     }
     if (p->yps || p->yps64) {
         std::vector<xmhw::Chunk> ch = h.make_chunks(nchunks);
