@@ -420,6 +420,9 @@ __global__ __launch_bounds__(256) void clim_ring_f64(
             }
         }
 
+        // occasional rendezvous of the workgroup's waves, which share every 128-B row segment
+        // (see kernels_ring.hip: keeps the L2-miss traffic at the input size)
+        if ((s & 63) == 63) __syncthreads();
 #pragma unroll
         for (int y = 0; y < YPS; ++y) {
             e_cur[y] = e_nxt[y];
