@@ -1,5 +1,5 @@
 """Host side of threshold() (xmhw/xmhw.py:38-247) without a GPU: the device
-stage is replaced by the CPU oracle through the `_compute` test hook, so that
+stage is replaced by the CPU oracle through the private `api._threshold(temp, compute, ...)`, so that
 validation, period slicing, land masking, doy labels, unstacking and attrs are
 checked against the oracle's threshold_grid()."""
 from datetime import date
@@ -12,6 +12,7 @@ import xmhw_oracle as ora
 import oracle_fast as fast
 import xmhw_amd
 from xmhw_amd import GridSeries, XmhwException, threshold
+from xmhw_amd.api import _threshold
 
 
 def oracle_compute(ts, doy, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
@@ -33,23 +34,23 @@ def grid(oisst):
 def test_exceptions_like_the_reference(oisst):
     g = grid(oisst)
     with pytest.raises(XmhwException):                       # xmhw.py:103-104
-        threshold(g, smoothPercentileWidth=6, _compute=oracle_compute)
+        _threshold(g, oracle_compute, smoothPercentileWidth=6)
     with pytest.raises(XmhwException):                       # xmhw.py:105-109
-        threshold(g, tdim="t", _compute=oracle_compute)
+        _threshold(g, oracle_compute, tdim="t")
     land = GridSeries(np.full((731, 3, 2), np.nan, np.float32), ("time", "lat", "lon"),
                       {"time": oisst["time64"], "lat": np.arange(3), "lon": np.arange(2)})
     with pytest.raises(XmhwException):                       # identify.py:527-528
-        threshold(land, _compute=oracle_compute)
+        _threshold(land, oracle_compute)
     empty = GridSeries(oisst["sst"][:, :0], ("time", "lat", "lon"),
                        {"time": oisst["time64"], "lat": np.arange(0), "lon": oisst["lon"]})
     with pytest.raises(XmhwException):                       # identify.py:514-516
-        threshold(empty, _compute=oracle_compute)
+        _threshold(empty, oracle_compute)
     with pytest.raises(XmhwException):
-        threshold(g, maxPadLength=3, _compute=oracle_compute)
+        _threshold(g, oracle_compute, maxPadLength=3)
 
 
 def test_grid_layout_attrs_and_values(oisst):
-    ds = threshold(grid(oisst), skipna=True, _compute=oracle_compute)
+    ds = _threshold(grid(oisst), oracle_compute, skipna=True)
     ref = ora.threshold_grid(oisst["sst"], oisst["time64"])
     keep = ref["keep"].reshape(8, 4)
     rows, cols = keep.any(axis=1), keep.any(axis=0)
@@ -75,7 +76,7 @@ def test_grid_layout_attrs_and_values(oisst):
 def test_point_path(oisst):
     x = oisst["sst"][:, 1, 2]
     g = GridSeries(x, ("time",), {"time": oisst["time64"]})
-    ds = threshold(g, smoothPercentile=False, _compute=oracle_compute)
+    ds = _threshold(g, oracle_compute, smoothPercentile=False)
     ref = ora.threshold_grid(x, oisst["time64"], dims=("time",), smoothPercentile=False)
     assert ds.dims == ("doy",) and ds["thresh"].shape == (366,)
     npt.assert_allclose(ds["thresh"], ref["thresh"], rtol=1e-13)
@@ -84,14 +85,14 @@ def test_point_path(oisst):
 
 def test_climatology_period_both_truthy_only(oisst):
     g = grid(oisst)
-    a = threshold(g, climatologyPeriod=[2004, 2004], smoothPercentile=False, _compute=oracle_compute)
+    a = _threshold(g, oracle_compute, climatologyPeriod=[2004, 2004], smoothPercentile=False)
     ref = ora.threshold_grid(oisst["sst"], oisst["time64"], climatologyPeriod=(2004, 2004),
                              smoothPercentile=False)
     keep = ref["keep"].reshape(8, 4)
     npt.assert_allclose(a["thresh"], ref["thresh"][:, keep.any(axis=1)][:, :, keep.any(axis=0)],
                         rtol=1e-13, equal_nan=True)
     assert "2004-2004" in a.attrs["xmhw_parameters"]
-    b = threshold(g, climatologyPeriod=[2004, None], smoothPercentile=False, _compute=oracle_compute)
+    b = _threshold(g, oracle_compute, climatologyPeriod=[2004, None], smoothPercentile=False)
     assert "2003-2004" in b.attrs["xmhw_parameters"]          # quirk Q7: ignored unless both set
 
 
@@ -101,13 +102,13 @@ def test_anynans_drops_cells_and_sorted_dim_order(oisst):
     # dims given as (lon, time, lat): the stacked order is still sorted names (lat, lon)
     v = np.transpose(sst, (2, 0, 1))
     g = GridSeries(v, ("lon", "time", "lat"), {"time": oisst["time64"], "lat": oisst["lat"], "lon": oisst["lon"]})
-    ds = threshold(g, anynans=True, smoothPercentile=False, _compute=oracle_compute)
+    ds = _threshold(g, oracle_compute, anynans=True, smoothPercentile=False)
     assert ds.dims == ("doy", "lat", "lon")
     i = list(ds.coords["lat"]).index(oisst["lat"][1])
     j = list(ds.coords["lon"]).index(oisst["lon"][2])
     assert np.isnan(ds["thresh"][:, i, j]).all()
     assert "any grid point with even only 1 NaN" in ds.attrs["xmhw_parameters"]
-    ds2 = threshold(g, smoothPercentile=False, _compute=oracle_compute)
+    ds2 = _threshold(g, oracle_compute, smoothPercentile=False)
     assert np.isfinite(ds2["thresh"][:, i, j]).all()
 
 
@@ -125,7 +126,7 @@ def test_360_day_calendar_forces_tstep():
         seen["doy"] = doy
         seen["tstep"] = a[4]
         return oracle_compute(ts, doy, *a)
-    threshold(g, windowHalfWidth=1, smoothPercentileWidth=3, _compute=spy)
+    _threshold(g, spy, windowHalfWidth=1, smoothPercentileWidth=3)
     assert seen["tstep"] is True                               # xmhw.py:143-144
     npt.assert_array_equal(seen["doy"], ora.add_doy(time, keep_tstep=True))
 

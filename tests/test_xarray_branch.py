@@ -68,14 +68,14 @@ def oracle_compute(ts, doy, pctile, w, smooth, width, tstep, cold=False):
 
 
 def test_xarray_in_xarray_out(fake_xarray, oisst):
-    from xmhw_amd import threshold
+    from xmhw_amd.api import _threshold
     da = FakeDataArray(
         oisst["sst"], ("time", "lat", "lon"),
         {"time": (oisst["time64"], {"long_name": "Center time of the day"}),
          "lat": (oisst["lat"], {"units": "degrees_north"}),
          "lon": (oisst["lon"], {"units": "degrees_east"})},
         attrs={"units": "Celsius"}, encodings={"time": {"calendar": "proleptic_gregorian"}})
-    ds = threshold(da, smoothPercentile=False, _compute=oracle_compute)
+    ds = _threshold(da, oracle_compute, smoothPercentile=False)
     assert isinstance(ds, FakeDataset)
     ref = ora.threshold_grid(oisst["sst"], oisst["time64"], smoothPercentile=False)
     keep = ref["keep"].reshape(8, 4)

@@ -116,18 +116,27 @@ def threshold(
     tstep=False,
     anynans=False,
     skipna=False,
-    _compute=None,
 ):
     """Calculate threshold and mean climatology (day-of-year).
 
-    Same parameters, defaults, exceptions and return layout as
+    Same signature, defaults, exceptions and return layout as
     ``xmhw.xmhw.threshold`` (xmhw/xmhw.py:38-99).  Differences, all documented
     in DESIGN.md: results are float64 whatever the input dtype; ``skipna`` only
     changes the provenance text (it never changes the reference's numbers
     either, quirk Q1); ``maxPadLength`` is not supported (quirk Q10).
-    ``_compute`` is a test hook (N>1 host-logic tests inject a stand-in for the
-    device stage); the product path always runs the HIP kernels.
+    The device stage is always the HIP path (no CPU fallback).
     """
+    return _threshold(temp, calc_clim_device, tdim, climatologyPeriod, pctile, windowHalfWidth,
+                      smoothPercentile, smoothPercentileWidth, maxPadLength, coldSpells, tstep,
+                      anynans, skipna)
+
+
+def _threshold(temp, compute, tdim="time", climatologyPeriod=[None, None], pctile=90,
+               windowHalfWidth=5, smoothPercentile=True, smoothPercentileWidth=31, maxPadLength=None,
+               coldSpells=False, tstep=False, anynans=False, skipna=False):
+    """Host side of threshold() around a device stage ``compute`` with the signature of
+    ``device.calc_clim_device``.  The public threshold() passes the HIP path; the CPU tests of
+    the host logic and of the multi-rank sharding pass a stand-in here."""
     if smoothPercentileWidth % 2 == 0:                       # xmhw.py:103-104
         raise XmhwException("smoothPercentileWidth should be odd")
     is_xr = _is_xarray(temp)
@@ -165,7 +174,6 @@ def threshold(
         tstep = True
     doy = cal.add_doy(time, keep_tstep=tstep)                 # xmhw.py:145
 
-    compute = _compute or calc_clim_device
     doys, th, se = compute(ts, doy, pctile, windowHalfWidth, smoothPercentile,
                            smoothPercentileWidth, tstep, coldSpells)
 

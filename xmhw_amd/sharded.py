@@ -98,5 +98,5 @@ def threshold_sharded(temp, group=None, dst=0, device=None, _compute=None, **kwa
     the others None."""
     import torch.distributed as dist
 
-    ds = api.threshold(temp, _compute=make_sharded_compute(group, dst, device, _compute), **kwargs)
+    ds = api._threshold(temp, make_sharded_compute(group, dst, device, _compute), **kwargs)
     return ds if dist.get_rank(group) == dst else None
