@@ -174,6 +174,36 @@ int xmhw_detect_events_f64(const double *ts_dev, int64_t T, int64_t C, int64_t l
                            int32_t *events_dev, int32_t *start_dev, int32_t *end_dev,
                            uint8_t *bthresh_dev, int64_t ldo, void *stream);
 
+/* Number of (joined) events per cell: nevents_dev[C] int32, from the start array of
+ * xmhw_detect_events_* (one start per event).                                            */
+int xmhw_count_events(const int32_t *start_dev, int64_t T, int64_t C, int64_t ldo,
+                      int32_t *nevents_dev, void *stream);
+
+/* Per-event statistics: mhw_df() (xmhw/features.py:22-70) and
+ * mhw_features() (features.py:72-315) for every event of every cell, from the labels of
+ * xmhw_detect_events_*.  seas/thresh are the (D, C) climatologies (re-expanded by
+ * row_of_t_host as in define_events(), identify.py:366-368); offsets_dev[C+1] int64 is the
+ * exclusive prefix sum of the per-cell event counts; table_dev[offsets[C]][XMHW_EVENT_COLUMNS]
+ * float64 receives one row per event, cells in order, events of a cell in time order.
+ * Columns (time stamps as positions along the time axis):
+ *  0 event  1 index_start  2 index_end  3 time_start  4 time_end  5 time_peak
+ *  6 intensity_max  7 intensity_mean  8 intensity_cumulative  9 severity_max
+ * 10 severity_mean 11 severity_cumulative 12 severity_var 13 intensity_mean_relThresh
+ * 14 intensity_cumulative_relThresh 15 intensity_mean_abs 16 intensity_cumulative_abs
+ * 17 duration_moderate 18 duration_strong 19 duration_severe 20 duration_extreme
+ * 21 index_peak 22 intensity_var 23 intensity_max_relThresh 24 intensity_max_abs
+ * 25 intensity_var_relThresh 26 intensity_var_abs 27 category 28 duration
+ * 29 rate_onset 30 rate_decline                                                          */
+#define XMHW_EVENT_COLUMNS 31
+int xmhw_event_stats_f32(const float *ts_dev, int64_t T, int64_t C, int64_t ld,
+                         const double *seas_dev, const double *thresh_dev, int64_t ldc,
+                         const int32_t *row_of_t_host, int32_t negate, const int32_t *events_dev,
+                         int64_t ldo, const int64_t *offsets_dev, double *table_dev, void *stream);
+int xmhw_event_stats_f64(const double *ts_dev, int64_t T, int64_t C, int64_t ld,
+                         const double *seas_dev, const double *thresh_dev, int64_t ldc,
+                         const int32_t *row_of_t_host, int32_t negate, const int32_t *events_dev,
+                         int64_t ldo, const int64_t *offsets_dev, double *table_dev, void *stream);
+
 /* Synthetic SST generated in HBM (bench + large parity runs):
  * x[t,c] = 15 + A_c sin(2 pi (t - phi_c)/365.25) + 5e-4 t beta_c + N(0,1),
  * counter-based on (seed, cell0 + c, t); a sample is NaN with probability

@@ -216,11 +216,34 @@ int detect_events(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* 
                                   hipMemcpyHostToDevice, st);
     if (e == hipSuccess)
         e = xmhw::launch_detect<T>(ts, Tn, C, ld, thresh, ldt, d_rows, min_duration, join_gaps, max_gap, negate,
-                                   events, start, end, bthresh, ldo, st);
+                                   events, start, end, bthresh, ldo, nullptr, st);
     // the row table must outlive the kernel: synchronise before releasing it
     hipError_t e2 = hipStreamSynchronize(st);
     (void)hipFree(d_rows);
     if (e != hipSuccess) return hip_fail(e, "detect_events launch");
+    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
+    return XMHW_OK;
+}
+
+template <typename T>
+int event_stats(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* seas, const double* thresh,
+                int64_t ldc, const int32_t* row_of_t, int32_t negate, const int32_t* events, int64_t ldo,
+                const int64_t* offsets, double* table, void* stream) {
+    if (Tn <= 0 || C < 0 || ld < C || ldc < C || ldo < C) return fail(XMHW_ERR_INVALID, "bad T/C/ld/ldc/ldo");
+    if (C == 0) return XMHW_OK;
+    if (!ts || !seas || !thresh || !row_of_t || !events || !offsets)
+        return fail(XMHW_ERR_INVALID, "NULL buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int32_t* d_rows = nullptr;
+    HIP_TRY(hipMalloc(&d_rows, sizeof(int32_t) * static_cast<size_t>(Tn)));
+    hipError_t e = hipMemcpyAsync(d_rows, row_of_t, sizeof(int32_t) * static_cast<size_t>(Tn),
+                                  hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = xmhw::launch_event_stats<T>(ts, Tn, C, ld, seas, thresh, ldc, d_rows, negate, events, ldo, offsets,
+                                        table, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_rows);
+    if (e != hipSuccess) return hip_fail(e, "event_stats launch");
     if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
     return XMHW_OK;
 }
@@ -534,6 +557,25 @@ int xmhw_detect_events_f64(const double* ts, int64_t T, int64_t C, int64_t ld, c
                            int64_t ldo, void* stream) {
     return detect_events<double>(ts, T, C, ld, thresh, ldt, row_of_t, min_duration, join_gaps, max_gap, negate,
                                  events, start, end, bthresh, ldo, stream);
+}
+
+int xmhw_count_events(const int32_t* start, int64_t T, int64_t C, int64_t ldo, int32_t* nevents, void* stream) {
+    if (T <= 0 || C < 0 || ldo < C) return fail(XMHW_ERR_INVALID, "bad T/C/ldo");
+    if (C == 0) return XMHW_OK;
+    if (!start || !nevents) return fail(XMHW_ERR_INVALID, "NULL buffer");
+    hipError_t e = xmhw::launch_count_events(start, T, C, ldo, nevents, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "count_events launch");
+    return XMHW_OK;
+}
+int xmhw_event_stats_f32(const float* ts, int64_t T, int64_t C, int64_t ld, const double* seas,
+                         const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,
+                         const int32_t* events, int64_t ldo, const int64_t* offsets, double* table, void* stream) {
+    return event_stats<float>(ts, T, C, ld, seas, thresh, ldc, row_of_t, negate, events, ldo, offsets, table, stream);
+}
+int xmhw_event_stats_f64(const double* ts, int64_t T, int64_t C, int64_t ld, const double* seas,
+                         const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,
+                         const int32_t* events, int64_t ldo, const int64_t* offsets, double* table, void* stream) {
+    return event_stats<double>(ts, T, C, ld, seas, thresh, ldc, row_of_t, negate, events, ldo, offsets, table, stream);
 }
 
 int xmhw_synth_sst_f32(float* ts, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,

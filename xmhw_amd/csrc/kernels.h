@@ -51,7 +51,18 @@ template <typename T>
 hipError_t launch_detect(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* thresh, int64_t ldt,
                          const int32_t* row_of_t, int32_t min_duration, int32_t join_gaps, int32_t max_gap,
                          int32_t negate, int32_t* events, int32_t* start, int32_t* end, uint8_t* bthresh,
-                         int64_t ldo, hipStream_t stream);
+                         int64_t ldo, int32_t* nevents, hipStream_t stream);
+
+hipError_t launch_count_events(const int32_t* start, int64_t Tn, int64_t C, int64_t ldo, int32_t* nevents,
+                               hipStream_t stream);
+
+// per-event statistics into a compact table (kEventColumns doubles per event)
+constexpr int kEventColumns = 31;
+template <typename T>
+hipError_t launch_event_stats(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* seas,
+                              const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,
+                              const int32_t* events, int64_t ldo, const int64_t* offsets, double* table,
+                              hipStream_t stream);
 
 template <typename T>
 hipError_t launch_synth(T* ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,

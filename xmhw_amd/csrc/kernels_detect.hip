@@ -20,9 +20,10 @@ __global__ __launch_bounds__(256) void detect_events(
     const T* __restrict__ ts, int64_t Tn, int64_t C, int64_t ld, const double* __restrict__ thresh,
     int64_t ldt, const int32_t* __restrict__ row_of_t, int32_t min_duration, int32_t join_gaps,
     int32_t max_gap, int32_t negate, int32_t* __restrict__ events, int32_t* __restrict__ start,
-    int32_t* __restrict__ end, uint8_t* __restrict__ bthresh, int64_t ldo) {
+    int32_t* __restrict__ end, uint8_t* __restrict__ bthresh, int64_t ldo, int32_t* __restrict__ nevents) {
     const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    int32_t count = 0;  // events after joining (= groups)
     int64_t prev_nonexc = -1;  // last step that was not an exceedance (-1: none yet)
     bool in_run = false;
     int64_t p = 0, run_first = 0;
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(256) void detect_events(
                     } else {
                         group_start = S;
                         start[te * ldo + c] = S;
+                        ++count;
                     }
                     end[te * ldo + c] = static_cast<int32_t>(te);
                     prev_end = te;
@@ -82,24 +84,217 @@ __global__ __launch_bounds__(256) void detect_events(
             if (!b) prev_nonexc = t;
         }
     }
+    if (nevents) nevents[c] = count;
+}
+
+// ---------------------------------------------------------------------------
+// event_stats: per-event statistics: mhw_df() (xmhw/features.py:22-70) and
+// mhw_features() (features.py:72-315: agg_df, properties, onset_decline) for every event of every
+// cell, from the labels produced by detect_events.  One thread per cell streams over time; the
+// steps of an event are contiguous (gap steps of joined events carry the label), so the groupby
+// aggregations become running accumulators that are flushed into the cell's slice of a compact
+// event table (offsets = exclusive prefix sum of the per-cell event counts).  NaN samples are
+// skipped as pandas does; variances are Welford updates (ddof = 1), returned as standard deviations.
+// Columns: see kEventColumns in kernels.h (same order as oracle/features_oracle.py COLUMNS).
+// ---------------------------------------------------------------------------
+struct Welford {
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    __device__ __forceinline__ void add(double x) {
+        n += 1.0;
+        const double d = x - mean;
+        mean += d / n;
+        m2 += d * (x - mean);
+    }
+    __device__ __forceinline__ double sd() const { return n >= 2.0 ? sqrt(m2 / (n - 1.0)) : make_nan(); }
+};
+
+struct EventAcc {
+    int32_t label;
+    int64_t first, last;          // first / last labelled step
+    double s_relS, s_sev, s_relT, s_abs;
+    double max_relS, max_sev, max_cat, relT_at_max, abs_at_max;
+    int64_t imax;                 // position (within the group) of the first maximum of relSeas
+    double n_mod, n_str, n_sev, n_ext;
+    double relS_first, relS_last, anom_first, anom_last;
+    bool have_first, have_afirst;
+    Welford w_relS, w_sev, w_relT, w_abs;
+    __device__ void reset(int32_t L, int64_t t) {
+        label = L; first = t; last = t;
+        s_relS = s_sev = s_relT = s_abs = 0.0;
+        max_relS = max_sev = max_cat = relT_at_max = abs_at_max = make_nan();
+        imax = -1;
+        n_mod = n_str = n_sev = n_ext = 0.0;
+        relS_first = relS_last = anom_first = anom_last = make_nan();
+        have_first = have_afirst = false;
+        w_relS = Welford(); w_sev = Welford(); w_relT = Welford(); w_abs = Welford();
+    }
+};
+
+__device__ void flush_event(const EventAcc& a, int64_t last_index, double* __restrict__ row) {
+    const double nan = make_nan();
+    const double L = static_cast<double>(a.label);
+    const double i_start = L, i_end = static_cast<double>(a.last);
+    const double i_peak = L + static_cast<double>(a.imax);
+    row[0] = L;
+    row[1] = i_start;
+    row[2] = i_end;
+    row[3] = static_cast<double>(a.first);
+    row[4] = static_cast<double>(a.last);
+    row[5] = a.imax >= 0 ? static_cast<double>(a.first + a.imax) : nan;
+    row[6] = a.max_relS;
+    row[7] = a.w_relS.n > 0 ? a.s_relS / a.w_relS.n : nan;
+    row[8] = a.s_relS;
+    row[9] = a.max_sev;
+    row[10] = a.w_sev.n > 0 ? a.s_sev / a.w_sev.n : nan;
+    row[11] = a.s_sev;
+    row[12] = a.w_sev.sd();
+    row[13] = a.w_relT.n > 0 ? a.s_relT / a.w_relT.n : nan;
+    row[14] = a.s_relT;
+    row[15] = a.w_abs.n > 0 ? a.s_abs / a.w_abs.n : nan;
+    row[16] = a.s_abs;
+    row[17] = a.n_mod;
+    row[18] = a.n_str;
+    row[19] = a.n_sev;
+    row[20] = a.n_ext;
+    row[21] = i_peak;
+    row[22] = a.w_relS.sd();
+    row[23] = a.relT_at_max;
+    row[24] = a.abs_at_max;
+    row[25] = a.w_relT.sd();
+    row[26] = a.w_abs.sd();
+    row[27] = a.max_cat == a.max_cat ? fmin(a.max_cat, 4.0) : nan;
+    row[28] = i_end - i_start + 1.0;
+    // onset / decline (features.py:224-295)
+    const double peak = i_peak - i_start;
+    const double esp = i_end - i_start - peak;
+    const double x = peak != 0.0 ? peak : 1.0;
+    const double onset_period = i_start == 0.0 ? x : x + 0.5;
+    const double y = peak != static_cast<double>(last_index) ? esp : 1.0;
+    const double decline_period = i_end == static_cast<double>(last_index) ? y : y + 0.5;
+    const double edge0 = 0.5 * (a.relS_first + (i_start == 0.0 ? a.relS_first : a.anom_first));
+    const double edge1 = 0.5 * (a.relS_last + (i_end == static_cast<double>(last_index) ? a.relS_last : a.anom_last));
+    row[29] = (a.max_relS - edge0) / onset_period;
+    row[30] = (a.max_relS - edge1) / decline_period;
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void event_stats(
+    const T* __restrict__ ts, int64_t Tn, int64_t C, int64_t ld, const double* __restrict__ seas,
+    const double* __restrict__ thresh, int64_t ldc, const int32_t* __restrict__ row_of_t, int32_t negate,
+    const int32_t* __restrict__ events, int64_t ldo, const int64_t* __restrict__ offsets,
+    double* __restrict__ table) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double* out = table + offsets[c] * kEventColumns;
+    const int64_t nmax = offsets[c + 1] - offsets[c];
+    int64_t nout = 0;
+    EventAcc a;
+    a.reset(-1, 0);
+    bool in_event = false, prev_in_event = false;
+    double anom_prev = make_nan();
+    for (int64_t t = 0; t < Tn; ++t) {
+        double x = static_cast<double>(ts[t * ld + c]);
+        if (negate) x = -x;
+        const int64_t r = row_of_t[t];
+        const double se = seas[r * ldc + c], th = thresh[r * ldc + c];
+        const int32_t ev = events[t * ldo + c];
+        const double anom = x - se;
+        // anom_minus of the previous step (= this step's anomaly) closes the previous step's view
+        if (prev_in_event && anom == anom) a.anom_last = anom;
+        if (in_event && ev != a.label) {
+            if (nout < nmax) flush_event(a, Tn - 1, out + nout * kEventColumns);
+            ++nout;
+            in_event = false;
+        }
+        if (ev >= 0) {
+            if (!in_event) { a.reset(ev, t); in_event = true; }
+            a.last = t;
+            if (!a.have_afirst && anom_prev == anom_prev) { a.anom_first = anom_prev; a.have_afirst = true; }
+            // every series skips its own NaNs, as pandas' groupby aggregations do
+            const double relS = x - se, relT = x - th, ths = th - se;
+            const double sev = relS / -(ths);
+            const double cat = floor(1.0 + relT / ths);
+            if (x == x) { a.s_abs += x; a.w_abs.add(x); }
+            if (relT == relT) { a.s_relT += relT; a.w_relT.add(relT); }
+            if (relS == relS) {
+                a.s_relS += relS; a.w_relS.add(relS);
+                if (!(a.max_relS >= relS)) {       // first maximum (NaN-initialised)
+                    a.max_relS = relS; a.imax = t - a.first; a.relT_at_max = relT; a.abs_at_max = x;
+                }
+                if (!a.have_first) { a.relS_first = relS; a.have_first = true; }
+                a.relS_last = relS;
+            }
+            if (sev == sev) {
+                a.s_sev += sev; a.w_sev.add(sev);
+                if (!(a.max_sev >= sev)) a.max_sev = sev;
+            }
+            if (cat == cat) {
+                if (!(a.max_cat >= cat)) a.max_cat = cat;
+                a.n_mod += cat == 1.0 ? 1.0 : 0.0;
+                a.n_str += cat == 2.0 ? 1.0 : 0.0;
+                a.n_sev += cat == 3.0 ? 1.0 : 0.0;
+                a.n_ext += cat >= 4.0 ? 1.0 : 0.0;
+            }
+        }
+        prev_in_event = in_event;
+        anom_prev = anom;
+    }
+    if (in_event) {
+        if (nout < nmax) flush_event(a, Tn - 1, out + nout * kEventColumns);
+        ++nout;
+    }
 }
 
 template <typename T>
 hipError_t launch_detect(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* thresh, int64_t ldt,
                          const int32_t* row_of_t, int32_t min_duration, int32_t join_gaps, int32_t max_gap,
                          int32_t negate, int32_t* events, int32_t* start, int32_t* end, uint8_t* bthresh,
-                         int64_t ldo, hipStream_t stream) {
+                         int64_t ldo, int32_t* nevents, hipStream_t stream) {
     if (C <= 0 || Tn <= 0) return hipSuccess;
     hipLaunchKernelGGL(detect_events<T>, dim3(static_cast<unsigned>((C + 255) / 256)), dim3(256), 0, stream, ts,
                        Tn, C, ld, thresh, ldt, row_of_t, min_duration, join_gaps, max_gap, negate, events,
-                       start, end, bthresh, ldo);
+                       start, end, bthresh, ldo, nevents);
     return hipGetLastError();
 }
+
+__global__ __launch_bounds__(256) void count_events(const int32_t* __restrict__ start, int64_t Tn, int64_t C,
+                                                    int64_t ldo, int32_t* __restrict__ nevents) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    int32_t n = 0;
+    for (int64_t t = 0; t < Tn; ++t) n += start[t * ldo + c] >= 0 ? 1 : 0;
+    nevents[c] = n;
+}
+
+hipError_t launch_count_events(const int32_t* start, int64_t Tn, int64_t C, int64_t ldo, int32_t* nevents,
+                               hipStream_t stream) {
+    if (C <= 0) return hipSuccess;
+    hipLaunchKernelGGL(count_events, dim3(static_cast<unsigned>((C + 255) / 256)), dim3(256), 0, stream, start, Tn,
+                       C, ldo, nevents);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_event_stats(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* seas,
+                              const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,
+                              const int32_t* events, int64_t ldo, const int64_t* offsets, double* table,
+                              hipStream_t stream) {
+    if (C <= 0 || Tn <= 0) return hipSuccess;
+    hipLaunchKernelGGL(event_stats<T>, dim3(static_cast<unsigned>((C + 127) / 128)), dim3(128), 0, stream, ts, Tn,
+                       C, ld, seas, thresh, ldc, row_of_t, negate, events, ldo, offsets, table);
+    return hipGetLastError();
+}
+template hipError_t launch_event_stats<float>(const float*, int64_t, int64_t, int64_t, const double*, const double*,
+                                              int64_t, const int32_t*, int32_t, const int32_t*, int64_t,
+                                              const int64_t*, double*, hipStream_t);
+template hipError_t launch_event_stats<double>(const double*, int64_t, int64_t, int64_t, const double*,
+                                               const double*, int64_t, const int32_t*, int32_t, const int32_t*,
+                                               int64_t, const int64_t*, double*, hipStream_t);
 template hipError_t launch_detect<float>(const float*, int64_t, int64_t, int64_t, const double*, int64_t,
                                          const int32_t*, int32_t, int32_t, int32_t, int32_t, int32_t*, int32_t*,
-                                         int32_t*, uint8_t*, int64_t, hipStream_t);
+                                         int32_t*, uint8_t*, int64_t, int32_t*, hipStream_t);
 template hipError_t launch_detect<double>(const double*, int64_t, int64_t, int64_t, const double*, int64_t,
                                           const int32_t*, int32_t, int32_t, int32_t, int32_t, int32_t*, int32_t*,
-                                          int32_t*, uint8_t*, int64_t, hipStream_t);
+                                          int32_t*, uint8_t*, int64_t, int32_t*, hipStream_t);
 
 }  // namespace xmhw

@@ -228,6 +228,32 @@ PYBIND11_MODULE(_xmhw_hip, m) {
        py::arg("row_of_t"), py::arg("min_duration"), py::arg("join_gaps"), py::arg("max_gap"), py::arg("negate"),
        py::arg("events"), py::arg("start"), py::arg("end"), py::arg("bthresh") = 0, py::arg("ldo"), py::arg("stream") = 0);
 
+    m.def("count_events", [](uintptr_t start, int64_t T, int64_t C, int64_t ldo, uintptr_t nevents, uintptr_t stream) {
+        check(xmhw_count_events(static_cast<const int32_t*>(vp(start)), T, C, ldo, static_cast<int32_t*>(vp(nevents)), vp(stream)));
+    }, py::arg("start"), py::arg("T"), py::arg("C"), py::arg("ldo"), py::arg("nevents"), py::arg("stream") = 0);
+    m.attr("EVENT_COLUMNS") = XMHW_EVENT_COLUMNS;
+    m.def("event_stats", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, uintptr_t seas, uintptr_t thresh,
+                            int64_t ldc, i32arr row_of_t, int negate, uintptr_t events, int64_t ldo, uintptr_t offsets,
+                            uintptr_t table, uintptr_t stream) {
+        if (row_of_t.size() != T) throw InvalidError("row_of_t length must equal T");
+        py::gil_scoped_release r;
+        int rc = -1;
+        if (itemsize == 4)
+            rc = xmhw_event_stats_f32(static_cast<const float*>(vp(ts)), T, C, ld, static_cast<const double*>(vp(seas)),
+                                      static_cast<const double*>(vp(thresh)), ldc, row_of_t.data(), negate,
+                                      static_cast<const int32_t*>(vp(events)), ldo, static_cast<const int64_t*>(vp(offsets)),
+                                      static_cast<double*>(vp(table)), vp(stream));
+        else if (itemsize == 8)
+            rc = xmhw_event_stats_f64(static_cast<const double*>(vp(ts)), T, C, ld, static_cast<const double*>(vp(seas)),
+                                      static_cast<const double*>(vp(thresh)), ldc, row_of_t.data(), negate,
+                                      static_cast<const int32_t*>(vp(events)), ldo, static_cast<const int64_t*>(vp(offsets)),
+                                      static_cast<double*>(vp(table)), vp(stream));
+        if (rc == -1) throw InvalidError("itemsize must be 4 or 8");
+        check(rc);
+    }, py::arg("ts"), py::arg("itemsize"), py::arg("T"), py::arg("C"), py::arg("ld"), py::arg("seas"), py::arg("thresh"),
+       py::arg("ldc"), py::arg("row_of_t"), py::arg("negate"), py::arg("events"), py::arg("ldo"), py::arg("offsets"),
+       py::arg("table"), py::arg("stream") = 0);
+
     m.def("synth_sst", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
                           double nan_frac, uintptr_t stream) {
         if (itemsize == 4)
