@@ -162,17 +162,18 @@ int xmhw_scatter_cells_f64(const double *in_dev, int64_t rows, int64_t ld_in,
  * Outputs are int32 [T][ldo] with -1 where the reference has NaN: events = label (start
  * position) of the event covering a step; start = start label stored at the END step of the
  * first member of a joined event; end = end step stored at the end step of its last member.
- * bthresh_dev may be NULL.                                                              */
+ * bthresh_dev (uint8 [T][ldo]) and nevents_dev (int32 [C], number of joined events per
+ * cell) may be NULL.                                                                    */
 int xmhw_detect_events_f32(const float *ts_dev, int64_t T, int64_t C, int64_t ld,
                            const double *thresh_dev, int64_t ldt, const int32_t *row_of_t_host,
                            int32_t min_duration, int32_t join_gaps, int32_t max_gap, int32_t negate,
                            int32_t *events_dev, int32_t *start_dev, int32_t *end_dev,
-                           uint8_t *bthresh_dev, int64_t ldo, void *stream);
+                           uint8_t *bthresh_dev, int64_t ldo, int32_t *nevents_dev, void *stream);
 int xmhw_detect_events_f64(const double *ts_dev, int64_t T, int64_t C, int64_t ld,
                            const double *thresh_dev, int64_t ldt, const int32_t *row_of_t_host,
                            int32_t min_duration, int32_t join_gaps, int32_t max_gap, int32_t negate,
                            int32_t *events_dev, int32_t *start_dev, int32_t *end_dev,
-                           uint8_t *bthresh_dev, int64_t ldo, void *stream);
+                           uint8_t *bthresh_dev, int64_t ldo, int32_t *nevents_dev, void *stream);
 
 /* Number of (joined) events per cell: nevents_dev[C] int32, from the start array of
  * xmhw_detect_events_* (one start per event).                                            */

@@ -27,15 +27,36 @@ clim_raw(plan, ts, 4, C, 0.9, False, raw_t, raw_s)
 clim_finish(plan, raw_t, raw_s, C, True, True, 31, th, se)
 ev, st, en = (DeviceBuffer(4 * T * C) for _ in range(3))
 b = DeviceBuffer(T * C)
+nev = DeviceBuffer(4 * C)
 h.stream_sync(0)
 e0, e1 = h.event_create(), h.event_create()
 ms = []
 for i in range(steps + 1):
     h.event_record(e0, 0)
-    h.detect_events(ts.ptr, 4, T, C, C, th.ptr, C, rows, 5, 1, 2, 0, ev.ptr, st.ptr, en.ptr, b.ptr, C)
+    h.detect_events(ts.ptr, 4, T, C, C, th.ptr, C, rows, 5, 1, 2, 0, ev.ptr, st.ptr, en.ptr, b.ptr, C, nev.ptr)
     h.event_record(e1, 0)
     if i: ms.append(h.event_elapsed_ms(e0, e1))
 ms = float(np.mean(ms))
+# ---- event statistics: per-cell counts (from detect) -> prefix offsets -> stats table ----
+h.stream_sync(0)
+counts = nev.to_array((C,), np.int32)
+offsets = np.zeros(C + 1, np.int64); np.cumsum(counts, out=offsets[1:])
+ntot = int(offsets[-1])
+d_off = DeviceBuffer.from_array(offsets)
+table = DeviceBuffer(8 * max(ntot, 1) * h.EVENT_COLUMNS)
+ms_stats, ms_count = [], []
+for i in range(steps + 1):
+    h.event_record(e0, 0)
+    h.count_events(st.ptr, T, C, C, nev.ptr)
+    h.event_record(e1, 0)
+    t_c = h.event_elapsed_ms(e0, e1)
+    h.event_record(e0, 0)
+    h.event_stats(ts.ptr, 4, T, C, C, se.ptr, th.ptr, C, rows, 0, ev.ptr, C, d_off.ptr, table.ptr)
+    h.event_record(e1, 0)
+    if i:
+        ms_count.append(t_c); ms_stats.append(h.event_elapsed_ms(e0, e1))
+ms_stats, ms_count = float(np.mean(ms_stats)), float(np.mean(ms_count))
+stats_bytes_cell = T * (4 + 4) + 2 * D * 8           # ts + labels read once, seas/thresh rows once
 bytes_cell = T * (4 + 13) + D * 8
 # parity + CPU baseline on a sample
 import detect_oracle as det
@@ -55,6 +76,11 @@ res = {"stage": "detect front end (exceedance + mhw_filter + join_gaps)", "cells
        "ms_per_launch": ms, "cells_per_s": C / (ms * 1e-3),
        "roofline": {"bound": "hbm", "achieved": C * bytes_cell / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                     "frac": C * bytes_cell / (ms * 1e-3) / 8e12, "algorithmic_bytes_per_cell": bytes_cell}}
+res["event_stats"] = {"events": ntot, "events_per_cell": ntot / C, "ms_per_launch": ms_stats,
+                      "count_events_ms": ms_count, "cells_per_s": C / (ms_stats * 1e-3),
+                      "roofline": {"bound": "hbm", "achieved": C * stats_bytes_cell / (ms_stats * 1e-3) / 1e9,
+                                   "peak": 8000.0, "unit": "GB/s", "frac": C * stats_bytes_cell / (ms_stats * 1e-3) / 8e12,
+                                   "algorithmic_bytes_per_cell": stats_bytes_cell}}
 if x is not None:
     thh = sample(th, 8, D, np.float64)
     evh = sample(ev, 4, T, np.float32).view(np.int32)
@@ -66,6 +92,18 @@ if x is not None:
         ok &= bool(np.array_equal(v_, evh[:, c]))
     dt = time.perf_counter() - t0
     res["parity_events_bit_exact"] = ok
+    import features_oracle as fo
+    tab = table.to_array((ntot, h.EVENT_COLUMNS), np.float64)
+    seh = sample(se, 8, D, np.float64)
+    worst = 0.0
+    for c in range(8):
+        _, s_, e_, v_ = det.detect_front(x[:, c], thh[:, c], rows, 5, True, 2)
+        want = fo.event_table(x[:, c].astype(np.float64), seh[rows, c], thh[rows, c], s_, e_, v_)
+        got = tab[offsets[c]:offsets[c + 1]]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            d = np.abs(got - want) / np.maximum(np.abs(want), 1e-12)
+        worst = max(worst, float(np.nanmax(d))) if want.size else worst
+    res["event_stats"]["max_rel_err_vs_oracle_8_cells"] = worst
     res["cpu_baseline"] = {"value": n / dt, "unit": "cells/s", "cores": 1, "kind": "port",
                            "sample": f"{n} cells, loop oracle (oracle/detect_oracle.py), one core"}
 print(json.dumps(res))

@@ -203,7 +203,7 @@ template <typename T>
 int detect_events(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* thresh, int64_t ldt,
                   const int32_t* row_of_t, int32_t min_duration, int32_t join_gaps, int32_t max_gap,
                   int32_t negate, int32_t* events, int32_t* start, int32_t* end, uint8_t* bthresh,
-                  int64_t ldo, void* stream) {
+                  int64_t ldo, int32_t* nevents, void* stream) {
     if (Tn <= 0 || C < 0 || ld < C || ldt < C || ldo < C) return fail(XMHW_ERR_INVALID, "bad T/C/ld/ldt/ldo");
     if (min_duration < 1 || max_gap < 0) return fail(XMHW_ERR_INVALID, "minDuration must be >= 1 and maxGap >= 0");
     if (C == 0) return XMHW_OK;
@@ -216,7 +216,7 @@ int detect_events(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* 
                                   hipMemcpyHostToDevice, st);
     if (e == hipSuccess)
         e = xmhw::launch_detect<T>(ts, Tn, C, ld, thresh, ldt, d_rows, min_duration, join_gaps, max_gap, negate,
-                                   events, start, end, bthresh, ldo, nullptr, st);
+                                   events, start, end, bthresh, ldo, nevents, st);
     // the row table must outlive the kernel: synchronise before releasing it
     hipError_t e2 = hipStreamSynchronize(st);
     (void)hipFree(d_rows);
@@ -547,16 +547,16 @@ int xmhw_scatter_cells_f64(const double* in, int64_t rows, int64_t ld_in, const 
 int xmhw_detect_events_f32(const float* ts, int64_t T, int64_t C, int64_t ld, const double* thresh, int64_t ldt,
                            const int32_t* row_of_t, int32_t min_duration, int32_t join_gaps, int32_t max_gap,
                            int32_t negate, int32_t* events, int32_t* start, int32_t* end, uint8_t* bthresh,
-                           int64_t ldo, void* stream) {
+                           int64_t ldo, int32_t* nevents, void* stream) {
     return detect_events<float>(ts, T, C, ld, thresh, ldt, row_of_t, min_duration, join_gaps, max_gap, negate,
-                                events, start, end, bthresh, ldo, stream);
+                                events, start, end, bthresh, ldo, nevents, stream);
 }
 int xmhw_detect_events_f64(const double* ts, int64_t T, int64_t C, int64_t ld, const double* thresh, int64_t ldt,
                            const int32_t* row_of_t, int32_t min_duration, int32_t join_gaps, int32_t max_gap,
                            int32_t negate, int32_t* events, int32_t* start, int32_t* end, uint8_t* bthresh,
-                           int64_t ldo, void* stream) {
+                           int64_t ldo, int32_t* nevents, void* stream) {
     return detect_events<double>(ts, T, C, ld, thresh, ldt, row_of_t, min_duration, join_gaps, max_gap, negate,
-                                 events, start, end, bthresh, ldo, stream);
+                                 events, start, end, bthresh, ldo, nevents, stream);
 }
 
 int xmhw_count_events(const int32_t* start, int64_t T, int64_t C, int64_t ldo, int32_t* nevents, void* stream) {

@@ -206,7 +206,7 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     m.def("detect_events", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, uintptr_t thresh, int64_t ldt,
                               i32arr row_of_t, int min_duration, int join_gaps, int max_gap, int negate,
                               uintptr_t events, uintptr_t start, uintptr_t end, uintptr_t bthresh, int64_t ldo,
-                              uintptr_t stream) {
+                              uintptr_t nevents, uintptr_t stream) {
         if (row_of_t.size() != T) throw InvalidError("row_of_t length must equal T");
         py::gil_scoped_release r;
         int rc;
@@ -214,19 +214,20 @@ PYBIND11_MODULE(_xmhw_hip, m) {
             rc = xmhw_detect_events_f32(static_cast<const float*>(vp(ts)), T, C, ld, static_cast<const double*>(vp(thresh)), ldt,
                                         row_of_t.data(), min_duration, join_gaps, max_gap, negate,
                                         static_cast<int32_t*>(vp(events)), static_cast<int32_t*>(vp(start)),
-                                        static_cast<int32_t*>(vp(end)), static_cast<uint8_t*>(vp(bthresh)), ldo, vp(stream));
+                                        static_cast<int32_t*>(vp(end)), static_cast<uint8_t*>(vp(bthresh)), ldo, static_cast<int32_t*>(vp(nevents)), vp(stream));
         else if (itemsize == 8)
             rc = xmhw_detect_events_f64(static_cast<const double*>(vp(ts)), T, C, ld, static_cast<const double*>(vp(thresh)), ldt,
                                         row_of_t.data(), min_duration, join_gaps, max_gap, negate,
                                         static_cast<int32_t*>(vp(events)), static_cast<int32_t*>(vp(start)),
-                                        static_cast<int32_t*>(vp(end)), static_cast<uint8_t*>(vp(bthresh)), ldo, vp(stream));
+                                        static_cast<int32_t*>(vp(end)), static_cast<uint8_t*>(vp(bthresh)), ldo, static_cast<int32_t*>(vp(nevents)), vp(stream));
         else
             rc = -1;
         if (rc == -1) throw InvalidError("itemsize must be 4 or 8");
         check(rc);
     }, py::arg("ts"), py::arg("itemsize"), py::arg("T"), py::arg("C"), py::arg("ld"), py::arg("thresh"), py::arg("ldt"),
        py::arg("row_of_t"), py::arg("min_duration"), py::arg("join_gaps"), py::arg("max_gap"), py::arg("negate"),
-       py::arg("events"), py::arg("start"), py::arg("end"), py::arg("bthresh") = 0, py::arg("ldo"), py::arg("stream") = 0);
+       py::arg("events"), py::arg("start"), py::arg("end"), py::arg("bthresh") = 0, py::arg("ldo"), py::arg("nevents") = 0,
+       py::arg("stream") = 0);
 
     m.def("count_events", [](uintptr_t start, int64_t T, int64_t C, int64_t ldo, uintptr_t nevents, uintptr_t stream) {
         check(xmhw_count_events(static_cast<const int32_t*>(vp(start)), T, C, ldo, static_cast<int32_t*>(vp(nevents)), vp(stream)));

@@ -118,10 +118,9 @@ def mhw_features_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True
         neg = int(bool(coldSpells))
         try:
             h.detect_events(d_ts.ptr, isz, T, C, C, d_th.ptr, C, rows, int(minDuration), int(bool(joinGaps)),
-                            int(maxGap), neg, d_ev.ptr, d_st.ptr, d_en.ptr, 0, C)
+                            int(maxGap), neg, d_ev.ptr, d_st.ptr, d_en.ptr, 0, C, d_n.ptr)
         except h.InvalidArgument as e:
             raise XmhwException(str(e)) from e
-        h.count_events(d_st.ptr, T, C, C, d_n.ptr)
         h.stream_sync(0)
         counts = d_n.to_array((C,), np.int32)
         offsets = np.zeros(C + 1, dtype=np.int64)
