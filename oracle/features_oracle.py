@@ -57,6 +57,29 @@ def _var(v):
     return ((x - m) ** 2).sum() / (x.size - 1)
 
 
+def get_rate(relSeas_peak, relSeas_edge, period):
+    """features.py:199-201"""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (relSeas_peak - relSeas_edge) / np.float64(period)
+
+
+def get_edge(relS_edge, anom_edge, idx, edge):
+    """features.py:204-221: the event's own edge value if it touches the series boundary `edge`,
+    else the mean of it and the anomaly one step outside the event."""
+    return relS_edge if idx == edge else 0.5 * (relS_edge + anom_edge)
+
+
+def get_period(start, end, peak, tsend):
+    """features.py:224-263.  `peak` is index_peak - index_start; note that it (not the absolute
+    peak index) is what the reference compares with tsend."""
+    esp = end - start - peak
+    x = peak if peak != 0 else 1
+    onset_period = x if start == 0 else x + 0.5
+    y = esp if peak != tsend else 1
+    decline_period = y if end == tsend else y + 0.5
+    return onset_period, decline_period
+
+
 def event_table(ts, seas, thresh, start, end, events):
     """Per-event statistics of one cell.  ts/seas/thresh: (T,) with seas/thresh already
     re-expanded along time; start/end/events: mhw_filter() output.  Returns (n_events, 31)."""
@@ -111,18 +134,11 @@ def event_table(ts, seas, thresh, start, end, events):
         r["category"] = np.minimum(_max(c), 4)
         r["duration"] = r["index_end"] - r["index_start"] + 1
         # onset / decline rates (features.py:224-295)
-        peak = r["index_peak"] - r["index_start"]
-        esp = r["index_end"] - r["index_start"] - peak
-        x = peak if peak != 0 else 1
-        onset_period = x if r["index_start"] == 0 else x + 0.5
-        y = esp if peak != last else 1
-        decline_period = y if r["index_end"] == last else y + 0.5
-        relS_first, relS_last = _first(rs), _last(rs)
-        a_first, a_last = _first(anom_plus[idx]), _last(anom_minus[idx])
-        edge0 = 0.5 * (relS_first + (relS_first if r["index_start"] == 0 else a_first))
-        edge1 = 0.5 * (relS_last + (relS_last if r["index_end"] == last else a_last))
-        with np.errstate(divide="ignore", invalid="ignore"):
-            r["rate_onset"] = (r["intensity_max"] - edge0) / onset_period
-            r["rate_decline"] = (r["intensity_max"] - edge1) / np.float64(decline_period)
+        onset_period, decline_period = get_period(r["index_start"], r["index_end"],
+                                                  r["index_peak"] - r["index_start"], last)
+        edge0 = get_edge(_first(rs), _first(anom_plus[idx]), r["index_start"], 0)
+        edge1 = get_edge(_last(rs), _last(anom_minus[idx]), r["index_end"], last)
+        r["rate_onset"] = get_rate(r["intensity_max"], edge0, onset_period)
+        r["rate_decline"] = get_rate(r["intensity_max"], edge1, decline_period)
         rows.append([r[k] for k in COLUMNS])
     return np.array(rows, dtype=np.float64).reshape(-1, len(COLUMNS))
