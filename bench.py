@@ -80,9 +80,16 @@ def main():
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="input dtype (output is always f64)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--force-dist", action="store_true", help="init RCCL and run the gather even with one rank")
     ap.add_argument("--cpu-cells", type=int, default=512)
     ap.add_argument("--parity-cells", type=int, default=512)
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: keep a private handle to it and point fd 1 at stderr, so
+    # that banners printed by native libraries (RCCL prints its version to stdout) cannot add lines
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -96,9 +103,12 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist   # --force-dist: exercise the RCCL path with one rank
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from xmhw_amd._lib import hip
     from xmhw_amd.device import Plan, clim_raw, clim_finish
@@ -130,7 +140,7 @@ def main():
     q = pctile / 100.0
     plan = Plan(doy, w, kernel=args.kernel, nchunks=args.chunks)
     D = plan.D
-    nslab = args.slabs or (1 if world == 1 else 8)
+    nslab = args.slabs or (8 if use_dist else 1)
     bounds = [C * i // nslab for i in range(nslab + 1)]
     slabs = [(bounds[i], bounds[i + 1]) for i in range(nslab) if bounds[i + 1] > bounds[i]]
 
@@ -144,7 +154,7 @@ def main():
     raw_se = [torch.empty((D, b - a), dtype=torch.float64, device=dev) for a, b in slabs]
     out = [torch.empty((2, D, b - a), dtype=torch.float64, device=dev) for a, b in slabs]
     gathered = None
-    if world > 1 and rank == 0:
+    if use_dist and rank == 0:
         gathered = [[torch.empty((2, D, b - a), dtype=torch.float64, device=dev) for _ in range(world)]
                     for a, b in slabs]
     torch.cuda.synchronize()
@@ -163,7 +173,7 @@ def main():
             clim_finish(plan, raw_th[i].data_ptr(), raw_se[i].data_ptr(), n, not tstep, True, width,
                         out[i][0].data_ptr(), out[i][1].data_ptr(), ldo=n, stream=stream)
             h.event_record(ev[i][2], stream)
-            if world > 1:
+            if use_dist:
                 works.append(dist.gather(out[i], gathered[i] if rank == 0 else None, dst=0, async_op=True))
         for wk in works:
             wk.wait()
@@ -176,18 +186,18 @@ def main():
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -242,7 +252,7 @@ def main():
                         f"windowHalfWidth={w}, pctile={pctile}, smoothPercentileWidth={width}, "
                         f"nan_frac={args.nan_frac}",
             "cells_per_gpu": C, "T": T, "D": D, "kernel": plan.kernel, "slabs": len(slabs),
-            "gather": "rccl gather to rank 0, pipelined per slab" if world > 1 else "none",
+            "gather": "rccl gather to rank 0, pipelined per slab" if use_dist else "none",
         },
         "roofline": {
             "bound": "hbm", "kernel": "clim_ring_" + args.dtype, "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -283,8 +293,9 @@ def main():
                           f"{cores} processes; excludes xarray/dask per-cell overhead",
                 "max_rel_diff_vs_gpu": float(np.nanmax(np.abs(g[0] - th_c) / np.abs(th_c))),
             }
-        print(json.dumps(result))
-    if world > 1:
+        json_out.write(json.dumps(result) + "\n")
+        json_out.flush()
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
