@@ -205,6 +205,24 @@ int xmhw_event_stats_f64(const double *ts_dev, int64_t T, int64_t C, int64_t ld,
                          const int32_t *row_of_t_host, int32_t negate, const int32_t *events_dev,
                          int64_t ldo, const int64_t *offsets_dev, double *table_dev, void *stream);
 
+/* The `intermediate` Dataset of detect() (xmhw/xmhw.py:354-356; define_events(),
+ * identify.py:405-409): the per-step columns mhw_df() adds (xmhw/features.py:36-69).
+ * out_dev [8][T][ldv] float64 = seas, thresh (NaN outside events), relSeas, relThresh,
+ * relThreshNorm, severity, cats, mabs; dur_dev [4][T][ldv] uint8 = duration_moderate,
+ * duration_strong, duration_severe, duration_extreme.                                    */
+#define XMHW_INTERMEDIATE_F64_PLANES 8
+#define XMHW_INTERMEDIATE_U8_PLANES 4
+int xmhw_event_intermediate_f32(const float *ts_dev, int64_t T, int64_t C, int64_t ld,
+                                const double *seas_dev, const double *thresh_dev, int64_t ldc,
+                                const int32_t *row_of_t_host, int32_t negate,
+                                const int32_t *events_dev, int64_t ldo, double *out_dev,
+                                int64_t ldv, uint8_t *dur_dev, void *stream);
+int xmhw_event_intermediate_f64(const double *ts_dev, int64_t T, int64_t C, int64_t ld,
+                                const double *seas_dev, const double *thresh_dev, int64_t ldc,
+                                const int32_t *row_of_t_host, int32_t negate,
+                                const int32_t *events_dev, int64_t ldo, double *out_dev,
+                                int64_t ldv, uint8_t *dur_dev, void *stream);
+
 /* Synthetic SST generated in HBM (bench + large parity runs):
  * x[t,c] = 15 + A_c sin(2 pi (t - phi_c)/365.25) + 5e-4 t beta_c + N(0,1),
  * counter-based on (seed, cell0 + c, t); a sample is NaN with probability

@@ -80,16 +80,11 @@ def get_period(start, end, peak, tsend):
     return onset_period, decline_period
 
 
-def event_table(ts, seas, thresh, start, end, events):
-    """Per-event statistics of one cell.  ts/seas/thresh: (T,) with seas/thresh already
-    re-expanded along time; start/end/events: mhw_filter() output.  Returns (n_events, 31)."""
+def intermediate_columns(ts, seas, thresh, events):
+    """mhw_df() (features.py:36-69): the per-step columns, for one cell.  ts/seas/thresh (T,) with
+    the climatologies already re-expanded along time, events: mhw_filter() labels (NaN = none)."""
     ts, seas, thresh = (np.asarray(a, dtype=np.float64) for a in (ts, seas, thresh))
-    T = ts.shape[0]
-    last = T - 1
     ismhw = ~np.isnan(events)
-    anom = ts - seas
-    anom_plus = np.concatenate(([np.nan], anom[:-1]))
-    anom_minus = np.concatenate((anom[1:], [np.nan]))
     mt = np.where(ismhw, ts, np.nan)
     ms = np.where(ismhw, seas, np.nan)
     mth = np.where(ismhw, thresh, np.nan)
@@ -100,6 +95,23 @@ def event_table(ts, seas, thresh, start, end, events):
         relTN = relT / th_se
         sev = relS / -(th_se)
     cats = np.floor(1.0 + relTN)
+    return dict(seas=ms, thresh=mth, relSeas=relS, relThresh=relT, relThreshNorm=relTN, severity=sev, cats=cats,
+                duration_moderate=cats == 1.0, duration_strong=cats == 2.0, duration_severe=cats == 3.0,
+                duration_extreme=cats >= 4.0, mabs=mt)
+
+
+def event_table(ts, seas, thresh, start, end, events):
+    """Per-event statistics of one cell.  ts/seas/thresh: (T,) with seas/thresh already
+    re-expanded along time; start/end/events: mhw_filter() output.  Returns (n_events, 31)."""
+    ts, seas, thresh = (np.asarray(a, dtype=np.float64) for a in (ts, seas, thresh))
+    T = ts.shape[0]
+    last = T - 1
+    ismhw = ~np.isnan(events)
+    anom = ts - seas
+    anom_plus = np.concatenate(([np.nan], anom[:-1]))
+    anom_minus = np.concatenate((anom[1:], [np.nan]))
+    ic = intermediate_columns(ts, seas, thresh, events)
+    mt, relS, relT, sev, cats = ic["mabs"], ic["relSeas"], ic["relThresh"], ic["severity"], ic["cats"]
     rows = []
     for L in np.unique(events[ismhw]):
         idx = np.nonzero(events == L)[0]

@@ -30,3 +30,21 @@ def test_event_tables_match_the_reference():
                                 err_msg=f"case {i} column {col}")
         nev += tab.shape[0]
     assert nev == toffs[-1] > 1500
+
+
+def test_per_step_columns_match_the_reference_mhw_df():
+    """mhw_df()'s per-step columns (tests/golden/mhw_df_cases.npz, made by RUNNING the reference)."""
+    g = np.load(GOLDEN)
+    d = np.load(os.path.join(os.path.dirname(GOLDEN), "mhw_df_cases.npz"))
+    offs = g["offsets"]
+    cols = list(d["columns"])
+    for j, case in enumerate(d["cases"]):
+        sl = slice(offs[case], offs[case + 1])
+        ts, se, th = g["ts"][sl], g["seas"][sl], g["thresh"][sl]
+        m, jg, gap = g["params"][case]
+        with np.errstate(invalid="ignore"):
+            _, _, ev = det.mhw_filter(ts > th, int(m), bool(jg), int(gap))
+        ic = fo.intermediate_columns(ts, se, th, ev)
+        want = d["values"][:, d["offsets"][j]:d["offsets"][j + 1]]
+        for k, name in enumerate(cols):
+            npt.assert_array_equal(np.asarray(ic[name], dtype=np.float64), want[k], err_msg=f"case {case} {name}")

@@ -20,6 +20,9 @@ import pandas as pd
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from make_golden_detect import load_reference_identify, REF
 
+DF_COLS = ["seas", "thresh", "relSeas", "relThresh", "relThreshNorm", "severity", "cats", "duration_moderate",
+           "duration_strong", "duration_severe", "duration_extreme", "mabs"]
+OUT_DF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "mhw_df_cases.npz")
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "mhw_features_cases.npz")
 COLS = ["event", "index_start", "index_end", "time_start", "time_end", "time_peak", "intensity_max",
         "intensity_mean", "intensity_cumulative", "severity_max", "severity_mean", "severity_cumulative",
@@ -37,6 +40,7 @@ def main():
     warnings.simplefilter("ignore")
     rng = np.random.default_rng(20260103)
     ts_all, se_all, th_all, offs, params, tables, toffs = [], [], [], [0], [], [], [0]
+    df_cases, df_cols = [], []      # per-step mhw_df() columns of a few cases -> mhw_df_cases.npz
     for i in range(36):
         T = int(rng.integers(200, 1500))
         t = np.arange(T)
@@ -62,6 +66,9 @@ def main():
             df["bthresh"] = df.ts > df.thresh
             dfev = ident.mhw_filter(df.bthresh, idxarr, m, jg, g)
             df = feat.mhw_df(pd.concat([df, dfev], axis=1))
+            if i % 6 == 0 and (m, jg, g) == (5, True, 2):
+                df_cases.append(len(params))
+                df_cols.append(np.stack([df[c].to_numpy(dtype=np.float64) for c in DF_COLS]))
             if df.events.notna().sum() == 0:
                 tab = np.zeros((0, len(COLS)))
             else:
@@ -77,6 +84,10 @@ def main():
     np.savez_compressed(OUT, ts=np.concatenate(ts_all), seas=np.concatenate(se_all), thresh=np.concatenate(th_all),
                         offsets=np.array(offs), params=np.array(params), table=np.concatenate(tables, axis=0),
                         table_offsets=np.array(toffs), columns=np.array(COLS))
+    np.savez_compressed(OUT_DF, cases=np.array(df_cases), columns=np.array(DF_COLS),
+                        values=np.concatenate(df_cols, axis=1),
+                        offsets=np.cumsum([0] + [c.shape[1] for c in df_cols]))
+    print("mhw_df cases", df_cases, "->", OUT_DF)
     print("cases", len(params), "events", toffs[-1], "samples", offs[-1], "->", OUT)
 
 

@@ -1,6 +1,6 @@
-"""xmhw_amd -- MI355X (gfx950) implementation of xmhw's threshold() hot path.
+"""xmhw_amd -- MI355X (gfx950) implementation of xmhw's threshold() hot path and of its consumer.
 
-    from xmhw_amd import threshold        # same signature as xmhw.xmhw.threshold
+    from xmhw_amd import threshold, detect     # same signatures as xmhw.xmhw.threshold / detect
 
 The device side is hand-written HIP behind a C ABI (include/xmhw_amd.h); this
 package holds only the host side of the path.  Importing it does not need a
@@ -10,7 +10,9 @@ from .exception import XmhwException
 from .api import threshold, threshold_array, GridSeries, ClimDataset
 from .calendar import add_doy, get_calendar
 from .landmask import land_check
+from .detect import detect, EventDataset, InterDataset, climatology_series
 
 __all__ = ["threshold", "threshold_array", "GridSeries", "ClimDataset", "XmhwException",
-           "add_doy", "get_calendar", "land_check"]
+           "add_doy", "get_calendar", "land_check", "detect", "EventDataset", "InterDataset",
+           "climatology_series"]
 __version__ = "0.1.0"

@@ -249,6 +249,29 @@ int event_stats(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* se
 }
 
 template <typename T>
+int event_intermediate(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* seas, const double* thresh,
+                       int64_t ldc, const int32_t* row_of_t, int32_t negate, const int32_t* events, int64_t ldo,
+                       double* out, int64_t ldv, uint8_t* dur, void* stream) {
+    if (Tn <= 0 || C < 0 || ld < C || ldc < C || ldo < C || ldv < C)
+        return fail(XMHW_ERR_INVALID, "bad T/C/ld/ldc/ldo/ldv");
+    if (C == 0) return XMHW_OK;
+    if (!ts || !seas || !thresh || !row_of_t || !events || !out || !dur) return fail(XMHW_ERR_INVALID, "NULL buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int32_t* d_rows = nullptr;
+    HIP_TRY(hipMalloc(&d_rows, sizeof(int32_t) * static_cast<size_t>(Tn)));
+    hipError_t e = hipMemcpyAsync(d_rows, row_of_t, sizeof(int32_t) * static_cast<size_t>(Tn),
+                                  hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = xmhw::launch_event_intermediate<T>(ts, Tn, C, ld, seas, thresh, ldc, d_rows, negate, events, ldo, out,
+                                               ldv, dur, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_rows);
+    if (e != hipSuccess) return hip_fail(e, "event_intermediate launch");
+    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
+    return XMHW_OK;
+}
+
+template <typename T>
 int clim_host(const T* ts, const int32_t* doy, int64_t Tn, int64_t C, int32_t D, int32_t w, double q,
               int smooth, int smooth_w, int feb29_fix, int negate, double* thresh, double* seas) {
     if (C == 0) return XMHW_OK;
@@ -571,6 +594,20 @@ int xmhw_event_stats_f32(const float* ts, int64_t T, int64_t C, int64_t ld, cons
                          const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,
                          const int32_t* events, int64_t ldo, const int64_t* offsets, double* table, void* stream) {
     return event_stats<float>(ts, T, C, ld, seas, thresh, ldc, row_of_t, negate, events, ldo, offsets, table, stream);
+}
+int xmhw_event_intermediate_f32(const float* ts, int64_t T, int64_t C, int64_t ld, const double* seas,
+                                const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,
+                                const int32_t* events, int64_t ldo, double* out, int64_t ldv, uint8_t* dur,
+                                void* stream) {
+    return event_intermediate<float>(ts, T, C, ld, seas, thresh, ldc, row_of_t, negate, events, ldo, out, ldv, dur,
+                                     stream);
+}
+int xmhw_event_intermediate_f64(const double* ts, int64_t T, int64_t C, int64_t ld, const double* seas,
+                                const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,
+                                const int32_t* events, int64_t ldo, double* out, int64_t ldv, uint8_t* dur,
+                                void* stream) {
+    return event_intermediate<double>(ts, T, C, ld, seas, thresh, ldc, row_of_t, negate, events, ldo, out, ldv, dur,
+                                      stream);
 }
 int xmhw_event_stats_f64(const double* ts, int64_t T, int64_t C, int64_t ld, const double* seas,
                          const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,

@@ -64,6 +64,13 @@ hipError_t launch_event_stats(const T* ts, int64_t Tn, int64_t C, int64_t ld, co
                               const int32_t* events, int64_t ldo, const int64_t* offsets, double* table,
                               hipStream_t stream);
 
+// per-step columns of mhw_df(): out [8][T][ldv] f64, dur [4][T][ldv] u8
+template <typename T>
+hipError_t launch_event_intermediate(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* seas,
+                                     const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,
+                                     const int32_t* events, int64_t ldo, double* out, int64_t ldv, uint8_t* dur,
+                                     hipStream_t stream);
+
 template <typename T>
 hipError_t launch_synth(T* ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
                         double nan_frac, hipStream_t stream);

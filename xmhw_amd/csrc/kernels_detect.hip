@@ -297,4 +297,73 @@ template hipError_t launch_detect<double>(const double*, int64_t, int64_t, int64
                                           const int32_t*, int32_t, int32_t, int32_t, int32_t, int32_t*, int32_t*,
                                           int32_t*, uint8_t*, int64_t, int32_t*, hipStream_t);
 
+// ---------------------------------------------------------------------------
+// event_intermediate: the per-step columns mhw_df() adds (xmhw/features.py:36-69), i.e. the
+// `intermediate` Dataset of detect() (xmhw/xmhw.py:354-356, identify.py:405-409).  Elementwise:
+// out plane k of [8][T][ldv] float64 = seas, thresh (both masked to event steps), relSeas,
+// relThresh, relThreshNorm, severity, cats, mabs; dur plane k of [4][T][ldv] u8 =
+// duration_moderate / strong / severe / extreme.
+// ---------------------------------------------------------------------------
+constexpr int kInterRows = 8;   // time steps per thread
+
+template <typename T>
+__global__ __launch_bounds__(256) void event_intermediate(
+    const T* __restrict__ ts, int64_t Tn, int64_t C, int64_t ld, const double* __restrict__ seas,
+    const double* __restrict__ thresh, int64_t ldc, const int32_t* __restrict__ row_of_t, int32_t negate,
+    const int32_t* __restrict__ events, int64_t ldo, double* __restrict__ out, int64_t ldv,
+    uint8_t* __restrict__ dur) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int64_t t0 = static_cast<int64_t>(blockIdx.y) * kInterRows;
+    const int64_t plane = Tn * ldv;
+    const double nan = make_nan();
+#pragma unroll
+    for (int u = 0; u < kInterRows; ++u) {
+        const int64_t t = t0 + u;
+        if (t >= Tn) break;
+        double x = static_cast<double>(ts[t * ld + c]);
+        if (negate) x = -x;
+        const int64_t r = row_of_t[t];
+        const bool is = events[t * ldo + c] >= 0;
+        const double mt = is ? x : nan;
+        const double ms = is ? seas[r * ldc + c] : nan;
+        const double mth = is ? thresh[r * ldc + c] : nan;
+        const double relS = mt - ms, relT = mt - mth, ths = mth - ms;
+        const double relTN = relT / ths;
+        const double sev = relS / -(ths);
+        const double cat = floor(1.0 + relTN);
+        const int64_t o = t * ldv + c;
+        out[o] = ms;
+        out[plane + o] = mth;
+        out[2 * plane + o] = relS;
+        out[3 * plane + o] = relT;
+        out[4 * plane + o] = relTN;
+        out[5 * plane + o] = sev;
+        out[6 * plane + o] = cat;
+        out[7 * plane + o] = mt;
+        dur[o] = cat == 1.0 ? 1 : 0;
+        dur[plane + o] = cat == 2.0 ? 1 : 0;
+        dur[2 * plane + o] = cat == 3.0 ? 1 : 0;
+        dur[3 * plane + o] = cat >= 4.0 ? 1 : 0;
+    }
+}
+
+template <typename T>
+hipError_t launch_event_intermediate(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* seas,
+                                     const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,
+                                     const int32_t* events, int64_t ldo, double* out, int64_t ldv, uint8_t* dur,
+                                     hipStream_t stream) {
+    if (C <= 0 || Tn <= 0) return hipSuccess;
+    const dim3 grid(static_cast<unsigned>((C + 255) / 256), static_cast<unsigned>((Tn + kInterRows - 1) / kInterRows));
+    hipLaunchKernelGGL(event_intermediate<T>, grid, dim3(256), 0, stream, ts, Tn, C, ld, seas, thresh, ldc, row_of_t,
+                       negate, events, ldo, out, ldv, dur);
+    return hipGetLastError();
+}
+template hipError_t launch_event_intermediate<float>(const float*, int64_t, int64_t, int64_t, const double*,
+                                                     const double*, int64_t, const int32_t*, int32_t, const int32_t*,
+                                                     int64_t, double*, int64_t, uint8_t*, hipStream_t);
+template hipError_t launch_event_intermediate<double>(const double*, int64_t, int64_t, int64_t, const double*,
+                                                      const double*, int64_t, const int32_t*, int32_t, const int32_t*,
+                                                      int64_t, double*, int64_t, uint8_t*, hipStream_t);
+
 }  // namespace xmhw

@@ -255,6 +255,28 @@ PYBIND11_MODULE(_xmhw_hip, m) {
        py::arg("ldc"), py::arg("row_of_t"), py::arg("negate"), py::arg("events"), py::arg("ldo"), py::arg("offsets"),
        py::arg("table"), py::arg("stream") = 0);
 
+    m.def("event_intermediate", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, uintptr_t seas,
+                                   uintptr_t thresh, int64_t ldc, i32arr row_of_t, int negate, uintptr_t events,
+                                   int64_t ldo, uintptr_t out, int64_t ldv, uintptr_t dur, uintptr_t stream) {
+        if (row_of_t.size() != T) throw InvalidError("row_of_t length must equal T");
+        py::gil_scoped_release r;
+        int rc = -1;
+        if (itemsize == 4)
+            rc = xmhw_event_intermediate_f32(static_cast<const float*>(vp(ts)), T, C, ld, static_cast<const double*>(vp(seas)),
+                                             static_cast<const double*>(vp(thresh)), ldc, row_of_t.data(), negate,
+                                             static_cast<const int32_t*>(vp(events)), ldo, static_cast<double*>(vp(out)), ldv,
+                                             static_cast<uint8_t*>(vp(dur)), vp(stream));
+        else if (itemsize == 8)
+            rc = xmhw_event_intermediate_f64(static_cast<const double*>(vp(ts)), T, C, ld, static_cast<const double*>(vp(seas)),
+                                             static_cast<const double*>(vp(thresh)), ldc, row_of_t.data(), negate,
+                                             static_cast<const int32_t*>(vp(events)), ldo, static_cast<double*>(vp(out)), ldv,
+                                             static_cast<uint8_t*>(vp(dur)), vp(stream));
+        if (rc == -1) throw InvalidError("itemsize must be 4 or 8");
+        check(rc);
+    }, py::arg("ts"), py::arg("itemsize"), py::arg("T"), py::arg("C"), py::arg("ld"), py::arg("seas"), py::arg("thresh"),
+       py::arg("ldc"), py::arg("row_of_t"), py::arg("negate"), py::arg("events"), py::arg("ldo"), py::arg("out"),
+       py::arg("ldv"), py::arg("dur"), py::arg("stream") = 0);
+
     m.def("synth_sst", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
                           double nan_frac, uintptr_t stream) {
         if (itemsize == 4)

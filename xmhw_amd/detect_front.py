@@ -3,8 +3,10 @@ gap joining for all cells at once (define_events() front part, mhw_filter(), joi
 xmhw/identify.py:366-372, :415-479, :273-325).  The reference does this per cell in pandas
 (one dask task per cell, xmhw/xmhw.py:440-454).
 
-This is the first consumer of threshold()'s output; event
-statistics (mhw_df / mhw_features) are not part of it.
+These are the consumers of threshold()'s output: the event
+filter (mhw_filter_cells) and the whole per-cell define_events() (detect_cells: filter + per-event
+statistics + the optional per-step `intermediate` columns).  xmhw_amd.detect.detect() is the
+reference-shaped entry point on top of detect_cells().
 """
 import numpy as np
 
@@ -79,16 +81,11 @@ EVENT_COLUMNS = ["event", "index_start", "index_end", "time_start", "time_end", 
                  "rate_onset", "rate_decline"]
 
 
-def mhw_features_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False):
-    """Event detection + per-event statistics for a dense (T, C) series on the GPU:
-    define_events() (xmhw/identify.py:329-412) without the xarray/pandas packaging, i.e.
-    mhw_filter() + mhw_df() + mhw_features() (xmhw/features.py:22-315) for all cells.
+INTERMEDIATE_F64 = ["seas", "thresh", "relSeas", "relThresh", "relThreshNorm", "severity", "cats", "mabs"]
+INTERMEDIATE_U8 = ["duration_moderate", "duration_strong", "duration_severe", "duration_extreme"]
 
-    seas, thresh: (D, C) climatologies on the same cells; doy (T,), doys (D,) as in
-    mhw_filter_cells().  Returns (table, offsets): table (n_events, 31) float64 with the
-    columns EVENT_COLUMNS (time stamps as positions along the time axis), events of cell c in
-    rows offsets[c]:offsets[c+1] in time order.
-    """
+
+def _check_inputs(ts, seas, thresh, doy, doys):
     ts = np.asarray(ts)
     if ts.dtype not in (np.float32, np.float64):
         ts = ts.astype(np.float64)
@@ -98,40 +95,101 @@ def mhw_features_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True
     if ts.ndim != 2 or thresh.shape != seas.shape or thresh.ndim != 2 or ts.shape[1] != thresh.shape[1]:
         raise XmhwException("ts must be (T, C) and seas/thresh (D, C) on the same cells")
     doy, doys = np.asarray(doy), np.asarray(doys)
-    T, C = ts.shape
-    if doy.shape[0] != T or doys.shape[0] != thresh.shape[0]:
+    if doy.shape[0] != ts.shape[0] or doys.shape[0] != thresh.shape[0]:
         raise XmhwException("doy must have length T and doys length D")
-    rows = np.searchsorted(doys, doy)
-    if np.any(rows >= doys.shape[0]) or np.any(doys[np.minimum(rows, doys.shape[0] - 1)] != doy):
+    order = np.argsort(doys, kind="stable")
+    rows = np.searchsorted(doys, doy, sorter=order)
+    ok = rows < doys.shape[0]
+    rows = order[np.minimum(rows, doys.shape[0] - 1)]
+    if not ok.all() or np.any(doys[rows] != doy):
+        # th.sel(doy=ts.doy) raises KeyError in the reference for a label without climatology
         raise XmhwException("a time step's doy label has no row in the climatology")
-    rows = rows.astype(np.int32)
+    return ts, seas, thresh, rows.astype(np.int32)
+
+
+def detect_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
+                 intermediate=False, max_batch_bytes=64 << 30):
+    """define_events() (xmhw/identify.py:329-412) for all cells of a dense (T, C) series on the
+    GPU: th.sel(doy=ts.doy) + exceedance + mhw_filter() + mhw_df() + mhw_features()
+    (xmhw/features.py:22-315), without the xarray/pandas packaging.
+
+    ts (T, C) float32/float64; seas, thresh (D, C) climatologies on the same cells; doy (T,)
+    label of every step, doys (D,) labels of the climatology rows.  With coldSpells the series
+    is negated first (xmhw/xmhw.py:411-412; the climatologies are expected to come from
+    threshold(coldSpells=True), as in the reference).
+    Returns dict(table (n_events, 31) float64 with columns EVENT_COLUMNS, time stamps as
+    positions; offsets (C+1,): events of cell c are table[offsets[c]:offsets[c+1]] in time
+    order; inter: None or dict of (T, C) arrays with the per-step columns of mhw_df()).
+    Cells are processed in batches so that the device working set stays below max_batch_bytes.
+    """
+    ts, seas, thresh, rows = _check_inputs(ts, seas, thresh, doy, doys)
+    T, C = ts.shape
+    D = thresh.shape[0]
     h = hip()
-    bufs = []
-    try:
-        d_ts = DeviceBuffer.from_array(ts)
-        d_th = DeviceBuffer.from_array(thresh)
-        d_se = DeviceBuffer.from_array(seas)
-        d_ev, d_st, d_en = (DeviceBuffer(4 * T * C) for _ in range(3))
-        d_n = DeviceBuffer(4 * C)
-        bufs += [d_ts, d_th, d_se, d_ev, d_st, d_en, d_n]
-        isz = ts.dtype.itemsize
-        neg = int(bool(coldSpells))
+    isz = ts.dtype.itemsize
+    neg = int(bool(coldSpells))
+    per_cell = T * (isz + 12) + 2 * D * 8 + (T * (8 * len(INTERMEDIATE_F64) + len(INTERMEDIATE_U8) + 1) if intermediate else 0)
+    batch = int(max(1, min(C, max_batch_bytes // max(per_cell, 1))))
+    tables, counts_all = [], []
+    inter = None
+    if intermediate:
+        inter = {k: np.empty((T, C), dtype=np.float64) for k in INTERMEDIATE_F64 + ["events"]}
+        inter.update({k: np.empty((T, C), dtype=bool) for k in INTERMEDIATE_U8 + ["bthresh"]})
+        inter["ts"] = -ts if coldSpells else ts.copy()
+    for c0 in range(0, C, batch):
+        c1 = min(C, c0 + batch)
+        n = c1 - c0
+        bufs = []
         try:
-            h.detect_events(d_ts.ptr, isz, T, C, C, d_th.ptr, C, rows, int(minDuration), int(bool(joinGaps)),
-                            int(maxGap), neg, d_ev.ptr, d_st.ptr, d_en.ptr, 0, C, d_n.ptr)
-        except h.InvalidArgument as e:
-            raise XmhwException(str(e)) from e
-        h.stream_sync(0)
-        counts = d_n.to_array((C,), np.int32)
-        offsets = np.zeros(C + 1, dtype=np.int64)
-        np.cumsum(counts, out=offsets[1:])
-        ntot = int(offsets[-1])
-        d_off = DeviceBuffer.from_array(offsets)
-        d_tab = DeviceBuffer(8 * max(ntot, 1) * h.EVENT_COLUMNS)
-        bufs += [d_off, d_tab]
-        h.event_stats(d_ts.ptr, isz, T, C, C, d_se.ptr, d_th.ptr, C, rows, neg, d_ev.ptr, C, d_off.ptr, d_tab.ptr)
-        table = d_tab.to_array((ntot, h.EVENT_COLUMNS), np.float64) if ntot else np.zeros((0, h.EVENT_COLUMNS))
-    finally:
-        for b in bufs:
-            b.free()
-    return table, offsets
+            d_ts = DeviceBuffer.from_array(np.ascontiguousarray(ts[:, c0:c1])); bufs.append(d_ts)
+            d_th = DeviceBuffer.from_array(np.ascontiguousarray(thresh[:, c0:c1])); bufs.append(d_th)
+            d_se = DeviceBuffer.from_array(np.ascontiguousarray(seas[:, c0:c1])); bufs.append(d_se)
+            d_ev, d_st, d_en = (DeviceBuffer(4 * T * n) for _ in range(3))
+            d_n = DeviceBuffer(4 * n)
+            bufs += [d_ev, d_st, d_en, d_n]
+            d_b = None
+            if intermediate:
+                d_b = DeviceBuffer(T * n); bufs.append(d_b)
+            try:
+                h.detect_events(d_ts.ptr, isz, T, n, n, d_th.ptr, n, rows, int(minDuration), int(bool(joinGaps)),
+                                int(maxGap), neg, d_ev.ptr, d_st.ptr, d_en.ptr, d_b.ptr if d_b else 0, n, d_n.ptr)
+            except h.InvalidArgument as e:
+                raise XmhwException(str(e)) from e
+            h.stream_sync(0)
+            counts = d_n.to_array((n,), np.int32)
+            offs = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(counts, out=offs[1:])
+            ntot = int(offs[-1])
+            d_off = DeviceBuffer.from_array(offs); bufs.append(d_off)
+            d_tab = DeviceBuffer(8 * max(ntot, 1) * h.EVENT_COLUMNS); bufs.append(d_tab)
+            h.event_stats(d_ts.ptr, isz, T, n, n, d_se.ptr, d_th.ptr, n, rows, neg, d_ev.ptr, n, d_off.ptr, d_tab.ptr)
+            tables.append(d_tab.to_array((ntot, h.EVENT_COLUMNS), np.float64) if ntot
+                          else np.zeros((0, h.EVENT_COLUMNS)))
+            counts_all.append(counts)
+            if intermediate:
+                d_out = DeviceBuffer(8 * len(INTERMEDIATE_F64) * T * n); bufs.append(d_out)
+                d_dur = DeviceBuffer(len(INTERMEDIATE_U8) * T * n); bufs.append(d_dur)
+                h.event_intermediate(d_ts.ptr, isz, T, n, n, d_se.ptr, d_th.ptr, n, rows, neg, d_ev.ptr, n,
+                                     d_out.ptr, n, d_dur.ptr)
+                out = d_out.to_array((len(INTERMEDIATE_F64), T, n), np.float64)
+                dur = d_dur.to_array((len(INTERMEDIATE_U8), T, n), np.uint8)
+                for k, name in enumerate(INTERMEDIATE_F64):
+                    inter[name][:, c0:c1] = out[k]
+                for k, name in enumerate(INTERMEDIATE_U8):
+                    inter[name][:, c0:c1] = dur[k] != 0
+                inter["events"][:, c0:c1] = _nan_where_negative(d_ev.to_array((T, n), np.int32))
+                inter["bthresh"][:, c0:c1] = d_b.to_array((T, n), np.uint8) != 0
+        finally:
+            for b in bufs:
+                b.free()
+    counts = np.concatenate(counts_all) if counts_all else np.zeros(0, np.int32)
+    offsets = np.zeros(C + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    table = np.concatenate(tables, axis=0) if tables else np.zeros((0, len(EVENT_COLUMNS)))
+    return dict(table=table, offsets=offsets, inter=inter)
+
+
+def mhw_features_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False):
+    """Event table only: (table, offsets) of detect_cells()."""
+    r = detect_cells(ts, seas, thresh, doy, doys, minDuration, joinGaps, maxGap, coldSpells)
+    return r["table"], r["offsets"]
