@@ -92,3 +92,41 @@ def test_xarray_in_xarray_out(fake_xarray, oisst):
     assert "xmhw_parameters" in ds.attrs and ds.attrs["source"].startswith("xmhw code")
     # the caller's array is not mutated (the reference adds a 'doy' coord to it)
     assert set(da.coords) == {"time", "lat", "lon"}
+
+
+def test_detect_xarray_in_xarray_out(fake_xarray, oisst):
+    """detect(): DataArrays in -> Datasets out, laid out like the reference's (events, lat, lon)."""
+    from detect_standin import oracle_detect_cells
+    from xmhw_amd.api import _threshold
+    from xmhw_amd.detect import EVENT_COLUMNS, _detect
+    coords = {"time": (oisst["time64"], {"long_name": "Center time of the day"}),
+              "lat": (oisst["lat"], {"units": "degrees_north"}),
+              "lon": (oisst["lon"], {"units": "degrees_east"})}
+    da = FakeDataArray(oisst["sst"], ("time", "lat", "lon"), coords, attrs={"units": "Celsius"},
+                       encodings={"time": {"calendar": "proleptic_gregorian"}})
+    clim = _threshold(da, oracle_compute)
+    th = FakeDataArray(clim["thresh"].values, clim["thresh"].dims,
+                       {d: (clim[d].values, clim[d].attrs) for d in clim["thresh"].dims})
+    se = FakeDataArray(clim["seas"].values, clim["seas"].dims,
+                       {d: (clim[d].values, clim[d].attrs) for d in clim["seas"].dims})
+    mhw, inter = _detect(da, th, se, oracle_detect_cells, intermediate=True)
+    assert isinstance(mhw, FakeDataset) and isinstance(inter, FakeDataset)
+    assert mhw["intensity_max"].dims == ("events", "lat", "lon")
+    n_labels = mhw["events"].values.shape[0]
+    assert mhw["duration"].values.shape == (n_labels, clim["lat"].values.shape[0], clim["lon"].values.shape[0])
+    npt.assert_array_equal(mhw["lat"].values, clim["lat"].values)
+    assert mhw["lat"].attrs == {"units": "degrees_north"}
+    assert mhw["events"].attrs["long_name"] == "MHW event identifier: starting index"
+    assert mhw["rate_onset"].attrs == {"long_name": "MHW onset rate", "units": "degree_C day-1"}
+    assert mhw["time_start"].values.dtype.kind == "M"
+    assert mhw.attrs["title"].startswith("Marine heatwave events identified")
+    for name in EVENT_COLUMNS:
+        assert mhw[name].values.shape[0] == n_labels
+    # every event of every cell appears exactly once in the dense layout
+    ev = mhw["event"].values
+    lab = mhw["events"].values
+    ok = ~np.isnan(ev)
+    assert ok.sum() > 0
+    npt.assert_array_equal(ev[ok], np.broadcast_to(lab[:, None, None], ev.shape)[ok])
+    assert inter["relSeas"].dims == ("time", "lat", "lon")
+    assert inter["relSeas"].values.shape == (731,) + ev.shape[1:]

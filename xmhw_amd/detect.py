@@ -190,11 +190,9 @@ class EventDataset:
         dims, coords, data = self.to_dense()
         ds = xr.Dataset({k: (dims, v) for k, v in data.items()}, coords={k: (k, v) for k, v in coords.items()})
         for c, a in self.coord_attrs.items():
-            if c in ds.coords:
-                ds[c].attrs.update(a)
+            ds[c].attrs.update(a)
         for v, a in self.var_attrs.items():
-            if v in ds:
-                ds[v].attrs.update(a)
+            ds[v].attrs.update(a)
         ds.attrs.update(self.attrs)
         return ds
 
