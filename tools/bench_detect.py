@@ -14,7 +14,7 @@ from xmhw_amd.calendar import add_doy
 
 h = hip()
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 259200
-steps = 5
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 t = np.arange("1982-01-01", "2022-01-01", dtype="datetime64[D]")
 doy = add_doy(t); T = len(doy)
 plan = Plan(doy, 5)

@@ -94,18 +94,26 @@ __global__ __launch_bounds__(256) void detect_events(
 // steps of an event are contiguous (gap steps of joined events carry the label), so the groupby
 // aggregations become running accumulators that are flushed into the cell's slice of a compact
 // event table (offsets = exclusive prefix sum of the per-cell event counts).  NaN samples are
-// skipped as pandas does; variances are Welford updates (ddof = 1), returned as standard deviations.
+// skipped as pandas does; variances (ddof = 1) come from shifted sums, returned as standard deviations.
 // Columns: see kEventColumns in kernels.h (same order as oracle/features_oracle.py COLUMNS).
 // ---------------------------------------------------------------------------
+// Running variance without a division per sample: sums of (x - K) and (x - K)^2 with K = the
+// series' first sample in the event (shifted-data algorithm: K lies inside the event's spread, so
+// the final subtraction does not cancel catastrophically), one division at the flush.
 struct Welford {
-    double n = 0.0, mean = 0.0, m2 = 0.0;
+    double n = 0.0, k = 0.0, s1 = 0.0, s2 = 0.0;
     __device__ __forceinline__ void add(double x) {
+        if (n == 0.0) k = x;
         n += 1.0;
-        const double d = x - mean;
-        mean += d / n;
-        m2 += d * (x - mean);
+        const double d = x - k;
+        s1 += d;
+        s2 += d * d;
     }
-    __device__ __forceinline__ double sd() const { return n >= 2.0 ? sqrt(m2 / (n - 1.0)) : make_nan(); }
+    __device__ __forceinline__ double sd() const {
+        if (n < 2.0) return make_nan();
+        const double v = (s2 - s1 * s1 / n) / (n - 1.0);
+        return sqrt(v > 0.0 ? v : 0.0);
+    }
 };
 
 struct EventAcc {
@@ -192,52 +200,82 @@ __global__ __launch_bounds__(128) void event_stats(
     a.reset(-1, 0);
     bool in_event = false, prev_in_event = false;
     double anom_prev = make_nan();
-    for (int64_t t = 0; t < Tn; ++t) {
-        double x = static_cast<double>(ts[t * ld + c]);
-        if (negate) x = -x;
-        const int64_t r = row_of_t[t];
-        const double se = seas[r * ldc + c], th = thresh[r * ldc + c];
-        const int32_t ev = events[t * ldo + c];
-        const double anom = x - se;
-        // anom_minus of the previous step (= this step's anomaly) closes the previous step's view
-        if (prev_in_event && anom == anom) a.anom_last = anom;
-        if (in_event && ev != a.label) {
-            if (nout < nmax) flush_event(a, Tn - 1, out + nout * kEventColumns);
-            ++nout;
-            in_event = false;
+    // Labels are read for every step; the sample and the two climatology rows only where they are
+    // used: on labelled steps and on their immediate neighbours (anom_plus / anom_minus).  Events
+    // cover ~10 % of the steps, so most 32-byte sectors of ts / seas / thresh are never fetched.
+    constexpr int U = 8;
+    int32_t ev_prev = -1;
+    int32_t ev_next = events[c];                         // label of step t0 (carried between batches)
+    for (int64_t t0 = 0; t0 < Tn; t0 += U) {
+        int32_t evs[U + 1];
+        evs[0] = ev_next;
+#pragma unroll
+        for (int u = 1; u <= U; ++u) evs[u] = t0 + u < Tn ? events[(t0 + u) * ldo + c] : -1;
+        ev_next = evs[U];
+        double xs[U], ses[U], ths[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t t = t0 + u;
+            const bool here = evs[u] >= 0;
+            const bool near = here || evs[u + 1] >= 0 || (u ? evs[u - 1] >= 0 : ev_prev >= 0);
+            xs[u] = ses[u] = ths[u] = make_nan();
+            if (t < Tn && near) {
+                const int64_t r = row_of_t[t];
+                xs[u] = static_cast<double>(ts[t * ld + c]);
+                ses[u] = seas[r * ldc + c];
+                if (here) ths[u] = thresh[r * ldc + c];
+            }
         }
-        if (ev >= 0) {
-            if (!in_event) { a.reset(ev, t); in_event = true; }
-            a.last = t;
-            if (!a.have_afirst && anom_prev == anom_prev) { a.anom_first = anom_prev; a.have_afirst = true; }
-            // every series skips its own NaNs, as pandas' groupby aggregations do
-            const double relS = x - se, relT = x - th, ths = th - se;
-            const double sev = relS / -(ths);
-            const double cat = floor(1.0 + relT / ths);
-            if (x == x) { a.s_abs += x; a.w_abs.add(x); }
-            if (relT == relT) { a.s_relT += relT; a.w_relT.add(relT); }
-            if (relS == relS) {
-                a.s_relS += relS; a.w_relS.add(relS);
-                if (!(a.max_relS >= relS)) {       // first maximum (NaN-initialised)
-                    a.max_relS = relS; a.imax = t - a.first; a.relT_at_max = relT; a.abs_at_max = x;
+        ev_prev = evs[U - 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t t = t0 + u;
+            if (t >= Tn) break;
+            double x = xs[u];
+            if (negate) x = -x;
+            const double se = ses[u], th = ths[u];
+            const int32_t ev = evs[u];
+            const double anom = x - se;
+            // anom_minus of the previous step (= this step's anomaly) closes the previous step's view
+            if (prev_in_event && anom == anom) a.anom_last = anom;
+            if (in_event && ev != a.label) {
+                if (nout < nmax) flush_event(a, Tn - 1, out + nout * kEventColumns);
+                ++nout;
+                in_event = false;
+            }
+            if (ev >= 0) {
+                if (!in_event) { a.reset(ev, t); in_event = true; }
+                a.last = t;
+                if (!a.have_afirst && anom_prev == anom_prev) { a.anom_first = anom_prev; a.have_afirst = true; }
+                // every series skips its own NaNs, as pandas' groupby aggregations do
+                const double relS = x - se, relT = x - th, thse = th - se;
+                const double sev = relS / -(thse);
+                const double cat = floor(1.0 + relT / thse);
+                if (x == x) { a.s_abs += x; a.w_abs.add(x); }
+                if (relT == relT) { a.s_relT += relT; a.w_relT.add(relT); }
+                if (relS == relS) {
+                    a.s_relS += relS; a.w_relS.add(relS);
+                    if (!(a.max_relS >= relS)) {       // first maximum (NaN-initialised)
+                        a.max_relS = relS; a.imax = t - a.first; a.relT_at_max = relT; a.abs_at_max = x;
+                    }
+                    if (!a.have_first) { a.relS_first = relS; a.have_first = true; }
+                    a.relS_last = relS;
                 }
-                if (!a.have_first) { a.relS_first = relS; a.have_first = true; }
-                a.relS_last = relS;
+                if (sev == sev) {
+                    a.s_sev += sev; a.w_sev.add(sev);
+                    if (!(a.max_sev >= sev)) a.max_sev = sev;
+                }
+                if (cat == cat) {
+                    if (!(a.max_cat >= cat)) a.max_cat = cat;
+                    a.n_mod += cat == 1.0 ? 1.0 : 0.0;
+                    a.n_str += cat == 2.0 ? 1.0 : 0.0;
+                    a.n_sev += cat == 3.0 ? 1.0 : 0.0;
+                    a.n_ext += cat >= 4.0 ? 1.0 : 0.0;
+                }
             }
-            if (sev == sev) {
-                a.s_sev += sev; a.w_sev.add(sev);
-                if (!(a.max_sev >= sev)) a.max_sev = sev;
-            }
-            if (cat == cat) {
-                if (!(a.max_cat >= cat)) a.max_cat = cat;
-                a.n_mod += cat == 1.0 ? 1.0 : 0.0;
-                a.n_str += cat == 2.0 ? 1.0 : 0.0;
-                a.n_sev += cat == 3.0 ? 1.0 : 0.0;
-                a.n_ext += cat >= 4.0 ? 1.0 : 0.0;
-            }
+            prev_in_event = in_event;
+            anom_prev = anom;
         }
-        prev_in_event = in_event;
-        anom_prev = anom;
     }
     if (in_event) {
         if (nout < nmax) flush_event(a, Tn - 1, out + nout * kEventColumns);
