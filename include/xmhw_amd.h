@@ -205,6 +205,42 @@ int xmhw_event_stats_f64(const double *ts_dev, int64_t T, int64_t C, int64_t ld,
                          const int32_t *row_of_t_host, int32_t negate, const int32_t *events_dev,
                          int64_t ldo, const int64_t *offsets_dev, double *table_dev, void *stream);
 
+/* define_events() (xmhw/identify.py:326-412) when only the event TABLE is wanted — no per-step
+ * outputs, the least HBM traffic the result allows.  Three stages:
+ *  1. xmhw_exceed_bits_*: ts > thresh[row(t)] (identify.py:366-372) as one bit per sample;
+ *     bits_dev [ceil(T/64)][ldb] uint64, bit (t & 63) of word t/64 of column c.  thresh_dev
+ *     is (D, ldt); the f32 variant compares against the float32 floor of each threshold
+ *     (identical results, half the bytes re-read per step).
+ *  2. xmhw_events_from_bits: mhw_filter() + join_gaps() (identify.py:415-479, 273-325) on the
+ *     bits.  offsets_dev == NULL: count only, nevents_dev[C] = events per cell.  Otherwise
+ *     (offsets_dev[C+1] = exclusive prefix sum of those counts) column 0 (label), 1 (cell
+ *     index, scratch), 3 and 4 (first / last labelled step) of every event's row of
+ *     table_dev[offsets[C]][XMHW_EVENT_COLUMNS] are written; nevents_dev may be NULL.
+ *     Asynchronous on `stream`.
+ *  3. xmhw_event_stats_sparse_*: mhw_df() + mhw_features() (xmhw/features.py:22-315) for the
+ *     n_events rows prepared by stage 2, one thread per event; fills all 31 columns.
+ * Same results as xmhw_detect_events_* + xmhw_event_stats_*.                              */
+int xmhw_exceed_bits_f32(const float *ts_dev, int64_t T, int64_t C, int64_t ld,
+                         const double *thresh_dev, int64_t ldt, int64_t D,
+                         const int32_t *row_of_t_host, int32_t negate, uint64_t *bits_dev,
+                         int64_t ldb, void *stream);
+int xmhw_exceed_bits_f64(const double *ts_dev, int64_t T, int64_t C, int64_t ld,
+                         const double *thresh_dev, int64_t ldt, int64_t D,
+                         const int32_t *row_of_t_host, int32_t negate, uint64_t *bits_dev,
+                         int64_t ldb, void *stream);
+int xmhw_events_from_bits(const uint64_t *bits_dev, int64_t T, int64_t C, int64_t ldb,
+                          int32_t min_duration, int32_t join_gaps, int32_t max_gap,
+                          const int64_t *offsets_dev, int32_t *nevents_dev, double *table_dev,
+                          void *stream);
+int xmhw_event_stats_sparse_f32(const float *ts_dev, int64_t T, int64_t C, int64_t ld,
+                                const double *seas_dev, const double *thresh_dev, int64_t ldc,
+                                const int32_t *row_of_t_host, int32_t negate, int64_t n_events,
+                                double *table_dev, void *stream);
+int xmhw_event_stats_sparse_f64(const double *ts_dev, int64_t T, int64_t C, int64_t ld,
+                                const double *seas_dev, const double *thresh_dev, int64_t ldc,
+                                const int32_t *row_of_t_host, int32_t negate, int64_t n_events,
+                                double *table_dev, void *stream);
+
 /* The `intermediate` Dataset of detect() (xmhw/xmhw.py:354-356; define_events(),
  * identify.py:405-409): the per-step columns mhw_df() adds (xmhw/features.py:36-69).
  * out_dev [8][T][ldv] float64 = seas, thresh (NaN outside events), relSeas, relThresh,

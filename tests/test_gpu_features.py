@@ -21,7 +21,8 @@ def front():
     return f
 
 
-def test_event_tables_against_reference(front):
+@pytest.mark.parametrize("per_step", [False, True])
+def test_event_tables_against_reference(front, per_step):
     """Each golden case is one cell whose climatology varies per step: a climatology with one row
     per time step (doy label = step index) re-expands to exactly the stored seas/thresh series."""
     g = np.load(GOLDEN)
@@ -33,8 +34,9 @@ def test_event_tables_against_reference(front):
         ts, se, th = g["ts"][sl], g["seas"][sl], g["thresh"][sl]
         T = ts.shape[0]
         lab = np.arange(1, T + 1)
-        table, offsets = front.mhw_features_cells(ts[:, None], se[:, None], th[:, None], lab, lab,
-                                                  int(m), bool(jg), int(gap))
+        r = front.detect_cells(ts[:, None], se[:, None], th[:, None], lab, lab, int(m), bool(jg), int(gap),
+                               per_step_kernels=per_step)
+        table, offsets = r["table"], r["offsets"]
         want = g["table"][toffs[i]:toffs[i + 1]]
         assert table.shape == want.shape and offsets[-1] == want.shape[0], f"case {i}"
         for k, col in enumerate(front.EVENT_COLUMNS):
@@ -70,3 +72,79 @@ def test_gridded_against_oracle(front, dtype):
         got = table[offsets[c]:offsets[c + 1]]
         assert got.shape == want.shape
         npt.assert_allclose(got, want, rtol=1e-9, atol=1e-11, equal_nan=True, err_msg=f"cell {c}")
+
+
+@pytest.mark.parametrize("T", [5, 63, 64, 65, 128, 1000])
+@pytest.mark.parametrize("params", [(5, True, 2), (2, True, 1), (3, False, 0), (1, True, 0)])
+def test_table_only_path_equals_per_step_path(front, T, params):
+    """The bit-packed / thread-per-event pipeline and the per-step kernels run the same per-event
+    arithmetic in the same order: identical tables, for series whose runs touch both ends, span
+    word boundaries, or cover everything."""
+    m, jg, gap = params
+    rng = np.random.default_rng(T * 31 + m)
+    C = 70                                       # more than one wave, not a multiple of 64
+    t = np.arange(T)[:, None]
+    x = rng.normal(size=(T, C)).cumsum(axis=0) * 0.3 + rng.normal(size=(T, C))
+    x[:, 0] = 10.0                               # always above
+    x[:, 1] = -10.0                              # never above
+    x[: min(T, 7), 2] = 10.0                     # run at the series start
+    x[-min(T, 7):, 3] = 10.0                     # run reaching the series end
+    x[rng.random((T, C)) < 0.03] = np.nan
+    x[:, 4] = np.nan
+    doy = (np.arange(T) % 366) + 1
+    doys = np.arange(1, min(T, 366) + 1)
+    se = rng.normal(size=(doys.shape[0], C)) * 0.1
+    th = se + 0.8 + 0.1 * rng.random((doys.shape[0], C))
+    for dtype in (np.float32, np.float64):
+        for cold in (False, True):
+            a = front.detect_cells(x.astype(dtype), se, th, doy, doys, m, jg, gap, coldSpells=cold)
+            b = front.detect_cells(x.astype(dtype), se, th, doy, doys, m, jg, gap, coldSpells=cold,
+                                   per_step_kernels=True)
+            npt.assert_array_equal(a["offsets"], b["offsets"])
+            npt.assert_array_equal(a["table"], b["table"])
+
+
+def test_exceed_bits_float32_floor_is_exact(front):
+    """xmhw_exceed_bits_f32 compares against the float32 floor of each threshold: same bits as
+    (double)x > th for thresholds equal to, one float64 ulp around, and far from float32 values,
+    and for inf / NaN / huge magnitudes on either side."""
+    from xmhw_amd._lib import hip
+    from xmhw_amd.device import DeviceBuffer
+    h = hip()
+    rng = np.random.default_rng(77)
+    T, C = 200, 96
+    x = (rng.normal(size=(T, C)) * 10.0 ** rng.integers(-3, 4, size=(T, C))).astype(np.float32)
+    x[5, :] = np.inf; x[6, :] = -np.inf; x[7, :] = np.nan; x[8, :] = np.float32(3.4e38); x[9, :] = 0.0; x[10, :] = -0.0
+    xd = x.astype(np.float64)
+    th = np.empty((T, C))
+    kind = rng.integers(0, 8, size=(T, C))
+    th[:] = rng.normal(size=(T, C))
+    th = np.where(kind == 0, xd, th)                                   # equal: not an exceedance
+    th = np.where(kind == 1, np.nextafter(xd, -np.inf), th)            # one f64 ulp below x
+    th = np.where(kind == 2, np.nextafter(xd, np.inf), th)             # one f64 ulp above x
+    th = np.where(kind == 3, np.nextafter(x, np.float32(-np.inf)).astype(np.float64), th)   # previous f32
+    th = np.where(kind == 4, xd * (1 + 1e-9), th)
+    th[11, :] = np.inf; th[12, :] = -np.inf; th[13, :] = np.nan; th[14, :] = 1e300; th[15, :] = -1e300
+    th[16, :] = 5e-324; th[17, :] = -5e-324
+    rows = np.arange(T, dtype=np.int32)                                # one threshold row per step
+    with np.errstate(invalid="ignore"):
+        want = xd > th
+    for neg in (0, 1):
+        w = (-xd > th) if neg else want
+        with np.errstate(invalid="ignore"):
+            w = (-xd > th) if neg else (xd > th)
+        d_x, d_th = DeviceBuffer.from_array(x), DeviceBuffer.from_array(th)
+        W = (T + 63) // 64
+        d_b = DeviceBuffer(8 * W * C)
+        try:
+            h.exceed_bits(d_x.ptr, 4, T, C, C, d_th.ptr, C, T, rows, neg, d_b.ptr, C)
+            words = d_b.to_array((W, C), np.uint64)
+        finally:
+            for b in (d_x, d_th, d_b):
+                b.free()
+        got = np.zeros((T, C), dtype=bool)
+        for t in range(T):
+            got[t] = (words[t // 64] >> np.uint64(t % 64)) & np.uint64(1)
+        npt.assert_array_equal(got, w)
+        # bits beyond T are zero
+        assert not np.any(words[-1] >> np.uint64(T % 64)) if T % 64 else True

@@ -56,6 +56,31 @@ for i in range(steps + 1):
     if i:
         ms_count.append(t_c); ms_stats.append(h.event_elapsed_ms(e0, e1))
 ms_stats, ms_count = float(np.mean(ms_stats)), float(np.mean(ms_count))
+# ---- table-only pipeline: exceedance bits -> run walk (count, fill) -> one thread per event -----
+W = (T + 63) // 64
+bits = DeviceBuffer(8 * W * C)
+nev2 = DeviceBuffer(4 * C)
+table2 = DeviceBuffer(8 * max(ntot, 1) * h.EVENT_COLUMNS)
+evs = [h.event_create() for _ in range(5)]
+t_bits, t_count, t_fill, t_sparse = [], [], [], []
+for i in range(steps + 1):
+    h.event_record(evs[0], 0)
+    h.exceed_bits(ts.ptr, 4, T, C, C, th.ptr, C, D, rows, 0, bits.ptr, C)
+    h.event_record(evs[1], 0)
+    h.events_from_bits(bits.ptr, T, C, C, 5, 1, 2, 0, nev2.ptr, 0)
+    h.event_record(evs[2], 0)
+    h.events_from_bits(bits.ptr, T, C, C, 5, 1, 2, d_off.ptr, 0, table2.ptr)
+    h.event_record(evs[3], 0)
+    h.event_stats_sparse(ts.ptr, 4, T, C, C, se.ptr, th.ptr, C, rows, 0, ntot, table2.ptr)
+    h.event_record(evs[4], 0)
+    h.stream_sync(0)
+    if i:
+        t_bits.append(h.event_elapsed_ms(evs[0], evs[1])); t_count.append(h.event_elapsed_ms(evs[1], evs[2]))
+        t_fill.append(h.event_elapsed_ms(evs[2], evs[3])); t_sparse.append(h.event_elapsed_ms(evs[3], evs[4]))
+t_bits, t_count, t_fill, t_sparse = (float(np.mean(v)) for v in (t_bits, t_count, t_fill, t_sparse))
+same_counts = bool(np.array_equal(nev2.to_array((C,), np.int32), counts))
+same_table = bool(np.array_equal(table2.to_array((ntot, h.EVENT_COLUMNS), np.float64),
+                                 table.to_array((ntot, h.EVENT_COLUMNS), np.float64), equal_nan=True))
 stats_bytes_cell = T * (4 + 4) + 2 * D * 8           # ts + labels read once, seas/thresh rows once
 bytes_cell = T * (4 + 13) + D * 8
 # parity + CPU baseline on a sample
@@ -81,6 +106,15 @@ res["event_stats"] = {"events": ntot, "events_per_cell": ntot / C, "ms_per_launc
                       "roofline": {"bound": "hbm", "achieved": C * stats_bytes_cell / (ms_stats * 1e-3) / 1e9,
                                    "peak": 8000.0, "unit": "GB/s", "frac": C * stats_bytes_cell / (ms_stats * 1e-3) / 8e12,
                                    "algorithmic_bytes_per_cell": stats_bytes_cell}}
+tot = t_bits + t_count + t_fill + t_sparse
+tb_bytes = T * 4 + 2 * D * 8 + (ntot / C) * h.EVENT_COLUMNS * 8      # series + climatologies once, table out
+res["table_only_pipeline"] = {
+    "ms": {"exceed_bits": t_bits, "events_from_bits_count": t_count, "events_from_bits_fill": t_fill,
+           "event_stats_sparse": t_sparse, "total": tot},
+    "per_step_kernels_total_ms": ms + ms_stats, "cells_per_s": C / (tot * 1e-3),
+    "identical_to_per_step_kernels": same_counts and same_table,
+    "roofline": {"bound": "hbm", "achieved": C * tb_bytes / (tot * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                 "frac": C * tb_bytes / (tot * 1e-3) / 8e12, "algorithmic_bytes_per_cell": tb_bytes}}
 if x is not None:
     thh = sample(th, 8, D, np.float64)
     evh = sample(ev, 4, T, np.float32).view(np.int32)

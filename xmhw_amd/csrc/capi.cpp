@@ -248,6 +248,66 @@ int event_stats(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* se
     return XMHW_OK;
 }
 
+// row_of_t on the device for the duration of one call
+struct DeviceRows {
+    int32_t* ptr = nullptr;
+    hipError_t err = hipSuccess;
+    DeviceRows(const int32_t* host, int64_t Tn, hipStream_t st) {
+        err = hipMalloc(&ptr, sizeof(int32_t) * static_cast<size_t>(Tn));
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(ptr, host, sizeof(int32_t) * static_cast<size_t>(Tn), hipMemcpyHostToDevice, st);
+    }
+    ~DeviceRows() { if (ptr) (void)hipFree(ptr); }
+};
+
+template <typename T>
+int exceed_bits(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* thresh, int64_t ldt, int64_t D,
+                const int32_t* row_of_t, int32_t negate, uint64_t* bits, int64_t ldb, void* stream) {
+    if (Tn <= 0 || C < 0 || ld < C || ldt < C || ldb < C || D <= 0) return fail(XMHW_ERR_INVALID, "bad T/C/ld/ldt/ldb/D");
+    if (C == 0) return XMHW_OK;
+    if (!ts || !thresh || !row_of_t || !bits) return fail(XMHW_ERR_INVALID, "NULL buffer");
+    for (int64_t t = 0; t < Tn; ++t)
+        if (row_of_t[t] < 0 || row_of_t[t] >= D) return fail(XMHW_ERR_INVALID, "row_of_t outside [0, D)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DeviceRows rows(row_of_t, Tn, st);
+    if (rows.err != hipSuccess) return hip_fail(rows.err, "row_of_t upload");
+    hipError_t e;
+    float* thf = nullptr;
+    if constexpr (sizeof(T) == 4) {
+        // float32 series: compare against the float32 floor of the thresholds (same results, see
+        // kernels_events.hip), 4 instead of 8 bytes re-read per step
+        HIP_TRY(hipMalloc(&thf, sizeof(float) * static_cast<size_t>(D) * static_cast<size_t>(ldt)));
+        e = xmhw::launch_floor_to_f32(thresh, D * ldt, thf, st);
+        if (e == hipSuccess)
+            e = xmhw::launch_exceed_bits<float, float>(ts, Tn, C, ld, thf, ldt, rows.ptr, negate, bits, ldb, st);
+    } else {
+        e = xmhw::launch_exceed_bits<double, double>(ts, Tn, C, ld, thresh, ldt, rows.ptr, negate, bits, ldb, st);
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    if (thf) (void)hipFree(thf);
+    if (e != hipSuccess) return hip_fail(e, "exceed_bits launch");
+    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
+    return XMHW_OK;
+}
+
+template <typename T>
+int event_stats_sparse(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* seas, const double* thresh,
+                       int64_t ldc, const int32_t* row_of_t, int32_t negate, int64_t n_events, double* table,
+                       void* stream) {
+    if (Tn <= 0 || C < 0 || ld < C || ldc < C || n_events < 0) return fail(XMHW_ERR_INVALID, "bad T/C/ld/ldc/n_events");
+    if (n_events == 0) return XMHW_OK;
+    if (!ts || !seas || !thresh || !row_of_t || !table) return fail(XMHW_ERR_INVALID, "NULL buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DeviceRows rows(row_of_t, Tn, st);
+    if (rows.err != hipSuccess) return hip_fail(rows.err, "row_of_t upload");
+    hipError_t e = xmhw::launch_event_stats_sparse<T>(ts, Tn, ld, seas, thresh, ldc, rows.ptr, negate, n_events,
+                                                      table, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hip_fail(e, "event_stats_sparse launch");
+    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
+    return XMHW_OK;
+}
+
 template <typename T>
 int event_intermediate(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* seas, const double* thresh,
                        int64_t ldc, const int32_t* row_of_t, int32_t negate, const int32_t* events, int64_t ldo,
@@ -594,6 +654,38 @@ int xmhw_event_stats_f32(const float* ts, int64_t T, int64_t C, int64_t ld, cons
                          const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,
                          const int32_t* events, int64_t ldo, const int64_t* offsets, double* table, void* stream) {
     return event_stats<float>(ts, T, C, ld, seas, thresh, ldc, row_of_t, negate, events, ldo, offsets, table, stream);
+}
+int xmhw_exceed_bits_f32(const float* ts, int64_t T, int64_t C, int64_t ld, const double* thresh, int64_t ldt,
+                         int64_t D, const int32_t* row_of_t, int32_t negate, uint64_t* bits, int64_t ldb,
+                         void* stream) {
+    return exceed_bits<float>(ts, T, C, ld, thresh, ldt, D, row_of_t, negate, bits, ldb, stream);
+}
+int xmhw_exceed_bits_f64(const double* ts, int64_t T, int64_t C, int64_t ld, const double* thresh, int64_t ldt,
+                         int64_t D, const int32_t* row_of_t, int32_t negate, uint64_t* bits, int64_t ldb,
+                         void* stream) {
+    return exceed_bits<double>(ts, T, C, ld, thresh, ldt, D, row_of_t, negate, bits, ldb, stream);
+}
+int xmhw_events_from_bits(const uint64_t* bits, int64_t T, int64_t C, int64_t ldb, int32_t min_duration,
+                          int32_t join_gaps, int32_t max_gap, const int64_t* offsets, int32_t* nevents,
+                          double* table, void* stream) {
+    if (T <= 0 || C < 0 || ldb < C) return fail(XMHW_ERR_INVALID, "bad T/C/ldb");
+    if (C == 0) return XMHW_OK;
+    if (!bits || (!offsets && !nevents) || (offsets && !table)) return fail(XMHW_ERR_INVALID, "NULL buffer");
+    if (min_duration < 1 || max_gap < 0) return fail(XMHW_ERR_INVALID, "bad minDuration/maxGap");
+    hipError_t e = xmhw::launch_events_from_bits(bits, T, C, ldb, min_duration, join_gaps, max_gap, offsets,
+                                                 nevents, table, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "events_from_bits launch");
+    return XMHW_OK;
+}
+int xmhw_event_stats_sparse_f32(const float* ts, int64_t T, int64_t C, int64_t ld, const double* seas,
+                                const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,
+                                int64_t n_events, double* table, void* stream) {
+    return event_stats_sparse<float>(ts, T, C, ld, seas, thresh, ldc, row_of_t, negate, n_events, table, stream);
+}
+int xmhw_event_stats_sparse_f64(const double* ts, int64_t T, int64_t C, int64_t ld, const double* seas,
+                                const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,
+                                int64_t n_events, double* table, void* stream) {
+    return event_stats_sparse<double>(ts, T, C, ld, seas, thresh, ldc, row_of_t, negate, n_events, table, stream);
 }
 int xmhw_event_intermediate_f32(const float* ts, int64_t T, int64_t C, int64_t ld, const double* seas,
                                 const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,

@@ -64,6 +64,20 @@ hipError_t launch_event_stats(const T* ts, int64_t Tn, int64_t C, int64_t ld, co
                               const int32_t* events, int64_t ldo, const int64_t* offsets, double* table,
                               hipStream_t stream);
 
+// table-only define_events() (kernels_events.hip): exceedance bits, run walk, per-event statistics
+hipError_t launch_floor_to_f32(const double* th, int64_t n, float* out, hipStream_t stream);
+template <typename T, typename TH>
+hipError_t launch_exceed_bits(const T* ts, int64_t Tn, int64_t C, int64_t ld, const TH* thresh, int64_t ldt,
+                              const int32_t* row_of_t, int32_t negate, uint64_t* bits, int64_t ldb,
+                              hipStream_t stream);
+hipError_t launch_events_from_bits(const uint64_t* bits, int64_t Tn, int64_t C, int64_t ldb, int32_t min_duration,
+                                   int32_t join_gaps, int32_t max_gap, const int64_t* offsets, int32_t* nevents,
+                                   double* table, hipStream_t stream);
+template <typename T>
+hipError_t launch_event_stats_sparse(const T* ts, int64_t Tn, int64_t ld, const double* seas, const double* thresh,
+                                     int64_t ldc, const int32_t* row_of_t, int32_t negate, int64_t n_events,
+                                     double* table, hipStream_t stream);
+
 // per-step columns of mhw_df(): out [8][T][ldv] f64, dur [4][T][ldv] u8
 template <typename T>
 hipError_t launch_event_intermediate(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* seas,

@@ -255,6 +255,47 @@ PYBIND11_MODULE(_xmhw_hip, m) {
        py::arg("ldc"), py::arg("row_of_t"), py::arg("negate"), py::arg("events"), py::arg("ldo"), py::arg("offsets"),
        py::arg("table"), py::arg("stream") = 0);
 
+    m.def("exceed_bits", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, uintptr_t thresh, int64_t ldt,
+                            int64_t D, i32arr row_of_t, int negate, uintptr_t bits, int64_t ldb, uintptr_t stream) {
+        if (row_of_t.size() != T) throw InvalidError("row_of_t length must equal T");
+        py::gil_scoped_release r;
+        int rc = -1;
+        if (itemsize == 4)
+            rc = xmhw_exceed_bits_f32(static_cast<const float*>(vp(ts)), T, C, ld, static_cast<const double*>(vp(thresh)), ldt,
+                                      D, row_of_t.data(), negate, static_cast<uint64_t*>(vp(bits)), ldb, vp(stream));
+        else if (itemsize == 8)
+            rc = xmhw_exceed_bits_f64(static_cast<const double*>(vp(ts)), T, C, ld, static_cast<const double*>(vp(thresh)), ldt,
+                                      D, row_of_t.data(), negate, static_cast<uint64_t*>(vp(bits)), ldb, vp(stream));
+        if (rc == -1) throw InvalidError("itemsize must be 4 or 8");
+        check(rc);
+    }, py::arg("ts"), py::arg("itemsize"), py::arg("T"), py::arg("C"), py::arg("ld"), py::arg("thresh"), py::arg("ldt"),
+       py::arg("D"), py::arg("row_of_t"), py::arg("negate"), py::arg("bits"), py::arg("ldb"), py::arg("stream") = 0);
+    m.def("events_from_bits", [](uintptr_t bits, int64_t T, int64_t C, int64_t ldb, int min_duration, int join_gaps,
+                                 int max_gap, uintptr_t offsets, uintptr_t nevents, uintptr_t table, uintptr_t stream) {
+        check(xmhw_events_from_bits(static_cast<const uint64_t*>(vp(bits)), T, C, ldb, min_duration, join_gaps, max_gap,
+                                    static_cast<const int64_t*>(vp(offsets)), static_cast<int32_t*>(vp(nevents)),
+                                    static_cast<double*>(vp(table)), vp(stream)));
+    }, py::arg("bits"), py::arg("T"), py::arg("C"), py::arg("ldb"), py::arg("min_duration"), py::arg("join_gaps"),
+       py::arg("max_gap"), py::arg("offsets") = 0, py::arg("nevents") = 0, py::arg("table") = 0, py::arg("stream") = 0);
+    m.def("event_stats_sparse", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, uintptr_t seas,
+                                   uintptr_t thresh, int64_t ldc, i32arr row_of_t, int negate, int64_t n_events,
+                                   uintptr_t table, uintptr_t stream) {
+        if (row_of_t.size() != T) throw InvalidError("row_of_t length must equal T");
+        py::gil_scoped_release r;
+        int rc = -1;
+        if (itemsize == 4)
+            rc = xmhw_event_stats_sparse_f32(static_cast<const float*>(vp(ts)), T, C, ld, static_cast<const double*>(vp(seas)),
+                                             static_cast<const double*>(vp(thresh)), ldc, row_of_t.data(), negate, n_events,
+                                             static_cast<double*>(vp(table)), vp(stream));
+        else if (itemsize == 8)
+            rc = xmhw_event_stats_sparse_f64(static_cast<const double*>(vp(ts)), T, C, ld, static_cast<const double*>(vp(seas)),
+                                             static_cast<const double*>(vp(thresh)), ldc, row_of_t.data(), negate, n_events,
+                                             static_cast<double*>(vp(table)), vp(stream));
+        if (rc == -1) throw InvalidError("itemsize must be 4 or 8");
+        check(rc);
+    }, py::arg("ts"), py::arg("itemsize"), py::arg("T"), py::arg("C"), py::arg("ld"), py::arg("seas"), py::arg("thresh"),
+       py::arg("ldc"), py::arg("row_of_t"), py::arg("negate"), py::arg("n_events"), py::arg("table"), py::arg("stream") = 0);
+
     m.def("event_intermediate", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, uintptr_t seas,
                                    uintptr_t thresh, int64_t ldc, i32arr row_of_t, int negate, uintptr_t events,
                                    int64_t ldo, uintptr_t out, int64_t ldv, uintptr_t dur, uintptr_t stream) {

@@ -107,8 +107,42 @@ def _check_inputs(ts, seas, thresh, doy, doys):
     return ts, seas, thresh, rows.astype(np.int32)
 
 
+def _table_only_batch(h, ts, seas, thresh, rows, T, n, isz, neg, minDuration, joinGaps, maxGap):
+    """Event table of one batch of cells without per-step outputs: exceedance bits -> run walk
+    (count, host prefix sum, fill) -> one thread per event (csrc/kernels_events.hip)."""
+    bufs = []
+    try:
+        d_ts = DeviceBuffer.from_array(ts); bufs.append(d_ts)
+        d_th = DeviceBuffer.from_array(thresh); bufs.append(d_th)
+        d_se = DeviceBuffer.from_array(seas); bufs.append(d_se)
+        W = (T + 63) // 64
+        d_bits = DeviceBuffer(8 * W * n); bufs.append(d_bits)
+        d_n = DeviceBuffer(4 * n); bufs.append(d_n)
+        try:
+            h.exceed_bits(d_ts.ptr, isz, T, n, n, d_th.ptr, n, thresh.shape[0], rows, neg, d_bits.ptr, n)
+            h.events_from_bits(d_bits.ptr, T, n, n, int(minDuration), int(bool(joinGaps)), int(maxGap), 0, d_n.ptr, 0)
+        except h.InvalidArgument as e:
+            raise XmhwException(str(e)) from e
+        h.stream_sync(0)
+        counts = d_n.to_array((n,), np.int32)
+        offs = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(counts, out=offs[1:])
+        ntot = int(offs[-1])
+        if ntot == 0:
+            return np.zeros((0, h.EVENT_COLUMNS)), counts
+        d_off = DeviceBuffer.from_array(offs); bufs.append(d_off)
+        d_tab = DeviceBuffer(8 * ntot * h.EVENT_COLUMNS); bufs.append(d_tab)
+        h.events_from_bits(d_bits.ptr, T, n, n, int(minDuration), int(bool(joinGaps)), int(maxGap), d_off.ptr, 0,
+                           d_tab.ptr)
+        h.event_stats_sparse(d_ts.ptr, isz, T, n, n, d_se.ptr, d_th.ptr, n, rows, neg, ntot, d_tab.ptr)
+        return d_tab.to_array((ntot, h.EVENT_COLUMNS), np.float64), counts
+    finally:
+        for b in bufs:
+            b.free()
+
+
 def detect_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
-                 intermediate=False, max_batch_bytes=64 << 30):
+                 intermediate=False, max_batch_bytes=64 << 30, per_step_kernels=False):
     """define_events() (xmhw/identify.py:329-412) for all cells of a dense (T, C) series on the
     GPU: th.sel(doy=ts.doy) + exceedance + mhw_filter() + mhw_df() + mhw_features()
     (xmhw/features.py:22-315), without the xarray/pandas packaging.
@@ -121,6 +155,9 @@ def detect_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxG
     positions; offsets (C+1,): events of cell c are table[offsets[c]:offsets[c+1]] in time
     order; inter: None or dict of (T, C) arrays with the per-step columns of mhw_df()).
     Cells are processed in batches so that the device working set stays below max_batch_bytes.
+    Without `intermediate` no per-step array is produced on the device either (bit-packed
+    exceedances, one thread per event); per_step_kernels=True forces the per-step kernels
+    (detect_events + event_stats) that `intermediate` needs — both give the same table.
     """
     ts, seas, thresh, rows = _check_inputs(ts, seas, thresh, doy, doys)
     T, C = ts.shape
@@ -139,6 +176,13 @@ def detect_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxG
     for c0 in range(0, C, batch):
         c1 = min(C, c0 + batch)
         n = c1 - c0
+        if not intermediate and not per_step_kernels:
+            tab, counts = _table_only_batch(h, np.ascontiguousarray(ts[:, c0:c1]), np.ascontiguousarray(seas[:, c0:c1]),
+                                            np.ascontiguousarray(thresh[:, c0:c1]), rows, T, n, isz, neg,
+                                            minDuration, joinGaps, maxGap)
+            tables.append(tab)
+            counts_all.append(counts)
+            continue
         bufs = []
         try:
             d_ts = DeviceBuffer.from_array(np.ascontiguousarray(ts[:, c0:c1])); bufs.append(d_ts)
