@@ -130,24 +130,37 @@ __global__ __launch_bounds__(256) void events_from_bits(const uint64_t* __restri
     }
     bool in_run = false;
     int64_t s = 0;
+    // Morphological opening by min_duration before the walk: runs shorter than min_duration can
+    // never qualify (identify.py:445-449), and white-noise exceedances are mostly such runs.
+    // eroded[t] = AND_{j<m} x[t+j] (needs the next word), opened[t] = OR_{j<m} eroded[t-j] (needs the
+    // previous eroded word): every run of >= m ones survives unchanged, every shorter run vanishes.
+    const int m = min_duration <= 64 ? min_duration : 1;
     constexpr int U = 4;
+    uint64_t cur = bits[c];
+    uint64_t er_prev = 0;
     for (int64_t w0 = 0; w0 < W; w0 += U) {
-        uint64_t ws[U];
+        uint64_t ws[U + 1];
+        ws[0] = cur;
 #pragma unroll
-        for (int u = 0; u < U; ++u) ws[u] = w0 + u < W ? bits[(w0 + u) * ldb + c] : 0;
+        for (int u = 1; u <= U; ++u) ws[u] = w0 + u < W ? bits[(w0 + u) * ldb + c] : 0;
+        cur = ws[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (w0 + u >= W) break;
             const int64_t base = (w0 + u) * 64;
-            uint64_t x = ws[u];
+            uint64_t er = ws[u];
+            for (int j = 1; j < m; ++j) er &= (ws[u] >> j) | (ws[u + 1] << (64 - j));
+            uint64_t x = er;
+            for (int j = 1; j < m; ++j) x |= (er << j) | (er_prev >> (64 - j));
+            er_prev = er;
             int pos = 0;
             while (pos < 64) {
                 const uint64_t rest = x >> pos;
                 if (in_run) {
                     const uint64_t z = ~rest;                       // zeros of the remaining bits
-                    const int k = __builtin_ctzll(z | (1ull << 63));   // ones from pos (63: sentinel)
-                    const bool ended = (z != 0) && pos + k < 64 && ((rest >> k) & 1ull) == 0;
-                    if (!ended) break;                              // the run continues into the next word
+                    if (z == 0) break;                              // pos == 0, all ones: continues
+                    const int k = __builtin_ctzll(z);               // ones from pos on
+                    if (pos + k >= 64) break;                       // the run continues into the next word
                     ew.run(s, base + pos + k - 1, min_duration, join_gaps, max_gap);
                     in_run = false;
                     pos += k;
