@@ -220,6 +220,10 @@ int xmhw_event_stats_f64(const double *ts_dev, int64_t T, int64_t C, int64_t ld,
  *  3. xmhw_event_stats_sparse_*: mhw_df() + mhw_features() (xmhw/features.py:22-315) for the
  *     n_events rows prepared by stage 2, one thread per event; fills all 31 columns.
  * Same results as xmhw_detect_events_* + xmhw_event_stats_*.                              */
+/* Kernel choice of xmhw_exceed_bits_* (process-wide; tests and measurements): 0 = automatic
+ * (tiled kernel - thresholds read once per cell - for calendar-like labels on >= 131072 cells,
+ * otherwise the per-step kernel), 1 = per-step kernel, 2 = tiled kernel.                     */
+int xmhw_set_exceed_kernel(int32_t mode);
 int xmhw_exceed_bits_f32(const float *ts_dev, int64_t T, int64_t C, int64_t ld,
                          const double *thresh_dev, int64_t ldt, int64_t D,
                          const int32_t *row_of_t_host, int32_t negate, uint64_t *bits_dev,

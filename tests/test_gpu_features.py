@@ -95,13 +95,20 @@ def test_table_only_path_equals_per_step_path(front, T, params):
     doys = np.arange(1, min(T, 366) + 1)
     se = rng.normal(size=(doys.shape[0], C)) * 0.1
     th = se + 0.8 + 0.1 * rng.random((doys.shape[0], C))
-    for dtype in (np.float32, np.float64):
-        for cold in (False, True):
-            a = front.detect_cells(x.astype(dtype), se, th, doy, doys, m, jg, gap, coldSpells=cold)
-            b = front.detect_cells(x.astype(dtype), se, th, doy, doys, m, jg, gap, coldSpells=cold,
-                                   per_step_kernels=True)
-            npt.assert_array_equal(a["offsets"], b["offsets"])
-            npt.assert_array_equal(a["table"], b["table"])
+    from xmhw_amd._lib import hip
+    h = hip()
+    try:
+        for dtype in (np.float32, np.float64):
+            for cold in (False, True):
+                b = front.detect_cells(x.astype(dtype), se, th, doy, doys, m, jg, gap, coldSpells=cold,
+                                       per_step_kernels=True)
+                for mode in (1, 2):                  # exceedance bits: per-step kernel, tiled kernel
+                    h.set_exceed_kernel(mode)
+                    a = front.detect_cells(x.astype(dtype), se, th, doy, doys, m, jg, gap, coldSpells=cold)
+                    npt.assert_array_equal(a["offsets"], b["offsets"])
+                    npt.assert_array_equal(a["table"], b["table"])
+    finally:
+        h.set_exceed_kernel(0)
 
 
 def test_exceed_bits_float32_floor_is_exact(front):
@@ -129,17 +136,18 @@ def test_exceed_bits_float32_floor_is_exact(front):
     rows = np.arange(T, dtype=np.int32)                                # one threshold row per step
     with np.errstate(invalid="ignore"):
         want = xd > th
-    for neg in (0, 1):
-        w = (-xd > th) if neg else want
+    for neg, mode in ((0, 1), (1, 1), (0, 2), (1, 2)):
         with np.errstate(invalid="ignore"):
             w = (-xd > th) if neg else (xd > th)
         d_x, d_th = DeviceBuffer.from_array(x), DeviceBuffer.from_array(th)
         W = (T + 63) // 64
         d_b = DeviceBuffer(8 * W * C)
         try:
+            h.set_exceed_kernel(mode)
             h.exceed_bits(d_x.ptr, 4, T, C, C, d_th.ptr, C, T, rows, neg, d_b.ptr, C)
             words = d_b.to_array((W, C), np.uint64)
         finally:
+            h.set_exceed_kernel(0)
             for b in (d_x, d_th, d_b):
                 b.free()
         got = np.zeros((T, C), dtype=bool)
@@ -148,3 +156,43 @@ def test_exceed_bits_float32_floor_is_exact(front):
         npt.assert_array_equal(got, w)
         # bits beyond T are zero
         assert not np.any(words[-1] >> np.uint64(T % 64)) if T % 64 else True
+
+
+def test_tiled_exceedance_on_calendar_and_irregular_labels(front):
+    """exceed_bits_tiled with real calendar labels (leap days split the chunks), with a label
+    sequence that jumps around (every step its own chunk), and with a leading dimension != C."""
+    import xmhw_oracle as ora
+    from xmhw_amd._lib import hip
+    from xmhw_amd.device import DeviceBuffer
+    h = hip()
+    rng = np.random.default_rng(5)
+    time = np.arange("1999-11-20", "2005-03-07", dtype="datetime64[D]")
+    cal = ora.add_doy(time) - 1
+    T, C, ld = time.shape[0], 130, 137
+    for rows, D in ((cal, 366), (rng.integers(0, 50, size=T), 50), ((np.arange(T) * 7) % 366, 366)):
+        for dtype in (np.float32, np.float64):
+            x = np.full((T, ld), np.nan, dtype=dtype)
+            x[:, :C] = rng.normal(size=(T, C))
+            th = rng.normal(size=(D, ld)) * 0.5 + 0.5
+            want = x[:, :C].astype(np.float64) > th[rows][:, :C]
+            d_x, d_th = DeviceBuffer.from_array(x), DeviceBuffer.from_array(th)
+            W = (T + 63) // 64
+            got = {}
+            try:
+                for mode in (1, 2):
+                    d_b = DeviceBuffer.from_array(np.full((W, ld), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64))
+                    h.set_exceed_kernel(mode)
+                    h.exceed_bits(d_x.ptr, x.dtype.itemsize, T, C, ld, d_th.ptr, ld, D, rows.astype(np.int32), 0,
+                                  d_b.ptr, ld)
+                    got[mode] = d_b.to_array((W, ld), np.uint64)
+                    d_b.free()
+            finally:
+                h.set_exceed_kernel(0)
+                d_x.free(); d_th.free()
+            for mode, words in got.items():
+                bits = np.zeros((T, C), dtype=bool)
+                for t in range(T):
+                    bits[t] = (words[t // 64, :C] >> np.uint64(t % 64)) & np.uint64(1)
+                npt.assert_array_equal(bits, want, err_msg=f"mode {mode}")
+                # columns beyond C are left alone
+                assert (words[:, C:] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()

@@ -260,34 +260,119 @@ struct DeviceRows {
     ~DeviceRows() { if (ptr) (void)hipFree(ptr); }
 };
 
+static int g_exceed_kernel = 0;   // 0 auto, 1 per-step kernel, 2 tiled kernel (xmhw_set_exceed_kernel)
+
+// Chunks for exceed_bits_tiled: maximal segments of consecutive steps with consecutive rows inside one
+// tile of `tile` rows, grouped by tile (time order kept inside a tile).
+struct ExceedChunks {
+    std::vector<int32_t> tile_begin, t0, i0, n;
+    int32_t ntiles = 0;
+    ExceedChunks(const int32_t* row_of_t, int64_t Tn, int64_t D, int tile) {
+        ntiles = static_cast<int32_t>((D + tile - 1) / tile);
+        std::vector<std::vector<int32_t>> per(ntiles);          // chunk start steps per tile
+        std::vector<int32_t> len;                                 // by start step (sparse via map below)
+        std::vector<int32_t> start, count;
+        for (int64_t t = 0; t < Tn;) {
+            const int32_t r = row_of_t[t];
+            const int32_t k = r / tile;
+            int64_t e = t + 1;
+            while (e < Tn && row_of_t[e] == row_of_t[e - 1] + 1 && row_of_t[e] / tile == k) ++e;
+            per[k].push_back(static_cast<int32_t>(start.size()));
+            start.push_back(static_cast<int32_t>(t));
+            count.push_back(static_cast<int32_t>(e - t));
+            t = e;
+        }
+        tile_begin.assign(ntiles + 1, 0);
+        for (int32_t k = 0; k < ntiles; ++k) {
+            tile_begin[k + 1] = tile_begin[k] + static_cast<int32_t>(per[k].size());
+            for (int32_t id : per[k]) {
+                t0.push_back(start[id]);
+                i0.push_back(row_of_t[start[id]] - k * tile);
+                n.push_back(count[id]);
+            }
+        }
+    }
+};
+
+struct DeviceI32 {
+    int32_t* ptr = nullptr;
+    hipError_t err = hipSuccess;
+    DeviceI32(const std::vector<int32_t>& v, hipStream_t st) {
+        const size_t bytes = sizeof(int32_t) * (v.empty() ? 1 : v.size());
+        err = hipMalloc(&ptr, bytes);
+        if (err == hipSuccess && !v.empty())
+            err = hipMemcpyAsync(ptr, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice, st);
+    }
+    ~DeviceI32() { if (ptr) (void)hipFree(ptr); }
+};
+
 template <typename T>
 int exceed_bits(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* thresh, int64_t ldt, int64_t D,
                 const int32_t* row_of_t, int32_t negate, uint64_t* bits, int64_t ldb, void* stream) {
     if (Tn <= 0 || C < 0 || ld < C || ldt < C || ldb < C || D <= 0) return fail(XMHW_ERR_INVALID, "bad T/C/ld/ldt/ldb/D");
+    if (Tn >= (int64_t{1} << 31)) return fail(XMHW_ERR_INVALID, "T too large");
     if (C == 0) return XMHW_OK;
     if (!ts || !thresh || !row_of_t || !bits) return fail(XMHW_ERR_INVALID, "NULL buffer");
     for (int64_t t = 0; t < Tn; ++t)
         if (row_of_t[t] < 0 || row_of_t[t] >= D) return fail(XMHW_ERR_INVALID, "row_of_t outside [0, D)");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    DeviceRows rows(row_of_t, Tn, st);
-    if (rows.err != hipSuccess) return hip_fail(rows.err, "row_of_t upload");
-    hipError_t e;
+    constexpr int kTile = sizeof(T) == 4 ? 64 : 32;
+    const ExceedChunks ch(row_of_t, Tn, D, kTile);
+    // The tiled kernel pays one pass over its unrolled tile per chunk: worth it when chunks are long
+    // (calendar-like labels); an arbitrary label sequence falls back to the per-step kernel.
+    // One thread walks all tiles of a cell, so small grids (too few workgroups to fill 256 CUs) keep the
+    // per-step kernel, which also splits the time axis over blocks.
+    const bool tiled = g_exceed_kernel == 2 ||
+                       (g_exceed_kernel == 0 && static_cast<int64_t>(ch.t0.size()) * kTile <= 4 * Tn && C >= 131072);
+    const int64_t W = (Tn + 63) / 64;
+    hipError_t e = hipSuccess;
     float* thf = nullptr;
     if constexpr (sizeof(T) == 4) {
         // float32 series: compare against the float32 floor of the thresholds (same results, see
-        // kernels_events.hip), 4 instead of 8 bytes re-read per step
+        // kernels_events.hip), 4 instead of 8 bytes per threshold
         HIP_TRY(hipMalloc(&thf, sizeof(float) * static_cast<size_t>(D) * static_cast<size_t>(ldt)));
         e = xmhw::launch_floor_to_f32(thresh, D * ldt, thf, st);
-        if (e == hipSuccess)
-            e = xmhw::launch_exceed_bits<float, float>(ts, Tn, C, ld, thf, ldt, rows.ptr, negate, bits, ldb, st);
-    } else {
-        e = xmhw::launch_exceed_bits<double, double>(ts, Tn, C, ld, thresh, ldt, rows.ptr, negate, bits, ldb, st);
     }
-    hipError_t e2 = hipStreamSynchronize(st);
+    if (e == hipSuccess && tiled) {
+        DeviceI32 d_tb(ch.tile_begin, st), d_t0(ch.t0, st), d_i0(ch.i0, st), d_n(ch.n, st);
+        for (const DeviceI32* d : {&d_tb, &d_t0, &d_i0, &d_n})
+            if (d->err != hipSuccess) e = d->err;
+        if (e == hipSuccess)
+            e = ldb == C ? hipMemsetAsync(bits, 0, sizeof(uint64_t) * static_cast<size_t>(W) * static_cast<size_t>(C), st)
+                         : hipMemset2DAsync(bits, sizeof(uint64_t) * static_cast<size_t>(ldb), 0,
+                                            sizeof(uint64_t) * static_cast<size_t>(C), static_cast<size_t>(W), st);
+        if (e == hipSuccess) {
+            if constexpr (sizeof(T) == 4)
+                e = xmhw::launch_exceed_bits_tiled<float, float, 64>(ts, C, ld, thf, ldt, D, d_tb.ptr, ch.ntiles,
+                                                                     d_t0.ptr, d_i0.ptr, d_n.ptr, negate, bits, ldb, st);
+            else
+                e = xmhw::launch_exceed_bits_tiled<double, double, 32>(ts, C, ld, thresh, ldt, D, d_tb.ptr, ch.ntiles,
+                                                                       d_t0.ptr, d_i0.ptr, d_n.ptr, negate, bits, ldb,
+                                                                       st);
+        }
+        hipError_t e2 = hipStreamSynchronize(st);
+        if (thf) (void)hipFree(thf);
+        if (e != hipSuccess) return hip_fail(e, "exceed_bits_tiled launch");
+        if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
+        return XMHW_OK;
+    }
+    if (e == hipSuccess) {
+        DeviceRows rows(row_of_t, Tn, st);
+        e = rows.err;
+        if (e == hipSuccess) {
+            if constexpr (sizeof(T) == 4)
+                e = xmhw::launch_exceed_bits<float, float>(ts, Tn, C, ld, thf, ldt, rows.ptr, negate, bits, ldb, st);
+            else
+                e = xmhw::launch_exceed_bits<double, double>(ts, Tn, C, ld, thresh, ldt, rows.ptr, negate, bits, ldb, st);
+        }
+        hipError_t e2 = hipStreamSynchronize(st);
+        if (thf) (void)hipFree(thf);
+        if (e != hipSuccess) return hip_fail(e, "exceed_bits launch");
+        if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
+        return XMHW_OK;
+    }
     if (thf) (void)hipFree(thf);
-    if (e != hipSuccess) return hip_fail(e, "exceed_bits launch");
-    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
-    return XMHW_OK;
+    return hip_fail(e, "exceed_bits setup");
 }
 
 template <typename T>
@@ -654,6 +739,11 @@ int xmhw_event_stats_f32(const float* ts, int64_t T, int64_t C, int64_t ld, cons
                          const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,
                          const int32_t* events, int64_t ldo, const int64_t* offsets, double* table, void* stream) {
     return event_stats<float>(ts, T, C, ld, seas, thresh, ldc, row_of_t, negate, events, ldo, offsets, table, stream);
+}
+int xmhw_set_exceed_kernel(int32_t mode) {
+    if (mode < 0 || mode > 2) return fail(XMHW_ERR_INVALID, "mode must be 0 (auto), 1 (per-step) or 2 (tiled)");
+    g_exceed_kernel = mode;
+    return XMHW_OK;
 }
 int xmhw_exceed_bits_f32(const float* ts, int64_t T, int64_t C, int64_t ld, const double* thresh, int64_t ldt,
                          int64_t D, const int32_t* row_of_t, int32_t negate, uint64_t* bits, int64_t ldb,

@@ -70,6 +70,11 @@ template <typename T, typename TH>
 hipError_t launch_exceed_bits(const T* ts, int64_t Tn, int64_t C, int64_t ld, const TH* thresh, int64_t ldt,
                               const int32_t* row_of_t, int32_t negate, uint64_t* bits, int64_t ldb,
                               hipStream_t stream);
+template <typename T, typename TH, int TILE>
+hipError_t launch_exceed_bits_tiled(const T* ts, int64_t C, int64_t ld, const TH* thresh, int64_t ldt, int64_t D,
+                                    const int32_t* tile_begin, int32_t ntiles, const int32_t* chunk_t0,
+                                    const int32_t* chunk_i0, const int32_t* chunk_n, int32_t negate, uint64_t* bits,
+                                    int64_t ldb, hipStream_t stream);
 hipError_t launch_events_from_bits(const uint64_t* bits, int64_t Tn, int64_t C, int64_t ldb, int32_t min_duration,
                                    int32_t join_gaps, int32_t max_gap, const int64_t* offsets, int32_t* nevents,
                                    double* table, hipStream_t stream);

@@ -71,6 +71,89 @@ __global__ __launch_bounds__(256) void exceed_bits(const T* __restrict__ ts, int
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// exceed_bits_tiled: the same bits with every threshold read ONCE per cell.  The host cuts the time
+// axis into chunks of consecutive steps whose climatology rows are consecutive and lie in one tile
+// of TILE rows (a calendar year gives one chunk per tile, two around a missing Feb 29) and groups
+// them by tile.  A thread keeps the TILE thresholds of its cell in registers (static indices: bit i
+// of the unrolled loop <-> row tile*TILE + i) and streams over the chunks of that tile - one visit
+// per year - so that the series is read once and the (D, C) thresholds once, instead of once per
+// step.  A chunk's bits are shifted to their place in the 64-step words and OR-ed in; only this
+// thread touches column c, the buffer is zeroed first.
+// ---------------------------------------------------------------------------
+template <typename T, typename TH, int TILE>
+__global__ __launch_bounds__(128) void exceed_bits_tiled(const T* __restrict__ ts, int64_t C, int64_t ld,
+                                                         const TH* __restrict__ thresh, int64_t ldt, int64_t D,
+                                                         const int32_t* __restrict__ tile_begin, int32_t ntiles,
+                                                         const int32_t* __restrict__ chunk_t0,
+                                                         const int32_t* __restrict__ chunk_i0,
+                                                         const int32_t* __restrict__ chunk_n, int32_t negate,
+                                                         uint64_t* __restrict__ bits, int64_t ldb) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    for (int32_t k = 0; k < ntiles; ++k) {
+        const int32_t cb = tile_begin[k], ce = tile_begin[k + 1];
+        if (cb == ce) continue;
+        TH thr[TILE];
+#pragma unroll
+        for (int i = 0; i < TILE; ++i) {
+            const int64_t r = static_cast<int64_t>(k) * TILE + i;
+            thr[i] = r < D ? thresh[r * ldt + c] : static_cast<TH>(0);
+        }
+        for (int32_t q = cb; q < ce; ++q) {
+            const int64_t t0 = chunk_t0[q];
+            const int i0 = chunk_i0[q], n = chunk_n[q];          // wave-uniform
+            uint64_t m = 0;
+            // loads are unconditional (index clamped into the chunk) so that a whole group is in
+            // flight before the first compare; positions outside the chunk are masked afterwards
+            constexpr int G = 32;
+#pragma unroll
+            for (int g = 0; g < TILE; g += G) {
+                T xs[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    int d = g + u - i0;
+                    d = d < 0 ? 0 : (d >= n ? n - 1 : d);
+                    xs[u] = ts[(t0 + d) * ld + c];
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int i = g + u;
+                    T x = xs[u];
+                    if (negate) x = -x;
+                    const bool in = i >= i0 && i < i0 + n;
+                    m |= static_cast<uint64_t>(in && static_cast<TH>(x) > thr[i]) << ((i - i0) & 63);
+                }
+            }
+            const int pos = static_cast<int>(t0 & 63);
+            const int64_t w = t0 >> 6;
+            bits[w * ldb + c] |= m << pos;
+            if (pos + n > 64) bits[(w + 1) * ldb + c] |= m >> (64 - pos);
+        }
+    }
+}
+
+template <typename T, typename TH, int TILE>
+hipError_t launch_exceed_bits_tiled(const T* ts, int64_t C, int64_t ld, const TH* thresh, int64_t ldt, int64_t D,
+                                    const int32_t* tile_begin, int32_t ntiles, const int32_t* chunk_t0,
+                                    const int32_t* chunk_i0, const int32_t* chunk_n, int32_t negate, uint64_t* bits,
+                                    int64_t ldb, hipStream_t stream) {
+    if (C <= 0 || ntiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL((exceed_bits_tiled<T, TH, TILE>), dim3(static_cast<unsigned>((C + 127) / 128)), dim3(128), 0,
+                       stream, ts, C, ld, thresh, ldt, D, tile_begin, ntiles, chunk_t0, chunk_i0, chunk_n, negate,
+                       bits, ldb);
+    return hipGetLastError();
+}
+template hipError_t launch_exceed_bits_tiled<float, float, 64>(const float*, int64_t, int64_t, const float*, int64_t,
+                                                               int64_t, const int32_t*, int32_t, const int32_t*,
+                                                               const int32_t*, const int32_t*, int32_t, uint64_t*,
+                                                               int64_t, hipStream_t);
+template hipError_t launch_exceed_bits_tiled<double, double, 32>(const double*, int64_t, int64_t, const double*,
+                                                                 int64_t, int64_t, const int32_t*, int32_t,
+                                                                 const int32_t*, const int32_t*, const int32_t*,
+                                                                 int32_t, uint64_t*, int64_t, hipStream_t);
+
 // ---------------------------------------------------------------------------
 // State of mhw_filter() + join_gaps() while walking the runs of one cell.
 // A qualified run [s, e] (length test of identify.py:445-449 with the fillna(0) quirk: a run that

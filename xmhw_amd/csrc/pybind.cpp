@@ -255,6 +255,7 @@ PYBIND11_MODULE(_xmhw_hip, m) {
        py::arg("ldc"), py::arg("row_of_t"), py::arg("negate"), py::arg("events"), py::arg("ldo"), py::arg("offsets"),
        py::arg("table"), py::arg("stream") = 0);
 
+    m.def("set_exceed_kernel", [](int mode) { check(xmhw_set_exceed_kernel(mode)); }, py::arg("mode"));
     m.def("exceed_bits", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, uintptr_t thresh, int64_t ldt,
                             int64_t D, i32arr row_of_t, int negate, uintptr_t bits, int64_t ldb, uintptr_t stream) {
         if (row_of_t.size() != T) throw InvalidError("row_of_t length must equal T");
