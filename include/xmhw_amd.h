@@ -77,6 +77,15 @@ int xmhw_plan_info(const xmhw_plan *plan, int32_t *D, int32_t *ntracks,
                    int32_t *kernel, int32_t *nsteps, int32_t *step_min);
 int xmhw_plan_doys(const xmhw_plan *plan, int32_t *doys_out /* [D] */);
 int xmhw_plan_set_kernel(xmhw_plan *plan, int32_t kernel);  /* tests / fallback */
+/* float64 input whose samples are all float32-representable (decoded int16 / float32 archives) is
+ * run through the float32 ring kernel (same pools, same float64 interpolation and sums of the same
+ * values; 2.7x the float64 kernel's rate).  The check happens on the device inside
+ * xmhw_clim_raw_f64 (sparse probe, then on every sample the kernel loads; the float64 kernel is
+ * queued behind and runs only if a sample failed), so the call stays asynchronous.  Enabled by
+ * default; xmhw_plan_narrowed() reports (synchronously) whether the last float64 call of this
+ * plan stayed on the float32 kernel.                                                         */
+int xmhw_plan_set_narrowing(xmhw_plan *plan, int32_t enable);
+int xmhw_plan_narrowed(xmhw_plan *plan, int32_t *narrowed_out);
 int xmhw_plan_set_chunks(xmhw_plan *plan, int32_t nchunks); /* 0 = auto         */
 /* host copy of the ring kernel's step table for inspection:
  * table[nsteps][ntracks_padded] (see csrc/plan.h for the encoding)            */

@@ -23,7 +23,9 @@ def _check(dev, x, doy, nchunks=0, rtol=1e-12, **kw):
     assert x.dtype == np.float64
     args = (kw.get("pctile", 90), kw.get("windowHalfWidth", 5), kw.get("smoothPercentile", True),
             kw.get("smoothPercentileWidth", 31), kw.get("tstep", False), kw.get("coldSpells", False))
-    d1, t1, s1 = dev.calc_clim_device(x, doy, *args, kernel="ring", nchunks=nchunks)
+    # narrowing off: the float64 ring kernel itself (quantised test data is float32-representable
+    # and would otherwise take the float32 kernel, which test_float64_narrowing covers)
+    d1, t1, s1 = dev.calc_clim_device(x, doy, *args, kernel="ring", nchunks=nchunks, narrowing=False)
     d0, t0, s0 = fast.threshold_cells_fast(x, doy, **kw)
     npt.assert_array_equal(d1, d0)
     npt.assert_array_equal(np.isnan(t1), np.isnan(t0))
@@ -92,7 +94,64 @@ def test_partial_years_and_extremes_f64(dev):
     npt.assert_allclose(t1[fin], t0[fin], rtol=1e-12)
     npt.assert_array_equal(t1[:, 4], t0[:, 4])
     npt.assert_array_equal(np.isfinite(t1), fin)
+    npt.assert_allclose(s1, s0, rtol=1e-12, equal_nan=True)     # means of pools holding +-inf, and the rows after
     # low percentile with -inf present: the inclusive extraction bound must admit -inf
     d1, t1, s1 = dev.calc_clim_device(x, doy, 0, 5, False, 31, True, kernel="ring")
     d0, t0, s0 = fast.threshold_cells_fast(x, doy, pctile=0, smoothPercentile=False, tstep=True)
     npt.assert_array_equal(t1[:, [0, 4]], t0[:, [0, 4]])
+
+
+def test_float64_narrowing(dev):
+    """float64 input holding float32-representable samples runs on the float32 ring kernel:
+    bit-identical to the float32 call; genuinely float64 data, and data with a single lossy sample
+    hidden from the probe, end on the float64 kernel with its exact result."""
+    from xmhw_amd.device import DeviceBuffer, Plan, clim_raw
+    from xmhw_amd._lib import hip
+    h = hip()
+    time, doy = _daily(1990, 2012)
+    T, C = time.shape[0], 77
+    x32 = _series(T, C, 21, 0.02, dtype=np.float32)
+    x32[:, 5] = np.nan
+    x32[100:140, 6] = np.inf
+    x64 = x32.astype(np.float64)
+    hidden = x64.copy()
+    hidden[1237, 41] = 12.345678901234567          # one sample that float32 cannot hold, off the probe rows
+    assert 1237 % max(T // 32, 1) != 0
+    rand = _series(T, C, 22, 0.02, dtype=np.float64)
+    D = 366
+
+    def run(arr, narrowing, q=0.9, neg=False):
+        plan = Plan(doy, 5, kernel="ring", narrowing=narrowing)
+        d_ts = DeviceBuffer.from_array(np.ascontiguousarray(arr))
+        th, se = DeviceBuffer(8 * D * C), DeviceBuffer(8 * D * C)
+        try:
+            clim_raw(plan, d_ts, arr.dtype.itemsize, C, q, neg, th, se)
+            h.stream_sync(0)
+            narrowed = plan.narrowed() if arr.dtype == np.float64 else None
+            return th.to_array((D, C), np.float64), se.to_array((D, C), np.float64), narrowed
+        finally:
+            for b in (d_ts, th, se):
+                b.free()
+            plan.destroy()
+
+    for neg in (False, True):
+        t32, s32, _ = run(x32, True, neg=neg)
+        tn, sn, narrowed = run(x64, True, neg=neg)
+        assert narrowed
+        npt.assert_array_equal(tn, t32)
+        npt.assert_array_equal(sn, s32)
+        t64, s64, narrowed = run(x64, False, neg=neg)      # the float64 kernel on the same values
+        assert not narrowed
+        npt.assert_array_equal(tn, t64)                     # exact selection + the same lerp
+        npt.assert_allclose(sn, s64, rtol=1e-13, equal_nan=True)
+    for arr in (hidden, rand):
+        ta, sa, narrowed = run(arr, True)
+        assert not narrowed
+        tb, sb, _ = run(arr, False)
+        npt.assert_array_equal(ta, tb)
+        npt.assert_array_equal(sa, sb)
+    # and through the host API, against the oracle
+    d1, t1, s1 = dev.calc_clim_device(x64, doy, 90, 5, True, 31, False)
+    d0, t0, s0 = fast.threshold_cells_fast(x64, doy)
+    npt.assert_allclose(t1, t0, rtol=1e-12, equal_nan=True)
+    npt.assert_allclose(s1, s0, rtol=1e-12, equal_nan=True)

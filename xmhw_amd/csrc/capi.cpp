@@ -50,9 +50,12 @@ struct xmhw_plan {
     int32_t* d_row_ptr = nullptr;
     int32_t* d_centres = nullptr;
     unsigned long long* d_stats = nullptr;  // debug: ring kernel pass counters (xmhw_plan_debug_stats)
+    uint32_t* d_narrow_flag = nullptr;      // float64 input: set when a sample is not float32-representable
+    bool narrowing = true;                  // xmhw_plan_set_narrowing
 
     ~xmhw_plan() {
         if (d_stats) (void)hipFree(d_stats);
+        if (d_narrow_flag) (void)hipFree(d_narrow_flag);
         if (d_table) (void)hipFree(d_table);
         if (d_table64) (void)hipFree(d_table64);
         if (d_chunks) (void)hipFree(d_chunks);
@@ -141,9 +144,24 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
                                       h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps, q,
                                       negate, thresh, seas, ldo, st, plan->d_stats);
         } else {
-            e = xmhw::launch_ring_f64(reinterpret_cast<const double*>(ts), C, ld, plan->d_table64,
-                                      h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps64, q,
-                                      negate, thresh, seas, ldo, st, plan->d_stats);
+            // float64 input: if every sample is float32-representable (decoded int16 / float32
+            // archives) the float32 kernel gives the same pools at 2.7x the rate.  All decisions are
+            // taken on the device so that the call stays asynchronous: probe -> narrowing float32
+            // kernel (stops at the first lossy sample) -> float64 kernel (runs only if flagged).
+            const uint32_t* run_flag = nullptr;
+            e = hipSuccess;
+            if (plan->narrowing && plan->yps) {
+                if (!plan->d_narrow_flag) HIP_TRY(hipMalloc(&plan->d_narrow_flag, sizeof(uint32_t)));
+                e = xmhw::launch_ring_f32_narrowing(reinterpret_cast<const double*>(ts), h.T, C, ld, plan->d_table,
+                                                    h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps, q,
+                                                    negate, thresh, seas, ldo, st, plan->d_stats,
+                                                    plan->d_narrow_flag);
+                run_flag = plan->d_narrow_flag;
+            }
+            if (e == hipSuccess)
+                e = xmhw::launch_ring_f64(reinterpret_cast<const double*>(ts), C, ld, plan->d_table64,
+                                          h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps64, q,
+                                          negate, thresh, seas, ldo, st, plan->d_stats, run_flag);
         }
     } else {
         e = xmhw::launch_generic<T>(ts, h.T, C, ld, plan->d_row_ptr, plan->d_centres, h.D, h.w, q,
@@ -584,6 +602,20 @@ int xmhw_plan_set_kernel(xmhw_plan* plan, int32_t kernel) {
     if (kernel < XMHW_KERNEL_AUTO || kernel > XMHW_KERNEL_GENERIC)
         return fail(XMHW_ERR_INVALID, "unknown kernel selector");
     plan->host.kernel_choice = kernel;
+    return XMHW_OK;
+}
+int xmhw_plan_set_narrowing(xmhw_plan* plan, int32_t enable) {
+    if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
+    plan->narrowing = enable != 0;
+    return XMHW_OK;
+}
+int xmhw_plan_narrowed(xmhw_plan* plan, int32_t* narrowed_out) {
+    if (!plan || !narrowed_out) return fail(XMHW_ERR_INVALID, "NULL argument");
+    *narrowed_out = 0;
+    if (!plan->d_narrow_flag) return XMHW_OK;
+    uint32_t flag = 1;
+    HIP_TRY(hipMemcpy(&flag, plan->d_narrow_flag, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *narrowed_out = flag == 0 ? 1 : 0;
     return XMHW_OK;
 }
 int xmhw_plan_set_chunks(xmhw_plan* plan, int32_t nchunks) {

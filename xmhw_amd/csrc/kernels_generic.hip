@@ -178,6 +178,12 @@ __global__ __launch_bounds__(256) void clim_finish(const double* __restrict__ th
             trail = (trail + 1 == D) ? 0 : trail + 1;
             lead = (lead + 1 == D) ? 0 : lead + 1;
             s += col.val(lead);
+            if (!(fabs(s) <= 1.7976931348623157e308)) {
+                // an infinite value went through the sliding sum (inf - inf = NaN): sum the window
+                // directly, which gives what numpy's mean gives (+-inf while it is inside, NaN for both signs)
+                s = 0.0;
+                for (int32_t i = 0, k = trail; i < width; ++i, k = (k + 1 == D) ? 0 : k + 1) s += col.val(k);
+            }
         }
         return;
     }
@@ -213,6 +219,10 @@ __global__ __launch_bounds__(256) void clim_finish(const double* __restrict__ th
         trail = next_present(trail);
         lead = next_present(lead);
         s += col.val(lead);
+        if (!(fabs(s) <= 1.7976931348623157e308)) {
+            s = 0.0;
+            for (int32_t i = 0, k = trail; i < width; ++i, k = next_present(k)) s += col.val(k);
+        }
         const int32_t nxt = next_present(cur);
         if (j + 1 < np)
             for (int32_t d = cur + 1; d < nxt; ++d) out[static_cast<int64_t>(d) * ld] = make_nan();
@@ -305,6 +315,10 @@ __global__ __launch_bounds__(256) void clim_finish_tiled(const double* __restric
             trail = (trail + 1 == D) ? 0 : trail + 1;
             lead = (lead + 1 == D) ? 0 : lead + 1;
             s += val(lead);
+            if (!(fabs(s) <= 1.7976931348623157e308)) {   // infinite value in the window: direct sum (see clim_finish)
+                s = 0.0;
+                for (int32_t i = 0, k = trail; i < width; ++i, k = (k + 1 == D) ? 0 : k + 1) s += val(k);
+            }
         }
         return;
     }
@@ -341,6 +355,10 @@ __global__ __launch_bounds__(256) void clim_finish_tiled(const double* __restric
         trail = next_present(trail);
         lead = next_present(lead);
         s += val(lead);
+        if (!(fabs(s) <= 1.7976931348623157e308)) {
+            s = 0.0;
+            for (int32_t i = 0, k = trail; i < width; ++i, k = next_present(k)) s += val(k);
+        }
         const int32_t nxt = next_present(cur);
         const int32_t stop = (j + 1 < np) ? nxt : D;
         for (int32_t d = cur + 1; d < stop; ++d) out[static_cast<int64_t>(d) * ld + c] = make_nan();

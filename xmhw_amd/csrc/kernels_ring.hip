@@ -157,12 +157,22 @@ struct TopJ {
 constexpr int kTopJ = 5;          // extraction width
 constexpr int kCountBudget = 6;   // count passes before the first extraction
 
-template <int W, int YPS>
+// TI = float, or double for float64 input whose values are all float32-representable (decoded
+// int16 / float32 archives promoted by the reader): the samples are narrowed on load and the kernel
+// runs at the float32 rate.  `narrow_flag` (TI = double only) is set as soon as a sample does not
+// survive the round trip; the kernel stops, later blocks do not start, and the float64 kernel
+// queued behind it (which runs only if the flag is set) recomputes everything.
+template <int W, int YPS, typename TI>
 __global__ __launch_bounds__(256) void clim_ring_f32(
-    const float* __restrict__ ts, int64_t C, int64_t ld, const uint32_t* __restrict__ table,
+    const TI* __restrict__ ts, int64_t C, int64_t ld, const uint32_t* __restrict__ table,
     int32_t step_min, const DevChunk* __restrict__ chunks, double q, int negate,
     double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
-    unsigned long long* __restrict__ stats) {
+    unsigned long long* __restrict__ stats, uint32_t* __restrict__ narrow_flag) {
+    constexpr bool kNarrow = sizeof(TI) == 8;
+    if constexpr (kNarrow) {
+        if (*narrow_flag != 0) return;
+    }
+    bool lossy = false;
     constexpr int R = 2 * W + 1;
     constexpr int NTP = kSubs * YPS;
     constexpr uint32_t NSLOT = static_cast<uint32_t>(NTP) * R;
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
     const bool cell_ok = cell < C;
     const DevChunk ch = chunks[blockIdx.y];
     const uint32_t* tab = table + sub * YPS;
-    const float* col = ts + (cell_ok ? cell : 0);
+    const TI* col = ts + (cell_ok ? cell : 0);
     const float fnan = __uint_as_float(0x7FC00000u);
 
     uint32_t ring[YPS][R];
@@ -196,18 +206,20 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
 #pragma unroll
         for (int y = 0; y < YPS; ++y) e[y] = p[y];
     };
-    auto load_samples = [&](const uint32_t (&e)[YPS], float (&x)[YPS]) {
+    // loads are issued one row ahead and only touched (narrowed, checked) when that row is
+    // processed, so that their latency stays hidden behind the selection of the current row
+    auto load_samples = [&](const uint32_t (&e)[YPS], TI (&x)[YPS]) {
 #pragma unroll
         for (int y = 0; y < YPS; ++y) {
             const uint32_t code = e[y] >> 1;
-            float v = fnan;
+            TI v = static_cast<TI>(fnan);
             if (code >= 2 && cell_ok) v = col[static_cast<int64_t>(code - 2) * ld];
             x[y] = v;
         }
     };
 
     uint32_t e_cur[YPS], e_nxt[YPS];
-    float x_cur[YPS];
+    TI x_cur[YPS];
     load_entries(ch.warm_start, e_cur);
     load_samples(e_cur, x_cur);
     if (ch.warm_start + 1 < ch.end) load_entries(ch.warm_start + 1, e_nxt);
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
 
     for (int32_t s = ch.warm_start; s < ch.end; ++s) {
         // ---- prefetch: samples of step s+1, table entries of step s+2 ------------
-        float x_nxt[YPS];
+        TI x_nxt[YPS];
         uint32_t e_nn[YPS];
         load_samples(e_nxt, x_nxt);
         if (s + 2 < ch.end) load_entries(s + 2, e_nn);
@@ -241,6 +253,7 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
 
         // ---- advance the rings -----------------------------------------------------
         uint32_t kin[YPS], kout[YPS];
+        float xf[YPS];
         bool hold[YPS], counted[YPS];
         bool any_hold = false, all_counted = true;
 #pragma unroll
@@ -249,10 +262,14 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
             hold[y] = (e_cur[y] >> 1) == kCodeHold;
             any_hold |= hold[y];
             all_counted &= counted[y];
-            float xv = x_cur[y];
+            float xv = static_cast<float>(x_cur[y]);
+            if constexpr (kNarrow) lossy |= (static_cast<TI>(xv) != x_cur[y]) && (x_cur[y] == x_cur[y]);
             if (negate) xv = -xv;
-            x_cur[y] = xv;
+            xf[y] = xv;
             kin[y] = f32_key(xv);  // NaN / not loaded -> 0 (invalid)
+        }
+        if constexpr (kNarrow) {
+            if (__builtin_amdgcn_ballot_w64(lossy) != 0) break;   // wave-uniform
         }
 #define XMHW_RING_CASE(K)                                                  \
     case K:                                                                \
@@ -277,7 +294,7 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
 #pragma unroll
         for (int y = 0; y < YPS; ++y) {
             if (!hold[y]) {
-                const float xin = (kin[y] != 0) ? x_cur[y] : 0.0f;
+                const float xin = (kin[y] != 0) ? xf[y] : 0.0f;
                 tsum[y] += static_cast<double>(xin);
                 tsum[y] -= key_value(kout[y]);
                 nval[y] += (kin[y] != 0 ? 1u : 0u) - (kout[y] != 0 ? 1u : 0u);
@@ -310,7 +327,22 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
             }
             const uint32_t n = sub_sum(nl);
             const uint32_t ninv = (allc ? NSLOT : static_cast<uint32_t>(R) * sub_sum(ncl)) - n;
-            const double total = sub_sum(tl);
+            double total = sub_sum(tl);
+            if (__any(!(fabs(total) <= 1.7976931348623157e308))) {
+                // an infinite sample went through a running sum (inf - inf = NaN once it leaves):
+                // rebuild the sums from the rings; with the sample still inside the pool the total
+                // stays +-inf / NaN, exactly what numpy's mean gives for that pool
+                tl = 0.0;
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) t += key_value(ring[y][k]);
+                    tsum[y] = t;
+                    tl += counted[y] ? t : 0.0;
+                }
+                total = sub_sum(tl);
+            }
             Fc += sub_sum(dF);  // raw count at the carried pivot, now for this row's rings
 
             const uint32_t nn = n ? n : 1u;
@@ -494,6 +526,9 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
             x_cur[y] = x_nxt[y];
         }
     }
+    if constexpr (kNarrow) {
+        if (lossy) atomicOr(narrow_flag, 1u);
+    }
     if (stats != nullptr && lane == 0) {
         atomicAdd(&stats[0], static_cast<unsigned long long>(st_rows));
         atomicAdd(&stats[1], static_cast<unsigned long long>(st_count));
@@ -507,9 +542,11 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
 // ---------------------------------------------------------------------------
 namespace {
 typedef void (*RingKernel)(const float*, int64_t, int64_t, const uint32_t*, int32_t, const DevChunk*,
-                           double, int, double*, double*, int64_t, unsigned long long*);
-struct RingEntry { int w, yps; RingKernel fn; };
-#define XMHW_RK(W, Y) {W, Y, clim_ring_f32<W, Y>}
+                           double, int, double*, double*, int64_t, unsigned long long*, uint32_t*);
+typedef void (*RingKernelN)(const double*, int64_t, int64_t, const uint32_t*, int32_t, const DevChunk*,
+                            double, int, double*, double*, int64_t, unsigned long long*, uint32_t*);
+struct RingEntry { int w, yps; RingKernel fn; RingKernelN fn_narrow; };
+#define XMHW_RK(W, Y) {W, Y, clim_ring_f32<W, Y, float>, clim_ring_f32<W, Y, double>}
 const RingEntry kRing[] = {
     XMHW_RK(5, 1), XMHW_RK(5, 2), XMHW_RK(5, 3), XMHW_RK(5, 4), XMHW_RK(5, 5), XMHW_RK(5, 6),
     XMHW_RK(1, 1), XMHW_RK(1, 5), XMHW_RK(2, 3), XMHW_RK(2, 5), XMHW_RK(3, 4),
@@ -519,6 +556,26 @@ RingKernel find_ring(int32_t w, int32_t yps) {
     for (const auto& e : kRing)
         if (e.w == w && e.yps == yps) return e.fn;
     return nullptr;
+}
+RingKernelN find_ring_narrow(int32_t w, int32_t yps) {
+    for (const auto& e : kRing)
+        if (e.w == w && e.yps == yps) return e.fn_narrow;
+    return nullptr;
+}
+
+// a sparse look at a float64 series (32 rows spread over the time axis, every cell) before the
+// narrowing kernel is tried: genuinely float64 data is recognised here at no cost
+__global__ __launch_bounds__(256) void narrow_probe(const double* __restrict__ ts, int64_t Tn, int64_t C,
+                                                    int64_t ld, uint32_t* __restrict__ flag) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int64_t stride = Tn / 32 > 0 ? Tn / 32 : 1;
+    bool lossy = false;
+    for (int64_t t = 0; t < Tn; t += stride) {
+        const double raw = ts[t * ld + c];
+        lossy |= (static_cast<double>(static_cast<float>(raw)) != raw) && (raw == raw);
+    }
+    if (lossy) atomicOr(flag, 1u);
 }
 }  // namespace
 
@@ -545,7 +602,27 @@ hipError_t launch_ring_f32(const float* ts, int64_t C, int64_t ld, const uint32_
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block),
               static_cast<unsigned>(nchunks));
     hipLaunchKernelGGL(fn, grid, dim3(64 * kWavesPerBlock), 0, stream, ts, C, ld, table, step_min,
-                       chunks, q, negate, thresh, seas, ldo, stats);
+                       chunks, q, negate, thresh, seas, ldo, stats, static_cast<uint32_t*>(nullptr));
+    return hipGetLastError();
+}
+
+hipError_t launch_ring_f32_narrowing(const double* ts, int64_t Tn, int64_t C, int64_t ld, const uint32_t* table,
+                                     int32_t step_min, const DevChunk* chunks, int32_t nchunks, int32_t w,
+                                     int32_t yps, double q, int negate, double* thresh, double* seas,
+                                     int64_t ldo, hipStream_t stream, unsigned long long* stats,
+                                     uint32_t* narrow_flag) {
+    RingKernelN fn = find_ring_narrow(w, yps);
+    if (!fn || !narrow_flag) return hipErrorInvalidValue;
+    if (C <= 0 || nchunks <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(narrow_flag, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(narrow_probe, dim3(static_cast<unsigned>((C + 255) / 256)), dim3(256), 0, stream, ts, Tn, C,
+                       ld, narrow_flag);
+    const int64_t cells_per_block = kCellsPerWave * kWavesPerBlock;
+    dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block),
+              static_cast<unsigned>(nchunks));
+    hipLaunchKernelGGL(fn, grid, dim3(64 * kWavesPerBlock), 0, stream, ts, C, ld, table, step_min,
+                       chunks, q, negate, thresh, seas, ldo, stats, narrow_flag);
     return hipGetLastError();
 }
 

@@ -118,8 +118,10 @@ __global__ __launch_bounds__(256) void clim_ring_f64(
     const double* __restrict__ ts, int64_t C, int64_t ld, const uint32_t* __restrict__ table,
     int32_t step_min, const DevChunk* __restrict__ chunks, double q, int negate,
     double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
-    unsigned long long* __restrict__ stats) {
+    unsigned long long* __restrict__ stats, const uint32_t* __restrict__ run_flag) {
     using namespace r64;
+    // queued behind the narrowing float32 kernel: nothing to do unless that one gave up
+    if (run_flag != nullptr && *run_flag == 0) return;
     constexpr int R = 2 * W + 1;
     constexpr int NTP = kSubs * YPS;
     constexpr int J = kTopJ;
@@ -255,7 +257,21 @@ __global__ __launch_bounds__(256) void clim_ring_f64(
                 tl += counted[y] ? tsum[y] : 0.0;
             }
             const uint32_t n = row_sum(nl);
-            const double total = row_sum(tl);
+            double total = row_sum(tl);
+            if (__any(!(fabs(total) <= 1.7976931348623157e308))) {
+                // an infinite sample went through a running sum: rebuild the sums from the rings
+                // (see kernels_ring.hip); NaN slots are the invalid ones
+                tl = 0.0;
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) t += ring[y][k] == ring[y][k] ? ring[y][k] : 0.0;
+                    tsum[y] = t;
+                    tl += counted[y] ? t : 0.0;
+                }
+                total = row_sum(tl);
+            }
             Fc += row_sum(dF);
 
             const uint32_t nn = n ? n : 1u;
@@ -440,7 +456,7 @@ __global__ __launch_bounds__(256) void clim_ring_f64(
 
 namespace {
 typedef void (*Ring64Kernel)(const double*, int64_t, int64_t, const uint32_t*, int32_t, const DevChunk*,
-                             double, int, double*, double*, int64_t, unsigned long long*);
+                             double, int, double*, double*, int64_t, unsigned long long*, const uint32_t*);
 struct Ring64Entry { int w, yps; Ring64Kernel fn; };
 #define XMHW_RK(W, Y) {W, Y, clim_ring_f64<W, Y>}
 const Ring64Entry kRing64[] = {
@@ -459,7 +475,8 @@ int32_t ring64_pick_yps(int32_t w, int32_t ntracks) {
 hipError_t launch_ring_f64(const double* ts, int64_t C, int64_t ld, const uint32_t* table,
                            int32_t step_min, const DevChunk* chunks, int32_t nchunks, int32_t w,
                            int32_t yps, double q, int negate, double* thresh, double* seas,
-                           int64_t ldo, hipStream_t stream, unsigned long long* stats) {
+                           int64_t ldo, hipStream_t stream, unsigned long long* stats,
+                           const uint32_t* run_flag) {
     Ring64Kernel fn = nullptr;
     for (const auto& e : kRing64)
         if (e.w == w && e.yps == yps) fn = e.fn;
@@ -469,7 +486,7 @@ hipError_t launch_ring_f64(const double* ts, int64_t C, int64_t ld, const uint32
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block),
               static_cast<unsigned>(nchunks));
     hipLaunchKernelGGL(fn, grid, dim3(64 * r64::kWavesPerBlock), 0, stream, ts, C, ld, table, step_min,
-                       chunks, q, negate, thresh, seas, ldo, stats);
+                       chunks, q, negate, thresh, seas, ldo, stats, run_flag);
     return hipGetLastError();
 }
 

@@ -102,6 +102,8 @@ PYBIND11_MODULE(_xmhw_hip, m) {
         return out;
     });
     m.def("plan_set_kernel", [](uintptr_t p, int k) { check(xmhw_plan_set_kernel(pp(p), k)); });
+    m.def("plan_set_narrowing", [](uintptr_t p, int on) { check(xmhw_plan_set_narrowing(pp(p), on)); });
+    m.def("plan_narrowed", [](uintptr_t p) { int32_t n = 0; check(xmhw_plan_narrowed(pp(p), &n)); return n != 0; });
     m.def("plan_set_chunks", [](uintptr_t p, int n) { check(xmhw_plan_set_chunks(pp(p), n)); });
     m.def("plan_table", [](uintptr_t p, int yps) {
         int32_t ns, ntp;

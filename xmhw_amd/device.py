@@ -47,7 +47,7 @@ class DeviceBuffer:
 class Plan:
     """Everything derived from the doy labels (xmhw_plan_* in the C ABI)."""
 
-    def __init__(self, doy, window_half_width, kernel="auto", nchunks=0):
+    def __init__(self, doy, window_half_width, kernel="auto", nchunks=0, narrowing=True):
         self._h = hip()
         doy = np.ascontiguousarray(doy, dtype=np.int32)
         try:
@@ -56,6 +56,7 @@ class Plan:
             raise XmhwException(str(e)) from e
         self._h.plan_set_kernel(self.handle, KERNELS[kernel])
         self._h.plan_set_chunks(self.handle, int(nchunks))
+        self._h.plan_set_narrowing(self.handle, int(bool(narrowing)))
         info = self._h.plan_info(self.handle)
         self.D = info["D"]
         self.ntracks = info["ntracks"]
@@ -65,6 +66,11 @@ class Plan:
         self.doys = self._h.plan_doys(self.handle).astype(np.int64)
         self.T = doy.shape[0]
         self.w = int(window_half_width)
+
+    def narrowed(self):
+        """True if the last float64 clim_raw() of this plan ran on the float32 ring kernel (every
+        sample float32-representable)."""
+        return bool(self._h.plan_narrowed(self.handle))
 
     def table(self, years_per_lane):
         return self._h.plan_table(self.handle, years_per_lane)
@@ -104,13 +110,16 @@ def clim_finish(plan, th_in, se_in, C, feb29_fix, smooth, width, th_out, se_out,
 
 
 def calc_clim_device(ts, doy, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
-                     tstep, coldSpells=False, kernel="auto", nchunks=0, max_batch_bytes=32 << 30):
+                     tstep, coldSpells=False, kernel="auto", nchunks=0, max_batch_bytes=32 << 30,
+                     narrowing=True):
     """calc_clim() (xmhw/xmhw.py:250-307) for all cells of a dense host (T, C)
     array on the GPU.  Returns (doys[D] int64, thresh[D, C], seas[D, C]).
 
     Cells are independent, so the array is processed in contiguous cell batches of at
     most ``max_batch_bytes`` of input (one plan, device buffers reused); the result is
     identical to a single call.  PCIe-inclusive: the input is copied to the device.
+    float64 input whose samples are all float32-representable runs on the float32 ring kernel
+    (decided on the device, see xmhw_plan_set_narrowing); narrowing=False forces the float64 one.
     """
     ts = np.asarray(ts)
     if ts.dtype not in (np.float32, np.float64):
@@ -119,7 +128,7 @@ def calc_clim_device(ts, doy, pctile, windowHalfWidth, smoothPercentile, smoothP
         raise XmhwException("calc_clim_device expects a (time, cell) array")
     T, C = ts.shape
     h = hip()
-    plan = Plan(doy, windowHalfWidth, kernel=kernel, nchunks=nchunks)
+    plan = Plan(doy, windowHalfWidth, kernel=kernel, nchunks=nchunks, narrowing=narrowing)
     bufs = []
     try:
         D = plan.D
