@@ -78,3 +78,61 @@ def test_slab_bounds_cover_and_balance():
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _detect_worker(rank, world, port, outdir):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from detect_standin import oracle_detect_cells
+    from xmhw_amd.sharded import detect_sharded
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    temp, th, se = _detect_inputs()
+    out = detect_sharded(temp, th, se, _compute=oracle_detect_cells, intermediate=True, minDuration=4, maxGap=1)
+    if rank == 0:
+        mhw, inter = out
+        np.savez(os.path.join(outdir, "detect.npz"), table=mhw.table, offsets=mhw.offsets,
+                 **{"inter_" + k: v for k, v in inter.data_vars.items()})
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _detect_inputs():
+    import oracle_fast as fast
+    from xmhw_amd import GridSeries, climatology_series
+    from xmhw_amd.api import _threshold
+
+    def compute(ts, doy, pctile, w, smooth, width, tstep, cold=False):
+        return fast.threshold_cells_fast(ts, doy, pctile=pctile, windowHalfWidth=w, smoothPercentile=smooth,
+                                         smoothPercentileWidth=width, tstep=tstep, coldSpells=cold)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "oisst_2003_2004.npz"))
+    time = np.datetime64("2003-01-01") + g["time"].astype("timedelta64[D]")
+    temp = GridSeries(g["sst"], ("time", "lat", "lon"), {"time": time, "lat": g["lat"], "lon": g["lon"]})
+    clim = _threshold(temp, compute, pctile=80)
+    return temp, climatology_series(clim, "thresh"), climatology_series(clim, "seas")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_detect_equals_single(tmp_path, world):
+    """detect() over 2 and 3 ranks (uneven slabs, variable-length event tables) = the single-rank result."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from detect_standin import oracle_detect_cells
+    from xmhw_amd.detect import _detect
+
+    mp.spawn(_detect_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "detect.npz")
+    temp, th, se = _detect_inputs()
+    mhw, inter = _detect(temp, th, se, oracle_detect_cells, intermediate=True, minDuration=4, maxGap=1)
+    assert mhw.n_events > 0
+    np.testing.assert_array_equal(got["offsets"], mhw.offsets)
+    np.testing.assert_array_equal(got["table"], mhw.table)
+    for k, v in inter.data_vars.items():
+        assert got["inter_" + k].dtype == v.dtype, k
+        np.testing.assert_array_equal(got["inter_" + k], v, err_msg=k)

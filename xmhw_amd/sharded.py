@@ -1,4 +1,4 @@
-"""Multi-GPU threshold(): cells shard across ranks, one gather at the end.
+"""Multi-GPU threshold() and detect(): cells shard across ranks, one gather at the end.
 
 The reference treats every grid cell as an independent task
 (xmhw/xmhw.py:184-197), so the path shards with no exchange during compute:
@@ -15,6 +15,7 @@ called through the C ABI.
 import numpy as np
 
 from . import api
+from .detect import INTER_VARIABLES, _detect
 from .device import calc_clim_device
 
 
@@ -100,3 +101,109 @@ def threshold_sharded(temp, group=None, dst=0, device=None, _compute=None, **kwa
 
     ds = api._threshold(temp, make_sharded_compute(group, dst, device, _compute), **kwargs)
     return ds if dist.get_rank(group) == dst else None
+
+
+def _device_for(group, device):
+    import torch
+    import torch.distributed as dist
+    if device is not None:
+        return device
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def _gather_columns(block, ncells, group, dst, device):
+    """Gather per-rank (rows, slab_r) float64 blocks into (rows, ncells) on dst (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    bounds = slab_bounds(ncells, world)
+    width = max(hi - lo for lo, hi in bounds)
+    rows = block.shape[0]
+    pad = torch.zeros((rows, width), dtype=torch.float64, device=device)
+    n_r = bounds[rank][1] - bounds[rank][0]
+    if n_r:
+        pad[:, :n_r] = torch.as_tensor(np.ascontiguousarray(block, dtype=np.float64), device=device)
+    out = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, out, dst=dst, group=group)
+    if rank != dst:
+        return None
+    full = np.empty((rows, ncells), dtype=np.float64)
+    for r, (lo, hi) in enumerate(bounds):
+        full[:, lo:hi] = out[r][:, : hi - lo].cpu().numpy()
+    return full
+
+
+def make_sharded_detect(group=None, dst=0, device=None, compute=None):
+    """A drop-in for detect_front.detect_cells that runs only this rank's slab of cells and gathers
+    the event tables (variable length per rank: sizes first, then one padded gather) and, if asked
+    for, the per-step columns.  Rank dst returns the full result, the others an empty one."""
+    import torch
+    import torch.distributed as dist
+    from .detect_front import EVENT_COLUMNS, detect_cells
+
+    from .detect_front import INTERMEDIATE_U8
+    inner = compute or detect_cells
+    ncol = len(EVENT_COLUMNS)
+    BOOL_VARIABLES = set(INTERMEDIATE_U8) | {"bthresh"}
+
+    def sharded(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
+                intermediate=False):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        dev = _device_for(group, device)
+        T, C = ts.shape
+        lo, hi = slab_bounds(C, world)[rank]
+        if hi > lo:
+            res = inner(np.ascontiguousarray(ts[:, lo:hi]), np.ascontiguousarray(seas[:, lo:hi]),
+                        np.ascontiguousarray(thresh[:, lo:hi]), doy, doys, minDuration, joinGaps, maxGap,
+                        coldSpells, intermediate)
+        else:
+            res = dict(table=np.zeros((0, ncol)), offsets=np.zeros(1, dtype=np.int64), inter=None)
+        counts = np.diff(res["offsets"]).astype(np.float64)[None, :]
+        all_counts = _gather_columns(counts, C, group, dst, dev)
+        # table rows: every rank learns the largest table, pads to it, one gather
+        n_r = torch.tensor([res["table"].shape[0]], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(n_r) for _ in range(world)]
+        dist.all_gather(sizes, n_r, group=group)
+        sizes = [int(v.item()) for v in sizes]
+        nmax = max(max(sizes), 1)
+        pad = torch.zeros((nmax, ncol), dtype=torch.float64, device=dev)
+        if sizes[rank]:
+            pad[: sizes[rank]] = torch.as_tensor(res["table"], device=dev)
+        out = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+        dist.gather(pad, out, dst=dst, group=group)
+        inter = None
+        if intermediate:
+            inter = {}
+            for k in INTER_VARIABLES:
+                blk = res["inter"][k] if hi > lo else np.zeros((T, 0))
+                full = _gather_columns(blk, C, group, dst, dev)
+                if rank != dst:
+                    continue
+                if k in BOOL_VARIABLES:
+                    inter[k] = full != 0
+                elif k == "ts":
+                    inter[k] = full.astype(ts.dtype)        # float32 values survive the float64 transport
+                else:
+                    inter[k] = full
+        if rank != dst:
+            return dict(table=np.zeros((0, ncol)), offsets=np.zeros(C + 1, dtype=np.int64),
+                        inter=None if not intermediate else
+                        {k: np.zeros((T, C), dtype=bool if k in BOOL_VARIABLES else np.float64)
+                         for k in INTER_VARIABLES})
+        table = np.concatenate([out[r][: sizes[r]].cpu().numpy() for r in range(world)], axis=0)
+        offsets = np.zeros(C + 1, dtype=np.int64)
+        np.cumsum(all_counts[0].astype(np.int64), out=offsets[1:])
+        return dict(table=table, offsets=offsets, inter=inter)
+
+    return sharded
+
+
+def detect_sharded(temp, th, se, group=None, dst=0, device=None, _compute=None, **kwargs):
+    """detect() over all ranks of ``group`` (cells shard exactly as in threshold_sharded; the event
+    tables are gathered to rank ``dst``, which gets what detect() returns; the others get None)."""
+    import torch.distributed as dist
+
+    out = _detect(temp, th, se, make_sharded_detect(group, dst, device, _compute), **kwargs)
+    return out if dist.get_rank(group) == dst else None
