@@ -217,6 +217,18 @@ int clim_oneshot(const T* ts, const int32_t* doy, int64_t Tn, int64_t C, int32_t
     return XMHW_OK;
 }
 
+// row_of_t on the device for the duration of one call
+struct DeviceRows {
+    int32_t* ptr = nullptr;
+    hipError_t err = hipSuccess;
+    DeviceRows(const int32_t* host, int64_t Tn, hipStream_t st) {
+        err = hipMalloc(&ptr, sizeof(int32_t) * static_cast<size_t>(Tn));
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(ptr, host, sizeof(int32_t) * static_cast<size_t>(Tn), hipMemcpyHostToDevice, st);
+    }
+    ~DeviceRows() { if (ptr) (void)hipFree(ptr); }
+};
+
 template <typename T>
 int detect_events(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* thresh, int64_t ldt,
                   const int32_t* row_of_t, int32_t min_duration, int32_t join_gaps, int32_t max_gap,
@@ -228,16 +240,13 @@ int detect_events(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* 
     if (!ts || !thresh || !row_of_t || !events || !start || !end)
         return fail(XMHW_ERR_INVALID, "NULL buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int32_t* d_rows = nullptr;
-    HIP_TRY(hipMalloc(&d_rows, sizeof(int32_t) * static_cast<size_t>(Tn)));
-    hipError_t e = hipMemcpyAsync(d_rows, row_of_t, sizeof(int32_t) * static_cast<size_t>(Tn),
-                                  hipMemcpyHostToDevice, st);
+    DeviceRows rows(row_of_t, Tn, st);
+    hipError_t e = rows.err;
     if (e == hipSuccess)
-        e = xmhw::launch_detect<T>(ts, Tn, C, ld, thresh, ldt, d_rows, min_duration, join_gaps, max_gap, negate,
+        e = xmhw::launch_detect<T>(ts, Tn, C, ld, thresh, ldt, rows.ptr, min_duration, join_gaps, max_gap, negate,
                                    events, start, end, bthresh, ldo, nevents, st);
     // the row table must outlive the kernel: synchronise before releasing it
     hipError_t e2 = hipStreamSynchronize(st);
-    (void)hipFree(d_rows);
     if (e != hipSuccess) return hip_fail(e, "detect_events launch");
     if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
     return XMHW_OK;
@@ -252,31 +261,16 @@ int event_stats(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* se
     if (!ts || !seas || !thresh || !row_of_t || !events || !offsets)
         return fail(XMHW_ERR_INVALID, "NULL buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int32_t* d_rows = nullptr;
-    HIP_TRY(hipMalloc(&d_rows, sizeof(int32_t) * static_cast<size_t>(Tn)));
-    hipError_t e = hipMemcpyAsync(d_rows, row_of_t, sizeof(int32_t) * static_cast<size_t>(Tn),
-                                  hipMemcpyHostToDevice, st);
+    DeviceRows rows(row_of_t, Tn, st);
+    hipError_t e = rows.err;
     if (e == hipSuccess)
-        e = xmhw::launch_event_stats<T>(ts, Tn, C, ld, seas, thresh, ldc, d_rows, negate, events, ldo, offsets,
+        e = xmhw::launch_event_stats<T>(ts, Tn, C, ld, seas, thresh, ldc, rows.ptr, negate, events, ldo, offsets,
                                         table, st);
     hipError_t e2 = hipStreamSynchronize(st);
-    (void)hipFree(d_rows);
     if (e != hipSuccess) return hip_fail(e, "event_stats launch");
     if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
     return XMHW_OK;
 }
-
-// row_of_t on the device for the duration of one call
-struct DeviceRows {
-    int32_t* ptr = nullptr;
-    hipError_t err = hipSuccess;
-    DeviceRows(const int32_t* host, int64_t Tn, hipStream_t st) {
-        err = hipMalloc(&ptr, sizeof(int32_t) * static_cast<size_t>(Tn));
-        if (err == hipSuccess)
-            err = hipMemcpyAsync(ptr, host, sizeof(int32_t) * static_cast<size_t>(Tn), hipMemcpyHostToDevice, st);
-    }
-    ~DeviceRows() { if (ptr) (void)hipFree(ptr); }
-};
 
 static int g_exceed_kernel = 0;   // 0 auto, 1 per-step kernel, 2 tiled kernel (xmhw_set_exceed_kernel)
 
@@ -420,15 +414,12 @@ int event_intermediate(const T* ts, int64_t Tn, int64_t C, int64_t ld, const dou
     if (C == 0) return XMHW_OK;
     if (!ts || !seas || !thresh || !row_of_t || !events || !out || !dur) return fail(XMHW_ERR_INVALID, "NULL buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int32_t* d_rows = nullptr;
-    HIP_TRY(hipMalloc(&d_rows, sizeof(int32_t) * static_cast<size_t>(Tn)));
-    hipError_t e = hipMemcpyAsync(d_rows, row_of_t, sizeof(int32_t) * static_cast<size_t>(Tn),
-                                  hipMemcpyHostToDevice, st);
+    DeviceRows rows(row_of_t, Tn, st);
+    hipError_t e = rows.err;
     if (e == hipSuccess)
-        e = xmhw::launch_event_intermediate<T>(ts, Tn, C, ld, seas, thresh, ldc, d_rows, negate, events, ldo, out,
+        e = xmhw::launch_event_intermediate<T>(ts, Tn, C, ld, seas, thresh, ldc, rows.ptr, negate, events, ldo, out,
                                                ldv, dur, st);
     hipError_t e2 = hipStreamSynchronize(st);
-    (void)hipFree(d_rows);
     if (e != hipSuccess) return hip_fail(e, "event_intermediate launch");
     if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
     return XMHW_OK;

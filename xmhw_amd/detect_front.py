@@ -31,22 +31,8 @@ def mhw_filter_cells(ts, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap
     Returns dict(bthresh bool (T, C); start, end, events float64 (T, C) with NaN as in the
     reference's per-cell DataFrame of mhw_filter()).
     """
-    ts = np.asarray(ts)
-    if ts.dtype not in (np.float32, np.float64):
-        ts = ts.astype(np.float64)
-    ts = np.ascontiguousarray(ts)
-    thresh = np.ascontiguousarray(thresh, dtype=np.float64)
-    if ts.ndim != 2 or thresh.ndim != 2 or ts.shape[1] != thresh.shape[1]:
-        raise XmhwException("ts must be (T, C) and thresh (D, C) on the same cells")
-    doy = np.asarray(doy)
-    doys = np.asarray(doys)
+    ts, _, thresh, rows = _check_inputs(ts, thresh, thresh, doy, doys)
     T, C = ts.shape
-    if doy.shape[0] != T or doys.shape[0] != thresh.shape[0]:
-        raise XmhwException("doy must have length T and doys length D")
-    rows = np.searchsorted(doys, doy)
-    if np.any(rows >= doys.shape[0]) or np.any(doys[np.minimum(rows, doys.shape[0] - 1)] != doy):
-        # th.sel(doy=ts.doy) raises KeyError in the reference for a label without climatology
-        raise XmhwException("a time step's doy label has no row in the climatology")
     h = hip()
     bufs = []
     try:
@@ -56,7 +42,7 @@ def mhw_filter_cells(ts, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap
         d_b = DeviceBuffer(T * C)
         bufs += [d_ev, d_st, d_en, d_b]
         try:
-            h.detect_events(d_ts.ptr, ts.dtype.itemsize, T, C, C, d_th.ptr, C, rows.astype(np.int32),
+            h.detect_events(d_ts.ptr, ts.dtype.itemsize, T, C, C, d_th.ptr, C, rows,
                             int(minDuration), int(bool(joinGaps)), int(maxGap), int(bool(coldSpells)),
                             d_ev.ptr, d_st.ptr, d_en.ptr, d_b.ptr, C)
         except h.InvalidArgument as e:
