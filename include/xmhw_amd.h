@@ -53,6 +53,10 @@ int xmhw_malloc(void **dev_ptr, size_t bytes);
 int xmhw_free(void *dev_ptr);
 int xmhw_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes, void *stream);
 int xmhw_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes, void *stream);
+/* a block of columns of a row-major host array into a dense device array (hipMemcpy2D):
+ * `height` rows of `width_bytes`, rows `spitch` bytes apart on the host, `dpitch` on the device */
+int xmhw_memcpy2d_h2d(void *dev_dst, size_t dpitch, const void *host_src, size_t spitch,
+                      size_t width_bytes, size_t height, void *stream);
 int xmhw_memset(void *dev_dst, int value, size_t bytes, void *stream);
 int xmhw_stream_create(void **stream);
 int xmhw_stream_destroy(void *stream);

@@ -185,3 +185,41 @@ def test_strided_slabs_ld_and_ldo(h, dtype):
     npt.assert_allclose(got_s[:, :n], s0, rtol=1e-12)
     # the padding columns of the output rows were not touched
     assert np.isnan(got_t[:, n:]).all() and (got_t[:, n:].view(np.uint64) == 0xFFFFFFFFFFFFFFFF).all()
+
+
+def test_device_side_land_mask_and_compaction_equal_host_path(oisst):
+    """threshold()/detect() hand the uncompacted grid to the device (pitched slab uploads, land_mask,
+    gather); same results as numpy's land_check() followed by the compact-array entry points, also
+    with several slabs, with anynans, and with a float64 grid."""
+    from xmhw_amd import landmask
+    from xmhw_amd.device import calc_clim_device, calc_clim_grid_device
+    from xmhw_amd.detect_front import detect_cells, detect_grid
+    import xmhw_oracle as ora
+    rng = np.random.default_rng(3)
+    sst = oisst["sst"].copy()
+    sst[rng.random(sst.shape) < 0.01] = np.nan               # scattered NaNs: anynans drops more cells
+    doy = ora.add_doy(oisst["time64"])
+    for dtype in (np.float32, np.float64):
+        for anynans in (False, True):
+            x = sst.astype(dtype)
+            x[:, 1, 1] = oisst["sst"][:, 1, 1] if not np.isnan(oisst["sst"][:, 1, 1]).all() else 1.0
+            ts, keep, sdims, sshape = landmask.land_check(x, ("time", "lat", "lon"), "time", anynans)
+            stacked, _, _ = landmask.stack_cells(x, ("time", "lat", "lon"), "time")
+            d0, th0, se0 = calc_clim_device(ts, doy, 90, 5, True, 31, False)
+            for budget in (64 << 30, 60_000):                # one slab / a handful of columns per slab
+                k1, d1, th1, se1 = calc_clim_grid_device(stacked, doy, anynans, 90, 5, True, 31, False,
+                                                         max_batch_bytes=budget)
+                npt.assert_array_equal(k1, keep)
+                npt.assert_array_equal(th1, th0)
+                npt.assert_array_equal(se1, se0)
+                r0 = detect_cells(ts, se0, th0, doy, d0, 5, True, 2)
+                r1 = detect_grid(stacked, anynans, se0, th0, doy, d0, 5, True, 2, max_batch_bytes=budget)
+                npt.assert_array_equal(r1["keep"], keep)
+                npt.assert_array_equal(r1["offsets"], r0["offsets"])
+                npt.assert_array_equal(r1["table"], r0["table"])
+    # all land -> the reference's exception, raised after the device mask
+    from xmhw_amd import XmhwException
+    with pytest.raises(XmhwException):
+        calc_clim_grid_device(np.full((731, 6), np.nan, np.float32), doy, False, 90, 5, True, 31, False)
+    with pytest.raises(XmhwException):                       # climatologies on fewer cells than the series
+        detect_grid(stacked, False, se0[:, :-1], th0[:, :-1], doy, d0)

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the public threshold() / detect() on HOST arrays (PCIe and host-side numpy
+included), 1-degree grid by default:  python tools/time_api.py [nlat nlon nyears]"""
+import os, sys, time
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+import numpy as np
+import xmhw_amd
+from xmhw_amd import GridSeries, climatology_series
+
+nlat, nlon, ny = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (180, 360, 30)
+t = np.arange("1991-01-01", f"{1991 + ny}-01-01", dtype="datetime64[D]")
+T = t.shape[0]
+rng = np.random.default_rng(1)
+t0 = time.perf_counter()
+x = (15 + 5 * np.sin(2 * np.pi * np.arange(T)[:, None, None] / 365.25)
+     + rng.standard_normal((T, nlat, nlon), dtype=np.float32)).astype(np.float32)
+x[:, : nlat // 6, :] = np.nan                         # a band of land
+print(f"input {x.shape} {x.nbytes / 1e9:.2f} GB built in {time.perf_counter() - t0:.1f} s", flush=True)
+g = GridSeries(x, ("time", "lat", "lon"), {"time": t, "lat": np.arange(nlat), "lon": np.arange(nlon)},
+               time_encoding={"calendar": "proleptic_gregorian"})
+for rep in range(2):
+    t0 = time.perf_counter()
+    clim = xmhw_amd.threshold(g)
+    t1 = time.perf_counter()
+    mhw = xmhw_amd.detect(g, climatology_series(clim, "thresh"), climatology_series(clim, "seas"))
+    t2 = time.perf_counter()
+    ncell = int(mhw.n_cells)
+    print(f"rep {rep}: threshold() {t1 - t0:.2f} s ({ncell / (t1 - t0):.3g} cells/s), detect() {t2 - t1:.2f} s "
+          f"({ncell / (t2 - t1):.3g} cells/s), {mhw.n_events} events in {ncell} cells", flush=True)

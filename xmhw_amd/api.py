@@ -16,7 +16,7 @@ import numpy as np
 
 from . import calendar as cal
 from . import landmask
-from .device import calc_clim_device
+from .device import calc_clim_device, calc_clim_grid_device
 from .exception import XmhwException
 
 GITHUB = "https://github.com/coecms/xmhw"
@@ -128,15 +128,17 @@ def threshold(
     """
     return _threshold(temp, calc_clim_device, tdim, climatologyPeriod, pctile, windowHalfWidth,
                       smoothPercentile, smoothPercentileWidth, maxPadLength, coldSpells, tstep,
-                      anynans, skipna)
+                      anynans, skipna, grid_compute=calc_clim_grid_device)
 
 
 def _threshold(temp, compute, tdim="time", climatologyPeriod=[None, None], pctile=90,
                windowHalfWidth=5, smoothPercentile=True, smoothPercentileWidth=31, maxPadLength=None,
-               coldSpells=False, tstep=False, anynans=False, skipna=False):
+               coldSpells=False, tstep=False, anynans=False, skipna=False, grid_compute=None):
     """Host side of threshold() around a device stage ``compute`` with the signature of
     ``device.calc_clim_device``.  The public threshold() passes the HIP path; the CPU tests of
-    the host logic and of the multi-rank sharding pass a stand-in here."""
+    the host logic and of the multi-rank sharding pass a stand-in here.  ``grid_compute``
+    (signature of ``device.calc_clim_grid_device``) additionally takes land_check()'s mask and
+    compaction off the host; without it they run in numpy (landmask.land_check)."""
     if smoothPercentileWidth % 2 == 0:                       # xmhw.py:103-104
         raise XmhwException("smoothPercentileWidth should be odd")
     is_xr = _is_xarray(temp)
@@ -164,9 +166,12 @@ def _threshold(temp, compute, tdim="time", climatologyPeriod=[None, None], pctil
     if time.shape[0] == 0:
         raise XmhwException("time axis is empty")
     point = len(dims) == 1                                    # xmhw.py:122-126
+    on_device = grid_compute is not None and not point
     if point:
         ts = np.ascontiguousarray(values.reshape(-1, 1))
         keep, sdims, sshape = np.array([True]), [], ()
+    elif on_device:
+        stacked, sdims, sshape = landmask.stack_cells(values, dims, tdim)   # raises like land_check
     else:
         ts, keep, sdims, sshape = landmask.land_check(values, dims, tdim, anynans)
     calname = cal.calendar_of(time, enc, coord_attrs.get(tdim, {}))
@@ -174,8 +179,12 @@ def _threshold(temp, compute, tdim="time", climatologyPeriod=[None, None], pctil
         tstep = True
     doy = cal.add_doy(time, keep_tstep=tstep)                 # xmhw.py:145
 
-    doys, th, se = compute(ts, doy, pctile, windowHalfWidth, smoothPercentile,
-                           smoothPercentileWidth, tstep, coldSpells)
+    if on_device:
+        keep, doys, th, se = grid_compute(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile,
+                                          smoothPercentileWidth, tstep, coldSpells)
+    else:
+        doys, th, se = compute(ts, doy, pctile, windowHalfWidth, smoothPercentile,
+                               smoothPercentileWidth, tstep, coldSpells)
 
     D = doys.shape[0]
     yrs = cal.years_of(time)

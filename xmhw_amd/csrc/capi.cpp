@@ -513,6 +513,15 @@ int xmhw_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
     HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return XMHW_OK;
 }
+int xmhw_memcpy2d_h2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+                      void* stream) {
+    if (width == 0 || height == 0) return XMHW_OK;
+    if (!dst || !src || dpitch < width || spitch < width) return fail(XMHW_ERR_INVALID, "bad pointer/pitch");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return XMHW_OK;
+}
 int xmhw_memset(void* dst, int value, size_t bytes, void* stream) {
     if (bytes == 0) return XMHW_OK;
     HIP_TRY(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)));

@@ -62,6 +62,18 @@ PYBIND11_MODULE(_xmhw_hip, m) {
         py::buffer_info bi = src.request();
         check(xmhw_memcpy_h2d(vp(dst), bi.ptr, static_cast<size_t>(bi.size) * bi.itemsize, vp(stream)));
     }, py::arg("dst"), py::arg("src"), py::arg("stream") = 0);
+    m.def("memcpy2d_h2d", [](uintptr_t dst, py::buffer src, int64_t col0, int64_t ncols, uintptr_t stream) {
+        // columns [col0, col0 + ncols) of a C-contiguous 2-D host array -> dense (rows, ncols) device array
+        py::buffer_info bi = src.request();
+        if (bi.ndim != 2 || bi.strides[1] != bi.itemsize || bi.strides[0] != bi.itemsize * bi.shape[1])
+            throw InvalidError("memcpy2d_h2d needs a C-contiguous 2-D array");
+        if (col0 < 0 || ncols < 0 || col0 + ncols > bi.shape[1]) throw InvalidError("column range outside the array");
+        const size_t isz = static_cast<size_t>(bi.itemsize);
+        py::gil_scoped_release r;
+        check(xmhw_memcpy2d_h2d(vp(dst), isz * static_cast<size_t>(ncols), static_cast<const char*>(bi.ptr) + isz * col0,
+                                isz * static_cast<size_t>(bi.shape[1]), isz * static_cast<size_t>(ncols),
+                                static_cast<size_t>(bi.shape[0]), vp(stream)));
+    }, py::arg("dst"), py::arg("src"), py::arg("col0"), py::arg("ncols"), py::arg("stream") = 0);
     m.def("memcpy_d2h", [](py::buffer dst, uintptr_t src, uintptr_t stream) {
         py::buffer_info bi = dst.request(true);
         check(xmhw_memcpy_d2h(bi.ptr, vp(src), static_cast<size_t>(bi.size) * bi.itemsize, vp(stream)));

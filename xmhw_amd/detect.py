@@ -19,7 +19,7 @@ import numpy as np
 from . import calendar as cal
 from . import landmask
 from .api import GITHUB, GridSeries, _from_xarray, _is_xarray
-from .detect_front import EVENT_COLUMNS, INTERMEDIATE_F64, INTERMEDIATE_U8, detect_cells
+from .detect_front import EVENT_COLUMNS, INTERMEDIATE_F64, INTERMEDIATE_U8, detect_cells, detect_grid
 from .exception import XmhwException
 
 TIME_COLUMNS = ("time_start", "time_end", "time_peak")
@@ -242,14 +242,15 @@ def detect(
     request) and, with ``intermediate``, an InterDataset.  The device stage is always the HIP path.
     """
     return _detect(temp, th, se, detect_cells, tdim, minDuration, joinGaps, maxGap, maxPadLength, coldSpells,
-                   intermediate, anynans, tstep)
+                   intermediate, anynans, tstep, grid_compute=detect_grid)
 
 
 def _detect(temp, th, se, compute, tdim="time", minDuration=5, joinGaps=True, maxGap=2, maxPadLength=None,
-            coldSpells=False, intermediate=False, anynans=False, tstep=False):
+            coldSpells=False, intermediate=False, anynans=False, tstep=False, grid_compute=None):
     """Host side of detect() around a device stage ``compute`` with the signature of
     ``detect_front.detect_cells``.  The public detect() passes the HIP path; the CPU tests of the
-    host logic pass an oracle-based stand-in."""
+    host logic pass an oracle-based stand-in.  ``grid_compute`` (signature of
+    ``detect_front.detect_grid``) also takes the series' land mask and compaction off the host."""
     if maxGap >= minDuration:                                  # xmhw.py:373-378
         raise XmhwException("Maximum gap between mhw events should"
                             + " be smaller than event minimum duration")
@@ -266,6 +267,7 @@ def _detect(temp, th, se, compute, tdim="time", minDuration=5, joinGaps=True, ma
         raise XmhwException("th and se must have a 'doy' dimension")
     time = np.asarray(coords[tdim])
     point = len(dims) == 1                                    # xmhw.py:381-385
+    on_device = grid_compute is not None and not point
     if point:
         if len(thdims) != 1 or len(sedims) != 1:
             raise XmhwException("a single-point series needs single-point climatologies")
@@ -275,18 +277,28 @@ def _detect(temp, th, se, compute, tdim="time", minDuration=5, joinGaps=True, ma
     else:
         # land_check on all three (xmhw.py:398-402); cells pair up by POSITION after each dropna
         # (stack(create_index=False), then ts.sel(cell=c) / th.sel(cell=c): xmhw.py:437-443)
-        ts, keep, sdims, sshape = landmask.land_check(values, dims, tdim, anynans)
+        if on_device:
+            stacked, sdims, sshape = landmask.stack_cells(values, dims, tdim)
+            ts = None
+        else:
+            ts, keep, sdims, sshape = landmask.land_check(values, dims, tdim, anynans)
         thc, _, thsd, _ = landmask.land_check(thv, thdims, "doy", anynans)
         sec, _, sesd, _ = landmask.land_check(sev, sedims, "doy", anynans)
-        if thc.shape[1] != ts.shape[1] or sec.shape[1] != ts.shape[1] or thsd != sdims or sesd != sdims:
+        nts = thc.shape[1] if on_device else ts.shape[1]        # the device path checks its own count
+        if thc.shape[1] != nts or sec.shape[1] != nts or thsd != sdims or sesd != sdims:
             raise XmhwException("temp, th and se do not have the same ocean cells: "
-                                + f"{ts.shape[1]}, {thc.shape[1]}, {sec.shape[1]} cells over dims {sdims}, {thsd}, {sesd}")
+                                + f"{nts}, {thc.shape[1]}, {sec.shape[1]} cells over dims {sdims}, {thsd}, {sesd}")
     doys = np.asarray(thcoords["doy"])
     if not np.array_equal(doys, np.asarray(secoords["doy"])):
         raise XmhwException("th and se have different doy coordinates")
     doy = cal.add_doy(time, keep_tstep=tstep)                  # xmhw.py:404 (no calendar sniffing here)
 
-    res = compute(ts, sec, thc, doy, doys, minDuration, joinGaps, maxGap, coldSpells, intermediate)
+    if on_device:
+        res = grid_compute(stacked, anynans, sec, thc, doy, doys, minDuration, joinGaps, maxGap, coldSpells,
+                           intermediate)
+        keep = res["keep"]
+    else:
+        res = compute(ts, sec, thc, doy, doys, minDuration, joinGaps, maxGap, coldSpells, intermediate)
     table, offsets = res["table"], res["offsets"]
     if coldSpells:                                             # flip_cold(), xmhw/features.py:298-315
         table = table.copy()

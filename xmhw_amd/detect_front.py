@@ -93,12 +93,12 @@ def _check_inputs(ts, seas, thresh, doy, doys):
     return ts, seas, thresh, rows.astype(np.int32)
 
 
-def _table_only_batch(h, ts, seas, thresh, rows, T, n, isz, neg, minDuration, joinGaps, maxGap):
-    """Event table of one batch of cells without per-step outputs: exceedance bits -> run walk
-    (count, host prefix sum, fill) -> one thread per event (csrc/kernels_events.hip)."""
+def _table_only_device(h, d_ts, isz, seas, thresh, rows, T, n, neg, minDuration, joinGaps, maxGap):
+    """Event table of n cells whose dense (T, n) series is already on the device, without per-step
+    outputs: exceedance bits -> run walk (count, host prefix sum, fill) -> one thread per event
+    (csrc/kernels_events.hip).  seas / thresh: host (D, n)."""
     bufs = []
     try:
-        d_ts = DeviceBuffer.from_array(ts); bufs.append(d_ts)
         d_th = DeviceBuffer.from_array(thresh); bufs.append(d_th)
         d_se = DeviceBuffer.from_array(seas); bufs.append(d_se)
         W = (T + 63) // 64
@@ -125,6 +125,14 @@ def _table_only_batch(h, ts, seas, thresh, rows, T, n, isz, neg, minDuration, jo
     finally:
         for b in bufs:
             b.free()
+
+
+def _table_only_batch(h, ts, seas, thresh, rows, T, n, isz, neg, minDuration, joinGaps, maxGap):
+    d_ts = DeviceBuffer.from_array(ts)
+    try:
+        return _table_only_device(h, d_ts, isz, seas, thresh, rows, T, n, neg, minDuration, joinGaps, maxGap)
+    finally:
+        d_ts.free()
 
 
 def detect_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
@@ -217,6 +225,68 @@ def detect_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxG
     np.cumsum(counts, out=offsets[1:])
     table = np.concatenate(tables, axis=0) if tables else np.zeros((0, len(EVENT_COLUMNS)))
     return dict(table=table, offsets=offsets, inter=inter)
+
+
+def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
+                intermediate=False, max_batch_bytes=64 << 30):
+    """detect_cells() for an UNCOMPACTED stacked host series (T, N): land_check()'s mask and
+    compaction of the series run on the device (device.compact_columns), slab by slab; seas / thresh
+    are the already compacted (D, C) climatologies, whose cells pair with the surviving columns by
+    position (xmhw/xmhw.py:398-402, 437-443).  Returns detect_cells()'s dict plus keep[N]."""
+    from .device import _grid_batch, compact_columns
+    stacked = np.asarray(stacked)
+    if stacked.dtype not in (np.float32, np.float64):
+        stacked = stacked.astype(np.float64)
+    stacked = np.ascontiguousarray(stacked)
+    T, N = stacked.shape
+    C = thresh.shape[1]
+    if intermediate:
+        # the per-step columns come back to the host anyway: compact there and take the per-step kernels
+        nan = np.isnan(stacked)
+        keep = ~(nan.any(axis=0) if anynans else nan.all(axis=0))
+        if not keep.any():
+            raise XmhwException("All points of grid are either land or NaN")
+        if int(keep.sum()) != C:
+            raise XmhwException(f"temp has {int(keep.sum())} ocean cells, th and se have {C}")
+        r = detect_cells(np.ascontiguousarray(stacked[:, keep]), seas, thresh, doy, doys, minDuration, joinGaps,
+                         maxGap, coldSpells, True, max_batch_bytes)
+        r["keep"] = keep
+        return r
+    _, seas, thresh, rows = _check_inputs(np.zeros((T, C), dtype=stacked.dtype), seas, thresh, doy, doys)
+    h = hip()
+    isz = stacked.dtype.itemsize
+    neg = int(bool(coldSpells))
+    D = thresh.shape[0]
+    cb = _grid_batch(stacked, max_batch_bytes, per_cell_extra=2 * D * 8 + T // 8 + 64)
+    keeps, tables, counts_all = [], [], []
+    k0 = 0
+    for lo in range(0, N, cb):
+        hi = min(N, lo + cb)
+        d_ts, keep = compact_columns(stacked, lo, hi, anynans)
+        keeps.append(keep)
+        n = int(keep.sum())
+        if d_ts is None:
+            continue
+        try:
+            if k0 + n > C:
+                raise XmhwException(f"temp has more ocean cells than th and se ({C})")
+            tab, counts = _table_only_device(h, d_ts, isz, np.ascontiguousarray(seas[:, k0:k0 + n]),
+                                             np.ascontiguousarray(thresh[:, k0:k0 + n]), rows, T, n, neg,
+                                             minDuration, joinGaps, maxGap)
+        finally:
+            d_ts.free()
+        tables.append(tab)
+        counts_all.append(counts)
+        k0 += n
+    keep = np.concatenate(keeps) if keeps else np.zeros(0, dtype=bool)
+    if not keep.any():
+        raise XmhwException("All points of grid are either land or NaN")
+    if k0 != C:
+        raise XmhwException(f"temp has {k0} ocean cells, th and se have {C}")
+    offsets = np.zeros(C + 1, dtype=np.int64)
+    np.cumsum(np.concatenate(counts_all), out=offsets[1:])
+    table = np.concatenate(tables, axis=0) if tables else np.zeros((0, len(EVENT_COLUMNS)))
+    return dict(table=table, offsets=offsets, inter=None, keep=keep)
 
 
 def mhw_features_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False):

@@ -168,3 +168,101 @@ def calc_clim_device(ts, doy, pctile, windowHalfWidth, smoothPercentile, smoothP
         for b in bufs:
             b.free()
         plan.destroy()
+
+
+def compact_columns(stacked, lo, hi, anynans):
+    """land_check()'s dropna + compaction (xmhw/identify.py:520-525) for columns [lo, hi) of a
+    C-contiguous host (T, N) array, on the device: pitched upload, land_mask kernel, gather of the
+    surviving columns.  Returns (DeviceBuffer holding the dense (T, n_keep) array or None if
+    n_keep == 0, keep mask of the slab)."""
+    h = hip()
+    T = stacked.shape[0]
+    n = hi - lo
+    isz = stacked.dtype.itemsize
+    d_raw = DeviceBuffer(isz * T * n)
+    d_mask = d_idx = d_out = None
+    try:
+        if lo == 0 and hi == stacked.shape[1]:
+            h.memcpy_h2d(d_raw.ptr, stacked)
+        else:
+            h.memcpy2d_h2d(d_raw.ptr, stacked, lo, n)
+        d_mask = DeviceBuffer(n)
+        h.land_mask(d_raw.ptr, isz, T, n, n, int(bool(anynans)), d_mask.ptr)
+        h.stream_sync(0)
+        keep = d_mask.to_array((n,), np.uint8) != 0
+        nk = int(keep.sum())
+        if nk == n:
+            out, d_raw = d_raw, None
+            return out, keep
+        if nk == 0:
+            return None, keep
+        d_idx = DeviceBuffer.from_array(np.nonzero(keep)[0].astype(np.int64))
+        d_out = DeviceBuffer(isz * T * nk)
+        h.gather_cells(d_raw.ptr, isz, T, n, d_idx.ptr, nk, d_out.ptr, nk)
+        h.stream_sync(0)
+        out, d_out = d_out, None
+        return out, keep
+    finally:
+        for b in (d_raw, d_mask, d_idx, d_out):
+            if b is not None:
+                b.free()
+
+
+def _grid_batch(stacked, max_batch_bytes, per_cell_extra=0):
+    """cells per slab so that raw + compacted copies (+ per-cell extras) stay below the budget"""
+    T, N = stacked.shape
+    per_cell = 2 * T * stacked.dtype.itemsize + per_cell_extra
+    return int(max(1, min(N, max_batch_bytes // max(per_cell, 1))))
+
+
+def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
+                          tstep, coldSpells=False, kernel="auto", nchunks=0, max_batch_bytes=64 << 30,
+                          narrowing=True):
+    """land_check() + calc_clim() for an UNCOMPACTED stacked host array (T, N): the land mask and
+    the compaction run on the device too, so the host only hands the array over (for a global
+    grid the numpy dropna costs tens of times the kernels).  Returns (keep[N] bool, doys[D],
+    thresh[D, C], seas[D, C]) with C = keep.sum() cells in stacked order."""
+    stacked = np.asarray(stacked)
+    if stacked.dtype not in (np.float32, np.float64):
+        stacked = stacked.astype(np.float64)
+    stacked = np.ascontiguousarray(stacked)
+    T, N = stacked.shape
+    h = hip()
+    plan = Plan(doy, windowHalfWidth, kernel=kernel, nchunks=nchunks, narrowing=narrowing)
+    D = plan.D
+    isz = stacked.dtype.itemsize
+    feb29_fix = tstep is False
+    finish = feb29_fix or smoothPercentile
+    keeps, ths, ses = [], [], []
+    try:
+        cb = _grid_batch(stacked, max_batch_bytes, per_cell_extra=4 * D * 8)
+        for lo in range(0, N, cb):
+            hi = min(N, lo + cb)
+            d_ts, keep = compact_columns(stacked, lo, hi, anynans)
+            keeps.append(keep)
+            if d_ts is None:
+                continue
+            n = int(keep.sum())
+            bufs = [d_ts]
+            try:
+                raw_th, raw_se = DeviceBuffer(8 * D * n), DeviceBuffer(8 * D * n)
+                bufs += [raw_th, raw_se]
+                clim_raw(plan, d_ts, isz, n, pctile / 100.0, coldSpells, raw_th, raw_se)
+                out_th, out_se = raw_th, raw_se
+                if finish:
+                    out_th, out_se = DeviceBuffer(8 * D * n), DeviceBuffer(8 * D * n)
+                    bufs += [out_th, out_se]
+                    clim_finish(plan, raw_th, raw_se, n, feb29_fix, smoothPercentile, smoothPercentileWidth,
+                                out_th, out_se)
+                h.stream_sync(0)
+                ths.append(out_th.to_array((D, n), np.float64))
+                ses.append(out_se.to_array((D, n), np.float64))
+            finally:
+                for b in bufs:
+                    b.free()
+        keep = np.concatenate(keeps) if keeps else np.zeros(0, dtype=bool)
+        if not keep.any():
+            raise XmhwException("All points of grid are either land or NaN")     # identify.py:527-528
+        return keep, plan.doys.copy(), np.concatenate(ths, axis=1), np.concatenate(ses, axis=1)
+    finally:
+        plan.destroy()
