@@ -217,6 +217,14 @@ def test_device_side_land_mask_and_compaction_equal_host_path(oisst):
                 npt.assert_array_equal(r1["keep"], keep)
                 npt.assert_array_equal(r1["offsets"], r0["offsets"])
                 npt.assert_array_equal(r1["table"], r0["table"])
+    # a rank's block of columns (sharded runs): same cells as the corresponding part of the whole
+    kf, df, thf, sef = calc_clim_grid_device(stacked, doy, False, 90, 5, True, 31, False)
+    for c0, c1 in ((0, 11), (11, 32), (5, 6), (30, 32)):
+        kp, dp, thp, sep = calc_clim_grid_device(stacked, doy, False, 90, 5, True, 31, False, columns=(c0, c1))
+        npt.assert_array_equal(kp, kf[c0:c1])
+        a, b = int(kf[:c0].sum()), int(kf[:c1].sum())
+        npt.assert_array_equal(thp, thf[:, a:b])
+        npt.assert_array_equal(sep, sef[:, a:b])
     # all land -> the reference's exception, raised after the device mask
     from xmhw_amd import XmhwException
     with pytest.raises(XmhwException):

@@ -136,3 +136,76 @@ def test_sharded_detect_equals_single(tmp_path, world):
     for k, v in inter.data_vars.items():
         assert got["inter_" + k].dtype == v.dtype, k
         np.testing.assert_array_equal(got["inter_" + k], v, err_msg=k)
+
+
+def _grid_standin(stacked, doy, anynans, pctile, w, smooth, width, tstep, cold=False, columns=None):
+    """numpy stand-in for device.calc_clim_grid_device (mask + compaction + oracle) on a column range"""
+    import oracle_fast as fast
+    c0, c1 = columns if columns is not None else (0, stacked.shape[1])
+    sub = stacked[:, c0:c1]
+    nan = np.isnan(sub)
+    keep = ~(nan.any(axis=0) if anynans else nan.all(axis=0))
+    doys = np.unique(np.asarray(doy, dtype=np.int64))
+    if not keep.any():
+        return keep, doys, np.zeros((doys.shape[0], 0)), np.zeros((doys.shape[0], 0))
+    d, th, se = fast.threshold_cells_fast(np.ascontiguousarray(sub[:, keep]), doy, pctile=pctile, windowHalfWidth=w,
+                                          smoothPercentile=smooth, smoothPercentileWidth=width, tstep=tstep,
+                                          coldSpells=cold)
+    return keep, d, th, se
+
+
+def _grid_worker(rank, world, port, outdir):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from xmhw_amd import GridSeries, XmhwException
+    from xmhw_amd.sharded import threshold_sharded
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "oisst_2003_2004.npz"))
+    time = np.datetime64("2003-01-01") + g["time"].astype("timedelta64[D]")
+    temp = GridSeries(g["sst"], ("time", "lat", "lon"), {"time": time, "lat": g["lat"], "lon": g["lon"]})
+    ds = threshold_sharded(temp, _grid_compute=_grid_standin, smoothPercentileWidth=11)
+    if rank == 0:
+        np.savez(os.path.join(outdir, "grid.npz"), thresh=ds["thresh"], seas=ds["seas"], lat=ds.coords["lat"],
+                 lon=ds.coords["lon"])
+    else:
+        assert ds is None
+    # an all-land grid raises on EVERY rank (the masks are all-gathered), nobody hangs
+    land = GridSeries(np.full((731, 3, 2), np.nan, np.float32), ("time", "lat", "lon"),
+                      {"time": time, "lat": np.arange(3), "lon": np.arange(2)})
+    try:
+        threshold_sharded(land, _grid_compute=_grid_standin)
+        raise AssertionError("expected XmhwException")
+    except XmhwException:
+        pass
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_grid_path_equals_single(tmp_path, world):
+    """Every rank masks and compacts only its own block of the uncompacted grid columns (ranks end
+    up with different numbers of ocean cells; one block of the fixture is all land for world=3)."""
+    import torch.multiprocessing as mp
+    import oracle_fast as fast
+    from xmhw_amd import GridSeries
+    from xmhw_amd.api import _threshold
+
+    mp.spawn(_grid_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "grid.npz")
+
+    def compute(ts, doy, pctile, w, smooth, width, tstep, cold=False):
+        return fast.threshold_cells_fast(ts, doy, pctile=pctile, windowHalfWidth=w, smoothPercentile=smooth,
+                                         smoothPercentileWidth=width, tstep=tstep, coldSpells=cold)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "oisst_2003_2004.npz"))
+    time = np.datetime64("2003-01-01") + g["time"].astype("timedelta64[D]")
+    temp = GridSeries(g["sst"], ("time", "lat", "lon"), {"time": time, "lat": g["lat"], "lon": g["lon"]})
+    ref = _threshold(temp, compute, smoothPercentileWidth=11)
+    np.testing.assert_array_equal(got["thresh"], ref["thresh"])
+    np.testing.assert_array_equal(got["seas"], ref["seas"])
+    np.testing.assert_array_equal(got["lat"], ref.coords["lat"])
+    np.testing.assert_array_equal(got["lon"], ref.coords["lon"])

@@ -217,11 +217,13 @@ def _grid_batch(stacked, max_batch_bytes, per_cell_extra=0):
 
 def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
                           tstep, coldSpells=False, kernel="auto", nchunks=0, max_batch_bytes=64 << 30,
-                          narrowing=True):
+                          narrowing=True, columns=None):
     """land_check() + calc_clim() for an UNCOMPACTED stacked host array (T, N): the land mask and
     the compaction run on the device too, so the host only hands the array over (for a global
     grid the numpy dropna costs tens of times the kernels).  Returns (keep[N] bool, doys[D],
-    thresh[D, C], seas[D, C]) with C = keep.sum() cells in stacked order."""
+    thresh[D, C], seas[D, C]) with C = keep.sum() cells in stacked order.
+    ``columns=(c0, c1)`` restricts the work to that column range (a rank's slab of a sharded run:
+    keep then has c1 - c0 entries and an all-land slab is not an error)."""
     stacked = np.asarray(stacked)
     if stacked.dtype not in (np.float32, np.float64):
         stacked = stacked.astype(np.float64)
@@ -236,8 +238,9 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
     keeps, ths, ses = [], [], []
     try:
         cb = _grid_batch(stacked, max_batch_bytes, per_cell_extra=4 * D * 8)
-        for lo in range(0, N, cb):
-            hi = min(N, lo + cb)
+        c0, c1 = (0, N) if columns is None else (int(columns[0]), int(columns[1]))
+        for lo in range(c0, c1, cb):
+            hi = min(c1, lo + cb)
             d_ts, keep = compact_columns(stacked, lo, hi, anynans)
             keeps.append(keep)
             if d_ts is None:
@@ -262,7 +265,9 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
                     b.free()
         keep = np.concatenate(keeps) if keeps else np.zeros(0, dtype=bool)
         if not keep.any():
-            raise XmhwException("All points of grid are either land or NaN")     # identify.py:527-528
+            if columns is None:
+                raise XmhwException("All points of grid are either land or NaN")     # identify.py:527-528
+            return keep, plan.doys.copy(), np.zeros((D, 0)), np.zeros((D, 0))
         return keep, plan.doys.copy(), np.concatenate(ths, axis=1), np.concatenate(ses, axis=1)
     finally:
         plan.destroy()

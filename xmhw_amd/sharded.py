@@ -16,7 +16,8 @@ import numpy as np
 
 from . import api
 from .detect import INTER_VARIABLES, _detect
-from .device import calc_clim_device
+from .device import calc_clim_device, calc_clim_grid_device
+from .exception import XmhwException
 
 
 def slab_bounds(ncells, world_size):
@@ -93,13 +94,67 @@ def make_sharded_compute(group=None, dst=0, device=None, compute=None):
     return sharded
 
 
-def threshold_sharded(temp, group=None, dst=0, device=None, _compute=None, **kwargs):
-    """threshold() over all ranks of ``group``; every rank passes the same
-    ``temp`` (or at least the same land mask); rank ``dst`` gets the Dataset,
-    the others None."""
+def make_sharded_grid_compute(group=None, dst=0, device=None, grid_compute=None):
+    """A drop-in for device.calc_clim_grid_device: every rank takes a contiguous block of the
+    UNCOMPACTED stacked columns, masks / compacts / computes it on its own GPU (so no rank runs
+    land_check() over the whole grid on the host), then the masks are all-gathered (every rank
+    needs the surviving cells for the output grid) and the variable-width result blocks gathered
+    to ``dst``."""
+    import torch
     import torch.distributed as dist
 
-    ds = api._threshold(temp, make_sharded_compute(group, dst, device, _compute), **kwargs)
+    inner = grid_compute or calc_clim_grid_device
+
+    def sharded(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
+                tstep, coldSpells=False):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        dev = _device_for(group, device)
+        N = stacked.shape[1]
+        bounds = slab_bounds(N, world)
+        lo, hi = bounds[rank]
+        keep_r, doys, th_r, se_r = inner(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile,
+                                         smoothPercentileWidth, tstep, coldSpells, columns=(lo, hi))
+        D = doys.shape[0]
+        width = max(b - a for a, b in bounds)
+        mine = torch.zeros(width, dtype=torch.uint8, device=dev)
+        mine[: hi - lo] = torch.as_tensor(keep_r.astype(np.uint8), device=dev)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        keep = np.concatenate([parts[r][: b - a].cpu().numpy() != 0 for r, (a, b) in enumerate(bounds)])
+        if not keep.any():
+            raise XmhwException("All points of grid are either land or NaN")     # on every rank alike
+        counts = [int(keep[a:b].sum()) for a, b in bounds]
+        nmax = max(max(counts), 1)
+        block = torch.zeros((2, D, nmax), dtype=torch.float64, device=dev)
+        if counts[rank]:
+            block[0, :, : counts[rank]] = torch.as_tensor(th_r, device=dev)
+            block[1, :, : counts[rank]] = torch.as_tensor(se_r, device=dev)
+        out = [torch.empty_like(block) for _ in range(world)] if rank == dst else None
+        dist.gather(block, out, dst=dst, group=group)
+        C = int(keep.sum())
+        if rank != dst:
+            th = se = np.full((D, C), np.nan)
+        else:
+            full = np.concatenate([out[r][:, :, : counts[r]].cpu().numpy() for r in range(world)], axis=2)
+            th, se = full[0], full[1]
+        return keep, doys, th, se
+
+    return sharded
+
+
+def threshold_sharded(temp, group=None, dst=0, device=None, _compute=None, _grid_compute=None, **kwargs):
+    """threshold() over all ranks of ``group``; every rank passes the same ``temp``; rank ``dst``
+    gets the Dataset, the others None.  The ranks split the uncompacted grid columns and each
+    masks and compacts its own block on its GPU; ``_compute`` (test hook, compact-array stand-in)
+    selects the older path in which every rank runs land_check() on the host first."""
+    import torch.distributed as dist
+
+    if _compute is not None:
+        ds = api._threshold(temp, make_sharded_compute(group, dst, device, _compute), **kwargs)
+    else:
+        # a single-point series has no grid to split: the compact-array path handles it
+        ds = api._threshold(temp, make_sharded_compute(group, dst, device, None),
+                            grid_compute=make_sharded_grid_compute(group, dst, device, _grid_compute), **kwargs)
     return ds if dist.get_rank(group) == dst else None
 
 
