@@ -18,7 +18,8 @@ def agg(d, key):
             if r['Counter_Name'] in ('TCC_EA0_RDREQ_sum', 'WRITE_SIZE'): n += 1
     return a, max(n, 1)
 T, N = 14610, $N
-for key, alg_r, alg_w in (('detect_events', T*4 + 366*8, T*13), ('event_stats', T*8 + 2*366*8, 14*31*8), ('count_events', T*4, 4)):
+for key, alg_r, alg_w in (('detect_events', T*4 + 366*8, T*13), ('event_stats<', T*8 + 2*366*8, 14*31*8), ('count_events', T*4, 4),
+                          ('exceed_bits', T*4 + 366*4, T/8), ('events_from_bits', T/8, 14*4*8/2), ('event_stats_sparse', 14*10*24, 14*31*8)):
     a, n = agg('rd', key)
     w, nw = agg('wr', key)
     by = (32*a['TCC_EA0_RDREQ_32B_sum'] + 64*a['TCC_EA0_RDREQ_64B_sum'] + 128*a['TCC_EA0_RDREQ_128B_sum']) / n
