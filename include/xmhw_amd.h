@@ -45,6 +45,7 @@ const char *xmhw_arch(void);            /* "gfx950"                             
 const char *xmhw_last_error(void);      /* message of the last failure (thread)   */
 int xmhw_device_count(int *count);
 int xmhw_set_device(int device);
+int xmhw_get_device(int *device);
 int xmhw_device_info(int device, char *name, int name_len, int *compute_units,
                      uint64_t *hbm_bytes);
 

@@ -208,23 +208,33 @@ def test_device_side_land_mask_and_compaction_equal_host_path(oisst):
             d0, th0, se0 = calc_clim_device(ts, doy, 90, 5, True, 31, False)
             for budget in (64 << 30, 60_000):                # one slab / a handful of columns per slab
                 k1, d1, th1, se1 = calc_clim_grid_device(stacked, doy, anynans, 90, 5, True, 31, False,
-                                                         max_batch_bytes=budget)
+                                                         max_batch_bytes=budget, scatter=False)
                 npt.assert_array_equal(k1, keep)
                 npt.assert_array_equal(th1, th0)
                 npt.assert_array_equal(se1, se0)
+                # default: results placed back on the grid by the device, NaN at the dropped cells
+                k2, d2, th2, se2 = calc_clim_grid_device(stacked, doy, anynans, 90, 5, True, 31, False,
+                                                         max_batch_bytes=budget)
+                assert th2.shape == (366, stacked.shape[1]) and np.isnan(th2[:, ~keep]).all()
+                npt.assert_array_equal(th2[:, keep], th0)
+                npt.assert_array_equal(se2[:, keep], se0)
                 r0 = detect_cells(ts, se0, th0, doy, d0, 5, True, 2)
                 r1 = detect_grid(stacked, anynans, se0, th0, doy, d0, 5, True, 2, max_batch_bytes=budget)
                 npt.assert_array_equal(r1["keep"], keep)
                 npt.assert_array_equal(r1["offsets"], r0["offsets"])
                 npt.assert_array_equal(r1["table"], r0["table"])
+                # climatologies handed over on the grid too (NaN at land): masked / compacted on the device
+                r2 = detect_grid(stacked, anynans, se2, th2, doy, d0, 5, True, 2, max_batch_bytes=budget,
+                                 clim_stacked=True)
+                npt.assert_array_equal(r2["offsets"], r0["offsets"])
+                npt.assert_array_equal(r2["table"], r0["table"])
     # a rank's block of columns (sharded runs): same cells as the corresponding part of the whole
     kf, df, thf, sef = calc_clim_grid_device(stacked, doy, False, 90, 5, True, 31, False)
     for c0, c1 in ((0, 11), (11, 32), (5, 6), (30, 32)):
         kp, dp, thp, sep = calc_clim_grid_device(stacked, doy, False, 90, 5, True, 31, False, columns=(c0, c1))
         npt.assert_array_equal(kp, kf[c0:c1])
-        a, b = int(kf[:c0].sum()), int(kf[:c1].sum())
-        npt.assert_array_equal(thp, thf[:, a:b])
-        npt.assert_array_equal(sep, sef[:, a:b])
+        npt.assert_array_equal(thp, thf[:, c0:c1])
+        npt.assert_array_equal(sep, sef[:, c0:c1])
     # all land -> the reference's exception, raised after the device mask
     from xmhw_amd import XmhwException
     with pytest.raises(XmhwException):

@@ -146,12 +146,16 @@ def _grid_standin(stacked, doy, anynans, pctile, w, smooth, width, tstep, cold=F
     nan = np.isnan(sub)
     keep = ~(nan.any(axis=0) if anynans else nan.all(axis=0))
     doys = np.unique(np.asarray(doy, dtype=np.int64))
+    th_full = np.full((doys.shape[0], c1 - c0), np.nan)
+    se_full = np.full((doys.shape[0], c1 - c0), np.nan)
     if not keep.any():
-        return keep, doys, np.zeros((doys.shape[0], 0)), np.zeros((doys.shape[0], 0))
+        return keep, doys, th_full, se_full
     d, th, se = fast.threshold_cells_fast(np.ascontiguousarray(sub[:, keep]), doy, pctile=pctile, windowHalfWidth=w,
                                           smoothPercentile=smooth, smoothPercentileWidth=width, tstep=tstep,
                                           coldSpells=cold)
-    return keep, d, th, se
+    th_full[:, keep] = th
+    se_full[:, keep] = se
+    return keep, d, th_full, se_full
 
 
 def _grid_worker(rank, world, port, outdir):

@@ -11,8 +11,9 @@ from .api import threshold, threshold_array, GridSeries, ClimDataset
 from .calendar import add_doy, get_calendar
 from .landmask import land_check
 from .detect import detect, EventDataset, InterDataset, climatology_series
+from .device import release_device_cache
 
 __all__ = ["threshold", "threshold_array", "GridSeries", "ClimDataset", "XmhwException",
            "add_doy", "get_calendar", "land_check", "detect", "EventDataset", "InterDataset",
-           "climatology_series"]
+           "climatology_series", "release_device_cache"]
 __version__ = "0.1.0"

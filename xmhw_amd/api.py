@@ -137,8 +137,9 @@ def _threshold(temp, compute, tdim="time", climatologyPeriod=[None, None], pctil
     """Host side of threshold() around a device stage ``compute`` with the signature of
     ``device.calc_clim_device``.  The public threshold() passes the HIP path; the CPU tests of
     the host logic and of the multi-rank sharding pass a stand-in here.  ``grid_compute``
-    (signature of ``device.calc_clim_grid_device``) additionally takes land_check()'s mask and
-    compaction off the host; without it they run in numpy (landmask.land_check)."""
+    (signature of ``device.calc_clim_grid_device``, returning full-width (D, N) arrays) additionally
+    takes land_check()'s mask, the compaction and the final placement on the grid off the host;
+    without it they run in numpy (landmask.land_check, boolean-mask assignment)."""
     if smoothPercentileWidth % 2 == 0:                       # xmhw.py:103-104
         raise XmhwException("smoothPercentileWidth should be odd")
     is_xr = _is_xarray(temp)
@@ -204,10 +205,13 @@ def _threshold(temp, compute, tdim="time", climatologyPeriod=[None, None], pctil
         odims = ("doy",)
         ocoords = {"doy": doys}
     else:
-        full_th = np.full((D, keep.shape[0]), np.nan)
-        full_se = np.full((D, keep.shape[0]), np.nan)
-        full_th[:, keep] = th
-        full_se[:, keep] = se
+        if on_device:
+            full_th, full_se = th, se            # already on the grid, NaN at the dropped cells
+        else:
+            full_th = np.full((D, keep.shape[0]), np.nan)
+            full_se = np.full((D, keep.shape[0]), np.nan)
+            full_th[:, keep] = th
+            full_se[:, keep] = se
         thg = full_th.reshape((D,) + sshape)
         seg = full_se.reshape((D,) + sshape)
         odims = ("doy",) + tuple(sdims)
@@ -218,8 +222,9 @@ def _threshold(temp, compute, tdim="time", climatologyPeriod=[None, None], pctil
         for ax, d in enumerate(sdims):
             other = tuple(i for i in range(len(sdims)) if i != ax)
             alive = keepg.any(axis=other) if other else keepg
-            thg = np.compress(alive, thg, axis=ax + 1)
-            seg = np.compress(alive, seg, axis=ax + 1)
+            if not alive.all():
+                thg = np.compress(alive, thg, axis=ax + 1)
+                seg = np.compress(alive, seg, axis=ax + 1)
             ocoords[d] = np.asarray(coords[d])[alive]
     q = pctile / 100.0
     out_coord_attrs = {"doy": doy_attrs}

@@ -477,6 +477,11 @@ int xmhw_set_device(int device) {
     HIP_TRY(hipSetDevice(device));
     return XMHW_OK;
 }
+int xmhw_get_device(int* device) {
+    if (!device) return fail(XMHW_ERR_INVALID, "device is NULL");
+    HIP_TRY(hipGetDevice(device));
+    return XMHW_OK;
+}
 int xmhw_device_info(int device, char* name, int name_len, int* compute_units, uint64_t* hbm_bytes) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));

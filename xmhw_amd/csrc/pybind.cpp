@@ -44,6 +44,7 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     m.def("arch", []() { return std::string(xmhw_arch()); });
     m.def("device_count", []() { int n = 0; check(xmhw_device_count(&n)); return n; });
     m.def("set_device", [](int d) { check(xmhw_set_device(d)); });
+    m.def("get_device", []() { int d = 0; check(xmhw_get_device(&d)); return d; });
     m.def("device_info", [](int d) {
         char name[256] = {0};
         int cus = 0;

@@ -278,16 +278,23 @@ def _detect(temp, th, se, compute, tdim="time", minDuration=5, joinGaps=True, ma
         # land_check on all three (xmhw.py:398-402); cells pair up by POSITION after each dropna
         # (stack(create_index=False), then ts.sel(cell=c) / th.sel(cell=c): xmhw.py:437-443)
         if on_device:
+            # the device masks and compacts all three; here they are only stacked (views / reshapes)
             stacked, sdims, sshape = landmask.stack_cells(values, dims, tdim)
+            thc, thsd, thshape = landmask.stack_cells(thv, thdims, "doy")
+            sec, sesd, seshape = landmask.stack_cells(sev, sedims, "doy")
+            if thsd != sdims or sesd != sdims:
+                raise XmhwException(f"temp, th and se are not on the same dimensions: {sdims}, {thsd}, {sesd}")
+            # (threshold() drops all-land grid lines, so th / se may live on a smaller grid than temp: the
+            # survivors pair up by position, whatever the grids)
+            clim_stacked = True
             ts = None
         else:
             ts, keep, sdims, sshape = landmask.land_check(values, dims, tdim, anynans)
-        thc, _, thsd, _ = landmask.land_check(thv, thdims, "doy", anynans)
-        sec, _, sesd, _ = landmask.land_check(sev, sedims, "doy", anynans)
-        nts = thc.shape[1] if on_device else ts.shape[1]        # the device path checks its own count
-        if thc.shape[1] != nts or sec.shape[1] != nts or thsd != sdims or sesd != sdims:
-            raise XmhwException("temp, th and se do not have the same ocean cells: "
-                                + f"{nts}, {thc.shape[1]}, {sec.shape[1]} cells over dims {sdims}, {thsd}, {sesd}")
+            thc, _, thsd, _ = landmask.land_check(thv, thdims, "doy", anynans)
+            sec, _, sesd, _ = landmask.land_check(sev, sedims, "doy", anynans)
+            if thc.shape[1] != ts.shape[1] or sec.shape[1] != ts.shape[1] or thsd != sdims or sesd != sdims:
+                raise XmhwException("temp, th and se do not have the same ocean cells: "
+                                    + f"{ts.shape[1]}, {thc.shape[1]}, {sec.shape[1]} cells over dims {sdims}, {thsd}, {sesd}")
     doys = np.asarray(thcoords["doy"])
     if not np.array_equal(doys, np.asarray(secoords["doy"])):
         raise XmhwException("th and se have different doy coordinates")
@@ -295,7 +302,7 @@ def _detect(temp, th, se, compute, tdim="time", minDuration=5, joinGaps=True, ma
 
     if on_device:
         res = grid_compute(stacked, anynans, sec, thc, doy, doys, minDuration, joinGaps, maxGap, coldSpells,
-                           intermediate)
+                           intermediate, clim_stacked=clim_stacked)
         keep = res["keep"]
     else:
         res = compute(ts, sec, thc, doy, doys, minDuration, joinGaps, maxGap, coldSpells, intermediate)

@@ -93,19 +93,18 @@ def _check_inputs(ts, seas, thresh, doy, doys):
     return ts, seas, thresh, rows.astype(np.int32)
 
 
-def _table_only_device(h, d_ts, isz, seas, thresh, rows, T, n, neg, minDuration, joinGaps, maxGap):
-    """Event table of n cells whose dense (T, n) series is already on the device, without per-step
+def _table_only_device(h, d_ts, isz, se_ptr, th_ptr, ldc, D, rows, T, n, neg, minDuration, joinGaps, maxGap):
+    """Event table of n cells whose dense (T, n) series and climatologies (device pointers to the
+    first of the n columns, leading dimension ldc) are already on the device, without per-step
     outputs: exceedance bits -> run walk (count, host prefix sum, fill) -> one thread per event
-    (csrc/kernels_events.hip).  seas / thresh: host (D, n)."""
+    (csrc/kernels_events.hip)."""
     bufs = []
     try:
-        d_th = DeviceBuffer.from_array(thresh); bufs.append(d_th)
-        d_se = DeviceBuffer.from_array(seas); bufs.append(d_se)
         W = (T + 63) // 64
         d_bits = DeviceBuffer(8 * W * n); bufs.append(d_bits)
         d_n = DeviceBuffer(4 * n); bufs.append(d_n)
         try:
-            h.exceed_bits(d_ts.ptr, isz, T, n, n, d_th.ptr, n, thresh.shape[0], rows, neg, d_bits.ptr, n)
+            h.exceed_bits(d_ts.ptr, isz, T, n, n, th_ptr, ldc, D, rows, neg, d_bits.ptr, n)
             h.events_from_bits(d_bits.ptr, T, n, n, int(minDuration), int(bool(joinGaps)), int(maxGap), 0, d_n.ptr, 0)
         except h.InvalidArgument as e:
             raise XmhwException(str(e)) from e
@@ -120,7 +119,7 @@ def _table_only_device(h, d_ts, isz, seas, thresh, rows, T, n, neg, minDuration,
         d_tab = DeviceBuffer(8 * ntot * h.EVENT_COLUMNS); bufs.append(d_tab)
         h.events_from_bits(d_bits.ptr, T, n, n, int(minDuration), int(bool(joinGaps)), int(maxGap), d_off.ptr, 0,
                            d_tab.ptr)
-        h.event_stats_sparse(d_ts.ptr, isz, T, n, n, d_se.ptr, d_th.ptr, n, rows, neg, ntot, d_tab.ptr)
+        h.event_stats_sparse(d_ts.ptr, isz, T, n, n, se_ptr, th_ptr, ldc, rows, neg, ntot, d_tab.ptr)
         return d_tab.to_array((ntot, h.EVENT_COLUMNS), np.float64), counts
     finally:
         for b in bufs:
@@ -128,11 +127,16 @@ def _table_only_device(h, d_ts, isz, seas, thresh, rows, T, n, neg, minDuration,
 
 
 def _table_only_batch(h, ts, seas, thresh, rows, T, n, isz, neg, minDuration, joinGaps, maxGap):
-    d_ts = DeviceBuffer.from_array(ts)
+    bufs = []
     try:
-        return _table_only_device(h, d_ts, isz, seas, thresh, rows, T, n, neg, minDuration, joinGaps, maxGap)
+        d_ts = DeviceBuffer.from_array(ts); bufs.append(d_ts)
+        d_se = DeviceBuffer.from_array(seas); bufs.append(d_se)
+        d_th = DeviceBuffer.from_array(thresh); bufs.append(d_th)
+        return _table_only_device(h, d_ts, isz, d_se.ptr, d_th.ptr, n, thresh.shape[0], rows, T, n, neg, minDuration,
+                                  joinGaps, maxGap)
     finally:
-        d_ts.free()
+        for b in bufs:
+            b.free()
 
 
 def detect_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
@@ -228,62 +232,99 @@ def detect_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxG
 
 
 def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
-                intermediate=False, max_batch_bytes=64 << 30):
+                intermediate=False, max_batch_bytes=None, clim_stacked=False):
     """detect_cells() for an UNCOMPACTED stacked host series (T, N): land_check()'s mask and
-    compaction of the series run on the device (device.compact_columns), slab by slab; seas / thresh
-    are the already compacted (D, C) climatologies, whose cells pair with the surviving columns by
-    position (xmhw/xmhw.py:398-402, 437-443).  Returns detect_cells()'s dict plus keep[N]."""
+    compaction run on the device (device.compact_columns), slab by slab.  The climatologies are
+    either already compacted (D, C) arrays, or - clim_stacked=True - uncompacted (D, N) arrays whose
+    own land masks and compaction then happen on the device as well.  Cells of the series and of
+    the climatologies pair up by POSITION among the survivors (xmhw/xmhw.py:398-402, 437-443).
+    Returns detect_cells()'s dict plus keep[N]."""
     from .device import _grid_batch, compact_columns
     stacked = np.asarray(stacked)
     if stacked.dtype not in (np.float32, np.float64):
         stacked = stacked.astype(np.float64)
     stacked = np.ascontiguousarray(stacked)
     T, N = stacked.shape
-    C = thresh.shape[1]
-    if intermediate:
-        # the per-step columns come back to the host anyway: compact there and take the per-step kernels
-        nan = np.isnan(stacked)
-        keep = ~(nan.any(axis=0) if anynans else nan.all(axis=0))
-        if not keep.any():
+
+    def host_compact(a):
+        nan = np.isnan(a)
+        k = ~(nan.any(axis=0) if anynans else nan.all(axis=0))
+        if not k.any():
             raise XmhwException("All points of grid are either land or NaN")
-        if int(keep.sum()) != C:
-            raise XmhwException(f"temp has {int(keep.sum())} ocean cells, th and se have {C}")
-        r = detect_cells(np.ascontiguousarray(stacked[:, keep]), seas, thresh, doy, doys, minDuration, joinGaps,
-                         maxGap, coldSpells, True, max_batch_bytes)
+        return np.ascontiguousarray(a[:, k]), k
+
+    def host_path(seas_c, thresh_c):
+        # positional pairing needs the global compact order: compact the series on the host
+        ts_c, keep = host_compact(stacked)
+        if ts_c.shape[1] != thresh_c.shape[1] or seas_c.shape[1] != thresh_c.shape[1]:
+            raise XmhwException(f"temp, th and se do not have the same ocean cells: {ts_c.shape[1]}, "
+                                f"{thresh_c.shape[1]}, {seas_c.shape[1]}")
+        r = detect_cells(ts_c, seas_c, thresh_c, doy, doys, minDuration, joinGaps, maxGap, coldSpells, intermediate,
+                         max_batch_bytes if max_batch_bytes is not None else 64 << 30)
         r["keep"] = keep
         return r
-    _, seas, thresh, rows = _check_inputs(np.zeros((T, C), dtype=stacked.dtype), seas, thresh, doy, doys)
+
+    if intermediate:
+        # the per-step columns come back to the host anyway: compact there and take the per-step kernels
+        if clim_stacked:
+            return host_path(host_compact(np.asarray(seas, dtype=np.float64))[0],
+                             host_compact(np.asarray(thresh, dtype=np.float64))[0])
+        return host_path(seas, thresh)
+    seas = np.ascontiguousarray(seas, dtype=np.float64)
+    thresh = np.ascontiguousarray(thresh, dtype=np.float64)
+    if seas.ndim != 2 or thresh.ndim != 2 or seas.shape[0] != thresh.shape[0]:
+        raise XmhwException("seas and thresh must be (D, cells) arrays")
+    D = thresh.shape[0]
+    _, _, _, rows = _check_inputs(np.zeros((T, 1), dtype=stacked.dtype), seas[:, :1], thresh[:, :1], doy, doys)
     h = hip()
     isz = stacked.dtype.itemsize
     neg = int(bool(coldSpells))
-    D = thresh.shape[0]
-    cb = _grid_batch(stacked, max_batch_bytes, per_cell_extra=2 * D * 8 + T // 8 + 64)
+    clim_bufs = []
     keeps, tables, counts_all = [], [], []
     k0 = 0
-    for lo in range(0, N, cb):
-        hi = min(N, lo + cb)
-        d_ts, keep = compact_columns(stacked, lo, hi, anynans)
-        keeps.append(keep)
-        n = int(keep.sum())
-        if d_ts is None:
-            continue
-        try:
-            if k0 + n > C:
-                raise XmhwException(f"temp has more ocean cells than th and se ({C})")
-            tab, counts = _table_only_device(h, d_ts, isz, np.ascontiguousarray(seas[:, k0:k0 + n]),
-                                             np.ascontiguousarray(thresh[:, k0:k0 + n]), rows, T, n, neg,
-                                             minDuration, joinGaps, maxGap)
-        finally:
-            d_ts.free()
-        tables.append(tab)
-        counts_all.append(counts)
-        k0 += n
+    try:
+        # the climatologies are small next to the series: whole on the device, compacted there if needed
+        if clim_stacked:
+            d_th, keep_th = compact_columns(thresh, 0, thresh.shape[1], anynans)
+            clim_bufs += [d_th] if d_th is not None else []
+            d_se, keep_se = compact_columns(seas, 0, seas.shape[1], anynans)
+            clim_bufs += [d_se] if d_se is not None else []
+            C, Cse = int(keep_th.sum()), int(keep_se.sum())
+            if C == 0 or Cse == 0:
+                raise XmhwException("All points of grid are either land or NaN")
+        else:
+            d_th = DeviceBuffer.from_array(thresh); clim_bufs.append(d_th)
+            d_se = DeviceBuffer.from_array(seas); clim_bufs.append(d_se)
+            C, Cse = thresh.shape[1], seas.shape[1]
+        if C != Cse:
+            raise XmhwException(f"th and se do not have the same ocean cells: {C}, {Cse}")
+        cb = _grid_batch(stacked, max_batch_bytes, per_cell_extra=6 * D * 8 + T // 8 + 64)
+        for lo in range(0, N, cb):
+            hi = min(N, lo + cb)
+            d_ts, keep = compact_columns(stacked, lo, hi, anynans)
+            keeps.append(keep)
+            n = int(keep.sum())
+            if d_ts is None:
+                continue
+            try:
+                if k0 + n > C:
+                    raise XmhwException(f"temp has more ocean cells than th and se ({C})")
+                tab, counts = _table_only_device(h, d_ts, isz, d_se.ptr + 8 * k0, d_th.ptr + 8 * k0, C, D, rows, T, n,
+                                                 neg, minDuration, joinGaps, maxGap)
+            finally:
+                d_ts.free()
+            tables.append(tab)
+            counts_all.append(counts)
+            k0 += n
+    finally:
+        for b in clim_bufs:
+            b.free()
     keep = np.concatenate(keeps) if keeps else np.zeros(0, dtype=bool)
     if not keep.any():
         raise XmhwException("All points of grid are either land or NaN")
     if k0 != C:
         raise XmhwException(f"temp has {k0} ocean cells, th and se have {C}")
-    offsets = np.zeros(C + 1, dtype=np.int64)
+    offsets = np.zeros(k0 + 1, dtype=np.int64)
     np.cumsum(np.concatenate(counts_all), out=offsets[1:])
     table = np.concatenate(tables, axis=0) if tables else np.zeros((0, len(EVENT_COLUMNS)))
     return dict(table=table, offsets=offsets, inter=None, keep=keep)

@@ -8,13 +8,47 @@ from .exception import XmhwException
 KERNELS = {"auto": 0, "ring": 1, "generic": 2}
 
 
+# Large allocations are kept for the next call instead of being returned to the driver: hipMalloc of
+# tens of GB costs about a second (page tables), which is as much as the upload of a global grid and
+# far more than the kernels.  At most _POOL_SLOTS buffers of >= _POOL_MIN bytes are held;
+# release_device_cache() frees them.
+_POOL = []
+_POOL_SLOTS = 4
+_POOL_MIN = 1 << 30
+
+
+def release_device_cache():
+    """Return the cached large device buffers (see DeviceBuffer) to the driver."""
+    h = hip()
+    while _POOL:
+        _, ptr = _POOL.pop()
+        h.free(ptr)
+
+
 class DeviceBuffer:
-    """Caller-owned HBM allocation (hipMalloc through the C ABI)."""
+    """Caller-owned HBM allocation (hipMalloc through the C ABI); buffers of a GB or more are
+    recycled through a small pool."""
 
     def __init__(self, nbytes):
         self._h = hip()
         self.nbytes = int(nbytes)
-        self.ptr = self._h.malloc(self.nbytes) if self.nbytes else 0
+        self.capacity = self.nbytes
+        self.ptr = 0
+        if not self.nbytes:
+            return
+        if self.nbytes >= _POOL_MIN:
+            fit = [i for i, (cap, _) in enumerate(_POOL) if self.nbytes <= cap <= 2 * self.nbytes]
+            if fit:
+                i = min(fit, key=lambda k: _POOL[k][0])
+                self.capacity, self.ptr = _POOL.pop(i)
+                return
+        try:
+            self.ptr = self._h.malloc(self.nbytes)
+        except Exception:
+            if not _POOL:
+                raise
+            release_device_cache()          # out of memory with buffers parked in the pool: retry without
+            self.ptr = self._h.malloc(self.nbytes)
 
     @classmethod
     def from_array(cls, a):
@@ -34,7 +68,10 @@ class DeviceBuffer:
 
     def free(self):
         if self.ptr:
-            self._h.free(self.ptr)
+            if self.capacity >= _POOL_MIN and len(_POOL) < _POOL_SLOTS:
+                _POOL.append((self.capacity, self.ptr))
+            else:
+                self._h.free(self.ptr)
             self.ptr = 0
 
     def __del__(self):
@@ -208,22 +245,36 @@ def compact_columns(stacked, lo, hi, anynans):
                 b.free()
 
 
+def device_budget_bytes(fraction=0.6):
+    """Working-set budget of the grid entry points: a fraction of the current device's HBM (a
+    single slab - one contiguous upload - whenever the whole grid fits: 173 GB on an MI355X)."""
+    h = hip()
+    try:
+        return int(fraction * h.device_info(h.get_device())["hbm_bytes"])
+    except Exception:
+        return 64 << 30
+
+
 def _grid_batch(stacked, max_batch_bytes, per_cell_extra=0):
     """cells per slab so that raw + compacted copies (+ per-cell extras) stay below the budget"""
+    if max_batch_bytes is None:
+        max_batch_bytes = device_budget_bytes()
     T, N = stacked.shape
     per_cell = 2 * T * stacked.dtype.itemsize + per_cell_extra
     return int(max(1, min(N, max_batch_bytes // max(per_cell, 1))))
 
 
 def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
-                          tstep, coldSpells=False, kernel="auto", nchunks=0, max_batch_bytes=64 << 30,
-                          narrowing=True, columns=None):
-    """land_check() + calc_clim() for an UNCOMPACTED stacked host array (T, N): the land mask and
-    the compaction run on the device too, so the host only hands the array over (for a global
-    grid the numpy dropna costs tens of times the kernels).  Returns (keep[N] bool, doys[D],
-    thresh[D, C], seas[D, C]) with C = keep.sum() cells in stacked order.
+                          tstep, coldSpells=False, kernel="auto", nchunks=0, max_batch_bytes=None,
+                          narrowing=True, columns=None, scatter=True):
+    """land_check() + calc_clim() for an UNCOMPACTED stacked host array (T, N): the land mask, the
+    compaction and the placement of the results back on the grid (what unstack('cell') does) run on
+    the device, so the host only hands the array over (for a global grid numpy's dropna and
+    boolean-mask assignment cost tens of times the kernels).  Returns (keep[N] bool, doys[D],
+    thresh[D, N], seas[D, N]) with NaN at the dropped cells; scatter=False returns the compact
+    (D, C) arrays of the C = keep.sum() surviving cells instead.
     ``columns=(c0, c1)`` restricts the work to that column range (a rank's slab of a sharded run:
-    keep then has c1 - c0 entries and an all-land slab is not an error)."""
+    keep and the arrays then cover c1 - c0 columns and an all-land slab is not an error)."""
     stacked = np.asarray(stacked)
     if stacked.dtype not in (np.float32, np.float64):
         stacked = stacked.astype(np.float64)
@@ -258,16 +309,35 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
                     clim_finish(plan, raw_th, raw_se, n, feb29_fix, smoothPercentile, smoothPercentileWidth,
                                 out_th, out_se)
                 h.stream_sync(0)
-                ths.append(out_th.to_array((D, n), np.float64))
-                ses.append(out_se.to_array((D, n), np.float64))
+                w = hi - lo
+                if scatter and n != w:
+                    d_idx = DeviceBuffer.from_array(np.nonzero(keep)[0].astype(np.int64)); bufs.append(d_idx)
+                    full_th, full_se = DeviceBuffer(8 * D * w), DeviceBuffer(8 * D * w)
+                    bufs += [full_th, full_se]
+                    h.scatter_cells(out_th.ptr, D, n, d_idx.ptr, n, full_th.ptr, w)
+                    h.scatter_cells(out_se.ptr, D, n, d_idx.ptr, n, full_se.ptr, w)
+                    h.stream_sync(0)
+                    out_th, out_se, n = full_th, full_se, w
+                ths.append(((lo, hi), out_th.to_array((D, n), np.float64)))
+                ses.append(((lo, hi), out_se.to_array((D, n), np.float64)))
             finally:
                 for b in bufs:
                     b.free()
         keep = np.concatenate(keeps) if keeps else np.zeros(0, dtype=bool)
-        if not keep.any():
-            if columns is None:
-                raise XmhwException("All points of grid are either land or NaN")     # identify.py:527-528
-            return keep, plan.doys.copy(), np.zeros((D, 0)), np.zeros((D, 0))
-        return keep, plan.doys.copy(), np.concatenate(ths, axis=1), np.concatenate(ses, axis=1)
+        if not keep.any() and columns is None:
+            raise XmhwException("All points of grid are either land or NaN")     # identify.py:527-528
+        if not scatter:
+            if not ths:
+                return keep, plan.doys.copy(), np.zeros((D, 0)), np.zeros((D, 0))
+            return (keep, plan.doys.copy(), np.concatenate([a for _, a in ths], axis=1),
+                    np.concatenate([a for _, a in ses], axis=1))
+        if len(ths) == 1 and ths[0][0] == (c0, c1):
+            return keep, plan.doys.copy(), ths[0][1], ses[0][1]          # one slab: no host copy at all
+        th = np.full((D, c1 - c0), np.nan)
+        se = np.full((D, c1 - c0), np.nan)
+        for ((a, b), x), (_, y) in zip(ths, ses):
+            th[:, a - c0:b - c0] = x
+            se[:, a - c0:b - c0] = y
+        return keep, plan.doys.copy(), th, se
     finally:
         plan.destroy()

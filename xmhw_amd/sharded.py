@@ -123,19 +123,17 @@ def make_sharded_grid_compute(group=None, dst=0, device=None, grid_compute=None)
         keep = np.concatenate([parts[r][: b - a].cpu().numpy() != 0 for r, (a, b) in enumerate(bounds)])
         if not keep.any():
             raise XmhwException("All points of grid are either land or NaN")     # on every rank alike
-        counts = [int(keep[a:b].sum()) for a, b in bounds]
-        nmax = max(max(counts), 1)
-        block = torch.zeros((2, D, nmax), dtype=torch.float64, device=dev)
-        if counts[rank]:
-            block[0, :, : counts[rank]] = torch.as_tensor(th_r, device=dev)
-            block[1, :, : counts[rank]] = torch.as_tensor(se_r, device=dev)
+        # the blocks come back on the grid (NaN at dropped cells), so they all have their slab's width
+        block = torch.full((2, D, width), float("nan"), dtype=torch.float64, device=dev)
+        if hi > lo:
+            block[0, :, : hi - lo] = torch.as_tensor(th_r, device=dev)
+            block[1, :, : hi - lo] = torch.as_tensor(se_r, device=dev)
         out = [torch.empty_like(block) for _ in range(world)] if rank == dst else None
         dist.gather(block, out, dst=dst, group=group)
-        C = int(keep.sum())
         if rank != dst:
-            th = se = np.full((D, C), np.nan)
+            th = se = np.full((D, N), np.nan)
         else:
-            full = np.concatenate([out[r][:, :, : counts[r]].cpu().numpy() for r in range(world)], axis=2)
+            full = np.concatenate([out[r][:, :, : b - a].cpu().numpy() for r, (a, b) in enumerate(bounds)], axis=2)
             th, se = full[0], full[1]
         return keep, doys, th, se
 
