@@ -241,3 +241,20 @@ def test_device_side_land_mask_and_compaction_equal_host_path(oisst):
         calc_clim_grid_device(np.full((731, 6), np.nan, np.float32), doy, False, 90, 5, True, 31, False)
     with pytest.raises(XmhwException):                       # climatologies on fewer cells than the series
         detect_grid(stacked, False, se0[:, :-1], th0[:, :-1], doy, d0)
+
+
+def test_large_buffers_are_recycled_and_released():
+    from xmhw_amd import release_device_cache
+    from xmhw_amd import device as dv
+    release_device_cache()
+    a = dv.DeviceBuffer(3 << 29)                 # 1.5 GB
+    p = a.ptr
+    a.free()
+    assert len(dv._POOL) == 1
+    b = dv.DeviceBuffer(1 << 30)                 # fits the parked buffer (capacity <= 2x the request)
+    assert b.ptr == p and b.capacity == 3 << 29
+    c = dv.DeviceBuffer(1 << 20)                 # small buffers never touch the pool
+    c.free(); b.free()
+    assert len(dv._POOL) == 1
+    release_device_cache()
+    assert dv._POOL == []

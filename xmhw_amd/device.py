@@ -21,7 +21,7 @@ def release_device_cache():
     """Return the cached large device buffers (see DeviceBuffer) to the driver."""
     h = hip()
     while _POOL:
-        _, ptr = _POOL.pop()
+        _, ptr, _ = _POOL.pop()
         h.free(ptr)
 
 
@@ -36,11 +36,12 @@ class DeviceBuffer:
         self.ptr = 0
         if not self.nbytes:
             return
-        if self.nbytes >= _POOL_MIN:
-            fit = [i for i, (cap, _) in enumerate(_POOL) if self.nbytes <= cap <= 2 * self.nbytes]
+        if self.nbytes >= _POOL_MIN and _POOL:
+            dev = self._h.get_device()          # a pooled buffer belongs to the device it was allocated on
+            fit = [i for i, (cap, _, d) in enumerate(_POOL) if d == dev and self.nbytes <= cap <= 2 * self.nbytes]
             if fit:
                 i = min(fit, key=lambda k: _POOL[k][0])
-                self.capacity, self.ptr = _POOL.pop(i)
+                self.capacity, self.ptr, _ = _POOL.pop(i)
                 return
         try:
             self.ptr = self._h.malloc(self.nbytes)
@@ -69,7 +70,7 @@ class DeviceBuffer:
     def free(self):
         if self.ptr:
             if self.capacity >= _POOL_MIN and len(_POOL) < _POOL_SLOTS:
-                _POOL.append((self.capacity, self.ptr))
+                _POOL.append((self.capacity, self.ptr, self._h.get_device()))
             else:
                 self._h.free(self.ptr)
             self.ptr = 0
