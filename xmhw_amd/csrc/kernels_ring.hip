@@ -2,7 +2,8 @@
 // pool held in VGPRs ("register ring"), hand-written for gfx950 wave64.
 //
 // Work decomposition
-//   wave  = 8 cells x 8 "subs"; lane = sub*8 + cell_in_wave.
+//   wave  = 8 cells x 8 "subs"; lane = (cell >> 1) * 16 + sub * 2 + (cell & 1), so the 8 subs of a
+//   cell sit in one 16-lane DPP row at stride 2 and combine with three row_ror DPP steps (8, 4, 2).
 //   A sub owns YPS tracks (years); 8*YPS >= ntracks.  For every owned track
 //   the lane keeps the R = 2w+1 samples of that year's current window as
 //   order-preserving 32-bit keys in VGPRs: ring[YPS][R].
@@ -10,8 +11,9 @@
 //   row each track PUSHes one new sample into ring slot (step mod R) -- the
 //   sample leaving the window sits exactly there -- so every input sample is
 //   read from HBM once (plus 2w per track boundary), 32 contiguous bytes per
-//   8 lanes, 128 B per 4-wave workgroup row.  No LDS, no barriers: a wave is
-//   self-contained; the 8 subs of a cell combine through cross-lane shuffles.
+//   8 lanes, 128 B per 4-wave workgroup row.  No LDS; a wave is self-contained, the
+//   only barrier is a rendezvous every 64 rows that keeps the four waves on the same
+//   128-byte lines (see the end of the row loop).
 //
 // Per row, per cell
 //   n      = number of valid pooled samples         (running per-track counts)
@@ -21,9 +23,12 @@
 //            lo+1.  Found by bracketing in key space: "count" passes give
 //            F(p) = #{valid keys <= p} (v_cmp + v_addc per key); the bracket
 //            (pl, F(pl) <= lo) / (ph, F(ph) > lo) starts from the previous
-//            row's answer and closes by secant steps on the counts; once
-//            F(pl) == lo (or ph == pl+1) one "extract" pass returns the two
-//            smallest keys above the pivot (v_sub, v_med3, v_min per key).
+//            row's pivot, whose count is kept up to date from the pushed / evicted
+//            keys alone, and closes by secant steps; once lo - F(pl) <= J - 2 one
+//            "extract" pass returns the J = 5 smallest keys above the pivot
+//            (v_sub, J-1 x v_med3, v_min per key; merged across the subs by a bitonic
+//            network over DPP), which contain both order statistics; a repair round
+//            handles tie-heavy data.
 //   Selection is exact for every input (ties, NaN, +-inf); heuristics only
 //   choose probe points.
 //
