@@ -157,3 +157,32 @@ def test_extreme_values(dev):
         d0, t0, s0 = fast.threshold_cells_fast(x, doy, smoothPercentile=True)
         npt.assert_allclose(t1, t0, rtol=1e-12, equal_nan=True)
         npt.assert_allclose(s1, s0, rtol=1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize("years", [(1960, 2020), (1931, 2020), (1925, 2020)])
+def test_long_records_use_the_16_lane_ring(dev, years):
+    """49..96 tracks: the float32 ring kernel with 16 lanes per cell (61, 90 and 96 years); bit-identical
+    raw thresholds to the generic kernel, oracle parity, also as float64 input holding float32 values."""
+    time, doy = _daily(*years)
+    nyears = years[1] - years[0] + 1
+    x = _series(time.shape[0], 19, 23, 0.01)
+    x[:, 3] = np.nan
+    plan = dev.Plan(doy, 5)
+    assert plan.kernel == "ring" and plan.ntracks == nyears > 48
+    plan.destroy()
+    _check(dev, x, doy, "ring", smoothPercentile=False)
+    t_ring = dev.calc_clim_device(x, doy, 90, 5, False, 31, True, kernel="ring")
+    t_gen = dev.calc_clim_device(x, doy, 90, 5, False, 31, True, kernel="generic")
+    npt.assert_array_equal(t_ring[1], t_gen[1])
+    npt.assert_allclose(t_ring[2], t_gen[2], rtol=1e-13, equal_nan=True)
+    t_chunks = dev.calc_clim_device(x, doy, 90, 5, False, 31, True, kernel="ring", nchunks=5)
+    npt.assert_array_equal(t_chunks[1], t_ring[1])
+    t64 = dev.calc_clim_device(x.astype(np.float64), doy, 90, 5, False, 31, True)
+    npt.assert_array_equal(t64[1], t_ring[1])
+
+
+def test_more_than_96_tracks_fall_back_to_the_generic_kernel(dev):
+    time, doy = _daily(1920, 2020)
+    plan = dev.Plan(doy, 5)
+    assert plan.kernel == "generic" and plan.ntracks == 101
+    plan.destroy()

@@ -42,6 +42,7 @@ struct xmhw_plan {
     std::mutex mu;
     bool uploaded = false;
     int32_t yps = 0;          // ring kernel years-per-lane (0: ring not available)
+    int32_t subs = 0;         // ... and its lanes per cell (8, or 16 for records of 49..96 tracks)
     int32_t nchunks = 0;
     uint32_t* d_table = nullptr;
     int32_t yps64 = 0;        // float64 ring kernel tracks-per-lane (16 lanes per cell)
@@ -68,7 +69,7 @@ namespace {
 
 int32_t resolve_kernel(const xmhw_plan* p, int elem_bytes) {
     const int32_t yps = elem_bytes == 8 ? xmhw::ring64_pick_yps(p->host.w, p->host.ntracks)
-                                        : xmhw::ring_pick_yps(p->host.w, p->host.ntracks, elem_bytes);
+                                        : xmhw::ring_pick(p->host.w, p->host.ntracks, elem_bytes, nullptr);
     if (p->host.kernel_choice == XMHW_KERNEL_GENERIC) return XMHW_KERNEL_GENERIC;
     if (p->host.kernel_choice == XMHW_KERNEL_RING) return yps ? XMHW_KERNEL_RING : -1;
     return yps ? XMHW_KERNEL_RING : XMHW_KERNEL_GENERIC;
@@ -101,8 +102,8 @@ int upload(xmhw_plan* p, int64_t C) {
         };
         HIP_TRY(put(&p->d_row_ptr, h.row_ptr));
         HIP_TRY(put(&p->d_centres, h.centres));
-        p->yps = xmhw::ring_pick_yps(h.w, h.ntracks, 4);
-        if (p->yps) HIP_TRY(put(&p->d_table, h.ring_table(kSubs, p->yps)));
+        p->yps = xmhw::ring_pick(h.w, h.ntracks, 4, &p->subs);
+        if (p->yps) HIP_TRY(put(&p->d_table, h.ring_table(p->subs, p->yps)));
         p->yps64 = xmhw::ring64_pick_yps(h.w, h.ntracks);
         if (p->yps64) HIP_TRY(put(&p->d_table64, h.ring_table(16, p->yps64)));
     }
@@ -141,7 +142,7 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
     if (kernel == XMHW_KERNEL_RING) {
         if constexpr (sizeof(T) == 4) {
             e = xmhw::launch_ring_f32(reinterpret_cast<const float*>(ts), C, ld, plan->d_table,
-                                      h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps, q,
+                                      h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps, plan->subs, q,
                                       negate, thresh, seas, ldo, st, plan->d_stats);
         } else {
             // float64 input: if every sample is float32-representable (decoded int16 / float32
@@ -153,8 +154,8 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
             if (plan->narrowing && plan->yps) {
                 if (!plan->d_narrow_flag) HIP_TRY(hipMalloc(&plan->d_narrow_flag, sizeof(uint32_t)));
                 e = xmhw::launch_ring_f32_narrowing(reinterpret_cast<const double*>(ts), h.T, C, ld, plan->d_table,
-                                                    h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps, q,
-                                                    negate, thresh, seas, ldo, st, plan->d_stats,
+                                                    h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps,
+                                                    plan->subs, q, negate, thresh, seas, ldo, st, plan->d_stats,
                                                     plan->d_narrow_flag);
                 run_flag = plan->d_narrow_flag;
             }

@@ -14,11 +14,13 @@ hipError_t launch_generic(const T* ts, int64_t Tn, int64_t C, int64_t ld, const 
                           double* thresh, double* seas, int64_t ldo, hipStream_t stream);
 
 // ring kernel (fast path).  Returns hipErrorInvalidValue if (w, yps) is not instantiated.
-bool ring_supported(int32_t w, int32_t yps, int elem_bytes);
-int32_t ring_pick_yps(int32_t w, int32_t ntracks, int elem_bytes);  // 0 if none
+bool ring_supported(int32_t w, int32_t yps, int32_t subs, int elem_bytes);
+// tracks per lane (0 if none) and lanes per cell (8, or 16 for records of 49..96 tracks) of the
+// float32 ring kernel that covers ntracks tracks
+int32_t ring_pick(int32_t w, int32_t ntracks, int elem_bytes, int32_t* subs_out);
 hipError_t launch_ring_f32(const float* ts, int64_t C, int64_t ld, const uint32_t* table,
                            int32_t step_min, const DevChunk* chunks, int32_t nchunks,
-                           int32_t w, int32_t yps, double q, int negate, double* thresh,
+                           int32_t w, int32_t yps, int32_t subs, double q, int negate, double* thresh,
                            double* seas, int64_t ldo, hipStream_t stream,
                            unsigned long long* stats = nullptr);
 
@@ -27,7 +29,7 @@ hipError_t launch_ring_f32(const float* ts, int64_t C, int64_t ld, const uint32_
 // representable and the outputs are garbage (queue launch_ring_f64(..., run_flag = narrow_flag) behind)
 hipError_t launch_ring_f32_narrowing(const double* ts, int64_t Tn, int64_t C, int64_t ld, const uint32_t* table,
                                      int32_t step_min, const DevChunk* chunks, int32_t nchunks, int32_t w,
-                                     int32_t yps, double q, int negate, double* thresh, double* seas,
+                                     int32_t yps, int32_t subs, double q, int negate, double* thresh, double* seas,
                                      int64_t ldo, hipStream_t stream, unsigned long long* stats,
                                      uint32_t* narrow_flag);
 

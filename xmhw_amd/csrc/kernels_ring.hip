@@ -41,20 +41,21 @@
 
 namespace xmhw {
 
-constexpr int kSubs = 8;
-constexpr int kCellsPerWave = 8;
 constexpr int kWavesPerBlock = 4;
 
-// Lane map: lane = (c >> 1) * 16 + sub * 2 + (c & 1), c = cell in wave (0..7).
+// Lane map (SUBS = 8): lane = (c >> 1) * 16 + sub * 2 + (c & 1), c = cell in wave (0..7).
 // The 8 subs of a cell sit in ONE 16-lane DPP row at stride 2, so the per-cell
 // all-reduce is three full-rate DPP row rotations (row_ror 8, 4, 2) instead of
 // LDS-pipe ds_bpermute (measured 24 cycles each vs 4.5, tools/ubench_valu.hip).
 // A ts row is still read as 8 x 4 = 32 contiguous bytes per wave.
+// SUBS = 16 (records of 49..96 tracks): a cell owns a whole DPP row, lane = c * 16 + sub with 4 cells
+// per wave, one more rotation (row_ror 1) per all-reduce; the per-cell logic then serves half as
+// many cells per instruction.
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
     return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), CTRL, 0xF, 0xF, false));
 }
-constexpr int kRor8 = 0x128, kRor4 = 0x124, kRor2 = 0x122;
+constexpr int kRor8 = 0x128, kRor4 = 0x124, kRor2 = 0x122, kRor1 = 0x121;
 
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
@@ -64,10 +65,12 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
+template <int SUBS>
 __device__ __forceinline__ uint32_t sub_sum(uint32_t v) {
     v += dpp_mov<kRor8>(v);
     v += dpp_mov<kRor4>(v);
     v += dpp_mov<kRor2>(v);
+    if constexpr (SUBS == 16) v += dpp_mov<kRor1>(v);
     return v;
 }
 template <int CTRL>
@@ -77,10 +80,12 @@ __device__ __forceinline__ double dpp_mov_f64(double v) {
     const uint32_t hi = dpp_mov<CTRL>(static_cast<uint32_t>(b >> 32));
     return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
 }
+template <int SUBS>
 __device__ __forceinline__ double sub_sum(double v) {
     v += dpp_mov_f64<kRor8>(v);
     v += dpp_mov_f64<kRor4>(v);
     v += dpp_mov_f64<kRor2>(v);
+    if constexpr (SUBS == 16) v += dpp_mov_f64<kRor1>(v);
     return v;
 }
 // merge two ascending pairs, keep the two smallest
@@ -88,11 +93,6 @@ __device__ __forceinline__ void min2_merge(uint32_t& a1, uint32_t& a2, uint32_t 
     const uint32_t hi = umax(a1, b1);
     a1 = umin(a1, b1);
     a2 = umin(hi, umin(a2, b2));
-}
-__device__ __forceinline__ void sub_min2(uint32_t& m1, uint32_t& m2) {
-    min2_merge(m1, m2, dpp_mov<kRor8>(m1), dpp_mov<kRor8>(m2));
-    min2_merge(m1, m2, dpp_mov<kRor4>(m1), dpp_mov<kRor4>(m2));
-    min2_merge(m1, m2, dpp_mov<kRor2>(m1), dpp_mov<kRor2>(m2));
 }
 
 __device__ __forceinline__ double key_value(uint32_t k) {
@@ -140,10 +140,12 @@ struct TopJ {
             }
         }
     }
+    template <int SUBS>
     __device__ __forceinline__ void sub_merge() {
         merge_dpp<kRor8>();
         merge_dpp<kRor4>();
         merge_dpp<kRor2>();
+        if constexpr (SUBS == 16) merge_dpp<kRor1>();
     }
     __device__ __forceinline__ uint32_t at(uint32_t j) const {  // m[j], j uniform per cell
         uint32_t r = m[0];
@@ -167,7 +169,7 @@ constexpr int kCountBudget = 6;   // count passes before the first extraction
 // runs at the float32 rate.  `narrow_flag` (TI = double only) is set as soon as a sample does not
 // survive the round trip; the kernel stops, later blocks do not start, and the float64 kernel
 // queued behind it (which runs only if the flag is set) recomputes everything.
-template <int W, int YPS, typename TI>
+template <int W, int YPS, typename TI, int SUBS>
 __global__ __launch_bounds__(256) void clim_ring_f32(
     const TI* __restrict__ ts, int64_t C, int64_t ld, const uint32_t* __restrict__ table,
     int32_t step_min, const DevChunk* __restrict__ chunks, double q, int negate,
@@ -179,16 +181,17 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
     }
     bool lossy = false;
     constexpr int R = 2 * W + 1;
-    constexpr int NTP = kSubs * YPS;
+    static_assert(SUBS == 8 || SUBS == 16, "lane maps exist for 8 and 16 subs");
+    constexpr int NTP = SUBS * YPS;
+    constexpr int kCells = 64 / SUBS;   // cells per wave
     constexpr uint32_t NSLOT = static_cast<uint32_t>(NTP) * R;
     constexpr int J = kTopJ;
     constexpr uint32_t SLACK = J - 2;  // a[lo], a[lo+1] are among the J keys above pl iff lo - F(pl) <= J-2
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int sub = (lane >> 1) & 7;
-    const int cw = (lane & 1) | ((lane >> 4) << 1);
-    const int64_t cell =
-        (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave) * kCellsPerWave + cw;
+    const int sub = SUBS == 8 ? (lane >> 1) & 7 : lane & 15;
+    const int cw = SUBS == 8 ? (lane & 1) | ((lane >> 4) << 1) : lane >> 4;
+    const int64_t cell = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave) * kCells + cw;
     const bool cell_ok = cell < C;
     const DevChunk ch = chunks[blockIdx.y];
     const uint32_t* tab = table + sub * YPS;
@@ -330,9 +333,9 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
                 ncl += counted[y] ? 1u : 0u;
                 tl += counted[y] ? tsum[y] : 0.0;
             }
-            const uint32_t n = sub_sum(nl);
-            const uint32_t ninv = (allc ? NSLOT : static_cast<uint32_t>(R) * sub_sum(ncl)) - n;
-            double total = sub_sum(tl);
+            const uint32_t n = sub_sum<SUBS>(nl);
+            const uint32_t ninv = (allc ? NSLOT : static_cast<uint32_t>(R) * sub_sum<SUBS>(ncl)) - n;
+            double total = sub_sum<SUBS>(tl);
             if (__any(!(fabs(total) <= 1.7976931348623157e308))) {
                 // an infinite sample went through a running sum (inf - inf = NaN once it leaves):
                 // rebuild the sums from the rings; with the sample still inside the pool the total
@@ -346,9 +349,9 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
                     tsum[y] = t;
                     tl += counted[y] ? t : 0.0;
                 }
-                total = sub_sum(tl);
+                total = sub_sum<SUBS>(tl);
             }
-            Fc += sub_sum(dF);  // raw count at the carried pivot, now for this row's rings
+            Fc += sub_sum<SUBS>(dF);  // raw count at the carried pivot, now for this row's rings
 
             const uint32_t nn = n ? n : 1u;
             const double vi = static_cast<double>(nn - 1) * q;
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
                         c += counted[y] ? cy : 0u;
                     }
                 }
-                return sub_sum(c);
+                return sub_sum<SUBS>(c);
             };
 
             // bracket: F(pl) = Fl <= lo < Fh = F(ph), F = #{valid counted keys <= .}
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
                             top.insert(counted[y] ? d : 0xFFFFFFFFu);
                         }
                 }
-                top.sub_merge();
+                top.template sub_merge<SUBS>();
                 ++st_extract;
                 if (!resolved) {
                     if (window) {
@@ -550,21 +553,18 @@ typedef void (*RingKernel)(const float*, int64_t, int64_t, const uint32_t*, int3
                            double, int, double*, double*, int64_t, unsigned long long*, uint32_t*);
 typedef void (*RingKernelN)(const double*, int64_t, int64_t, const uint32_t*, int32_t, const DevChunk*,
                             double, int, double*, double*, int64_t, unsigned long long*, uint32_t*);
-struct RingEntry { int w, yps; RingKernel fn; RingKernelN fn_narrow; };
-#define XMHW_RK(W, Y) {W, Y, clim_ring_f32<W, Y, float>, clim_ring_f32<W, Y, double>}
+struct RingEntry { int w, yps, subs; RingKernel fn; RingKernelN fn_narrow; };
+#define XMHW_RK(W, Y, S) {W, Y, S, clim_ring_f32<W, Y, float, S>, clim_ring_f32<W, Y, double, S>}
 const RingEntry kRing[] = {
-    XMHW_RK(5, 1), XMHW_RK(5, 2), XMHW_RK(5, 3), XMHW_RK(5, 4), XMHW_RK(5, 5), XMHW_RK(5, 6),
-    XMHW_RK(1, 1), XMHW_RK(1, 5), XMHW_RK(2, 3), XMHW_RK(2, 5), XMHW_RK(3, 4),
+    XMHW_RK(5, 1, 8), XMHW_RK(5, 2, 8), XMHW_RK(5, 3, 8), XMHW_RK(5, 4, 8), XMHW_RK(5, 5, 8), XMHW_RK(5, 6, 8),
+    XMHW_RK(1, 1, 8), XMHW_RK(1, 5, 8), XMHW_RK(2, 3, 8), XMHW_RK(2, 5, 8), XMHW_RK(3, 4, 8),
+    // long records: 16 lanes per cell, up to 96 tracks
+    XMHW_RK(5, 4, 16), XMHW_RK(5, 5, 16), XMHW_RK(5, 6, 16),
 };
 #undef XMHW_RK
-RingKernel find_ring(int32_t w, int32_t yps) {
+const RingEntry* find_ring(int32_t w, int32_t yps, int32_t subs) {
     for (const auto& e : kRing)
-        if (e.w == w && e.yps == yps) return e.fn;
-    return nullptr;
-}
-RingKernelN find_ring_narrow(int32_t w, int32_t yps) {
-    for (const auto& e : kRing)
-        if (e.w == w && e.yps == yps) return e.fn_narrow;
+        if (e.w == w && e.yps == yps && e.subs == subs) return &e;
     return nullptr;
 }
 
@@ -584,49 +584,57 @@ __global__ __launch_bounds__(256) void narrow_probe(const double* __restrict__ t
 }
 }  // namespace
 
-bool ring_supported(int32_t w, int32_t yps, int elem_bytes) {
-    return elem_bytes == 4 && find_ring(w, yps) != nullptr;
+bool ring_supported(int32_t w, int32_t yps, int32_t subs, int elem_bytes) {
+    return elem_bytes == 4 && find_ring(w, yps, subs) != nullptr;
 }
 
-int32_t ring_pick_yps(int32_t w, int32_t ntracks, int elem_bytes) {
+// fewest lanes per cell first (8 subs: twice the cells per wave), then the fewest tracks per lane
+int32_t ring_pick(int32_t w, int32_t ntracks, int elem_bytes, int32_t* subs_out) {
+    if (subs_out) *subs_out = 0;
     if (elem_bytes != 4) return 0;
-    int32_t best = 0;
-    for (const auto& e : kRing)
-        if (e.w == w && e.yps * kSubs >= ntracks && (best == 0 || e.yps < best)) best = e.yps;
-    return best;
+    for (int32_t subs : {8, 16}) {
+        int32_t best = 0;
+        for (const auto& e : kRing)
+            if (e.w == w && e.subs == subs && e.yps * subs >= ntracks && (best == 0 || e.yps < best)) best = e.yps;
+        if (best) {
+            if (subs_out) *subs_out = subs;
+            return best;
+        }
+    }
+    return 0;
 }
 
 hipError_t launch_ring_f32(const float* ts, int64_t C, int64_t ld, const uint32_t* table,
                            int32_t step_min, const DevChunk* chunks, int32_t nchunks, int32_t w,
-                           int32_t yps, double q, int negate, double* thresh, double* seas,
+                           int32_t yps, int32_t subs, double q, int negate, double* thresh, double* seas,
                            int64_t ldo, hipStream_t stream, unsigned long long* stats) {
-    RingKernel fn = find_ring(w, yps);
-    if (!fn) return hipErrorInvalidValue;
+    const RingEntry* e = find_ring(w, yps, subs);
+    if (!e) return hipErrorInvalidValue;
     if (C <= 0 || nchunks <= 0) return hipSuccess;
-    const int64_t cells_per_block = kCellsPerWave * kWavesPerBlock;
+    const int64_t cells_per_block = (64 / subs) * kWavesPerBlock;
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block),
               static_cast<unsigned>(nchunks));
-    hipLaunchKernelGGL(fn, grid, dim3(64 * kWavesPerBlock), 0, stream, ts, C, ld, table, step_min,
+    hipLaunchKernelGGL(e->fn, grid, dim3(64 * kWavesPerBlock), 0, stream, ts, C, ld, table, step_min,
                        chunks, q, negate, thresh, seas, ldo, stats, static_cast<uint32_t*>(nullptr));
     return hipGetLastError();
 }
 
 hipError_t launch_ring_f32_narrowing(const double* ts, int64_t Tn, int64_t C, int64_t ld, const uint32_t* table,
                                      int32_t step_min, const DevChunk* chunks, int32_t nchunks, int32_t w,
-                                     int32_t yps, double q, int negate, double* thresh, double* seas,
+                                     int32_t yps, int32_t subs, double q, int negate, double* thresh, double* seas,
                                      int64_t ldo, hipStream_t stream, unsigned long long* stats,
                                      uint32_t* narrow_flag) {
-    RingKernelN fn = find_ring_narrow(w, yps);
-    if (!fn || !narrow_flag) return hipErrorInvalidValue;
+    const RingEntry* e = find_ring(w, yps, subs);
+    if (!e || !narrow_flag) return hipErrorInvalidValue;
     if (C <= 0 || nchunks <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(narrow_flag, 0, sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
+    hipError_t err = hipMemsetAsync(narrow_flag, 0, sizeof(uint32_t), stream);
+    if (err != hipSuccess) return err;
     hipLaunchKernelGGL(narrow_probe, dim3(static_cast<unsigned>((C + 255) / 256)), dim3(256), 0, stream, ts, Tn, C,
                        ld, narrow_flag);
-    const int64_t cells_per_block = kCellsPerWave * kWavesPerBlock;
+    const int64_t cells_per_block = (64 / subs) * kWavesPerBlock;
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block),
               static_cast<unsigned>(nchunks));
-    hipLaunchKernelGGL(fn, grid, dim3(64 * kWavesPerBlock), 0, stream, ts, C, ld, table, step_min,
+    hipLaunchKernelGGL(e->fn_narrow, grid, dim3(64 * kWavesPerBlock), 0, stream, ts, C, ld, table, step_min,
                        chunks, q, negate, thresh, seas, ldo, stats, narrow_flag);
     return hipGetLastError();
 }
