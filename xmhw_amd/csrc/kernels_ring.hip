@@ -293,7 +293,11 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
             XMHW_RING_CASE(0) XMHW_RING_CASE(1) XMHW_RING_CASE(2) XMHW_RING_CASE(3)
             XMHW_RING_CASE(4) XMHW_RING_CASE(5) XMHW_RING_CASE(6) XMHW_RING_CASE(7)
             XMHW_RING_CASE(8) XMHW_RING_CASE(9) XMHW_RING_CASE(10) XMHW_RING_CASE(11)
-            XMHW_RING_CASE(12) XMHW_RING_CASE(13) XMHW_RING_CASE(14)
+            XMHW_RING_CASE(12) XMHW_RING_CASE(13) XMHW_RING_CASE(14) XMHW_RING_CASE(15)
+            XMHW_RING_CASE(16) XMHW_RING_CASE(17) XMHW_RING_CASE(18) XMHW_RING_CASE(19)
+            XMHW_RING_CASE(20) XMHW_RING_CASE(21) XMHW_RING_CASE(22) XMHW_RING_CASE(23)
+            XMHW_RING_CASE(24) XMHW_RING_CASE(25) XMHW_RING_CASE(26) XMHW_RING_CASE(27)
+            XMHW_RING_CASE(28) XMHW_RING_CASE(29) XMHW_RING_CASE(30)
             default: break;
         }
 #undef XMHW_RING_CASE
@@ -555,11 +559,21 @@ typedef void (*RingKernelN)(const double*, int64_t, int64_t, const uint32_t*, in
                             double, int, double*, double*, int64_t, unsigned long long*, uint32_t*);
 struct RingEntry { int w, yps, subs; RingKernel fn; RingKernelN fn_narrow; };
 #define XMHW_RK(W, Y, S) {W, Y, S, clim_ring_f32<W, Y, float, S>, clim_ring_f32<W, Y, double, S>}
+// (window half width, tracks per lane, lanes per cell); the ring holds YPS * (2w+1) keys per lane
+// (<= 66 VGPRs), so wide windows trade tracks per lane for lanes per cell
 const RingEntry kRing[] = {
+    // the default window: 8 lanes per cell up to 48 tracks, 16 lanes up to 96
     XMHW_RK(5, 1, 8), XMHW_RK(5, 2, 8), XMHW_RK(5, 3, 8), XMHW_RK(5, 4, 8), XMHW_RK(5, 5, 8), XMHW_RK(5, 6, 8),
-    XMHW_RK(1, 1, 8), XMHW_RK(1, 5, 8), XMHW_RK(2, 3, 8), XMHW_RK(2, 5, 8), XMHW_RK(3, 4, 8),
-    // long records: 16 lanes per cell, up to 96 tracks
     XMHW_RK(5, 4, 16), XMHW_RK(5, 5, 16), XMHW_RK(5, 6, 16),
+    // narrower windows (pentad / coarse-step data)
+    XMHW_RK(1, 1, 8), XMHW_RK(1, 2, 8), XMHW_RK(1, 4, 8), XMHW_RK(1, 6, 8),
+    XMHW_RK(2, 1, 8), XMHW_RK(2, 2, 8), XMHW_RK(2, 4, 8), XMHW_RK(2, 6, 8),
+    XMHW_RK(3, 2, 8), XMHW_RK(3, 4, 8), XMHW_RK(3, 6, 8),
+    XMHW_RK(4, 2, 8), XMHW_RK(4, 4, 8), XMHW_RK(4, 6, 8),
+    // wider windows
+    XMHW_RK(7, 2, 8), XMHW_RK(7, 4, 8), XMHW_RK(7, 4, 16),
+    XMHW_RK(10, 3, 8), XMHW_RK(10, 3, 16),
+    XMHW_RK(15, 2, 8), XMHW_RK(15, 2, 16),
 };
 #undef XMHW_RK
 const RingEntry* find_ring(int32_t w, int32_t yps, int32_t subs) {
