@@ -186,3 +186,20 @@ def test_more_than_96_tracks_fall_back_to_the_generic_kernel(dev):
     plan = dev.Plan(doy, 5)
     assert plan.kernel == "generic" and plan.ntracks == 101
     plan.destroy()
+
+
+@pytest.mark.parametrize("w,years", [(7, (1982, 2021)), (10, (1982, 2021)), (15, (1991, 2020)), (4, (1982, 2021)),
+                                      (7, (1991, 2020)), (10, (2001, 2020))])
+def test_other_window_widths_stay_on_the_ring_kernel(dev, w, years):
+    """Window half widths 4, 7, 10, 15 on 20-40 year records (8 or 16 lanes per cell): raw thresholds
+    bit-identical to the generic kernel, sums to rounding."""
+    time, doy = _daily(*years)
+    x = _series(time.shape[0], 13, 31 + w, 0.02)
+    plan = dev.Plan(doy, w)
+    assert plan.kernel == "ring"
+    plan.destroy()
+    a = dev.calc_clim_device(x, doy, 90, w, False, 31, True, kernel="ring")
+    b = dev.calc_clim_device(x, doy, 90, w, False, 31, True, kernel="generic")
+    npt.assert_array_equal(a[1], b[1])
+    npt.assert_allclose(a[2], b[2], rtol=1e-13, equal_nan=True)
+    _check(dev, x[:, :5], doy, "ring", windowHalfWidth=w)
