@@ -12,7 +12,7 @@ import oracle_fast as fast
 pytestmark = pytest.mark.gpu
 
 RING_WINDOWS_F32 = {1: 48, 2: 48, 3: 48, 4: 48, 5: 48, 7: 32, 10: 24, 15: 16}     # w -> tracks covered (8 lanes/cell)
-RING_WINDOWS_F64 = {1: 16, 2: 32, 3: 32, 5: 48}
+RING_WINDOWS_F64 = {1: 48, 2: 48, 3: 48, 4: 48, 5: 48, 7: 32, 10: 16, 15: 16}
 
 
 @pytest.fixture(scope="module")

@@ -220,7 +220,11 @@ __global__ __launch_bounds__(256) void clim_ring_f64(
             XMHW_RING_CASE(0) XMHW_RING_CASE(1) XMHW_RING_CASE(2) XMHW_RING_CASE(3)
             XMHW_RING_CASE(4) XMHW_RING_CASE(5) XMHW_RING_CASE(6) XMHW_RING_CASE(7)
             XMHW_RING_CASE(8) XMHW_RING_CASE(9) XMHW_RING_CASE(10) XMHW_RING_CASE(11)
-            XMHW_RING_CASE(12) XMHW_RING_CASE(13) XMHW_RING_CASE(14)
+            XMHW_RING_CASE(12) XMHW_RING_CASE(13) XMHW_RING_CASE(14) XMHW_RING_CASE(15)
+            XMHW_RING_CASE(16) XMHW_RING_CASE(17) XMHW_RING_CASE(18) XMHW_RING_CASE(19)
+            XMHW_RING_CASE(20) XMHW_RING_CASE(21) XMHW_RING_CASE(22) XMHW_RING_CASE(23)
+            XMHW_RING_CASE(24) XMHW_RING_CASE(25) XMHW_RING_CASE(26) XMHW_RING_CASE(27)
+            XMHW_RING_CASE(28) XMHW_RING_CASE(29) XMHW_RING_CASE(30)
             default: break;
         }
 #undef XMHW_RING_CASE
@@ -460,7 +464,11 @@ typedef void (*Ring64Kernel)(const double*, int64_t, int64_t, const uint32_t*, i
 struct Ring64Entry { int w, yps; Ring64Kernel fn; };
 #define XMHW_RK(W, Y) {W, Y, clim_ring_f64<W, Y>}
 const Ring64Entry kRing64[] = {
-    XMHW_RK(5, 1), XMHW_RK(5, 2), XMHW_RK(5, 3), XMHW_RK(1, 1), XMHW_RK(2, 2), XMHW_RK(3, 2),
+    // (window half width, tracks per lane) on 16 lanes per cell; the 64-bit ring is 2 * YPS * (2w+1) <= 66 VGPRs
+    XMHW_RK(5, 1), XMHW_RK(5, 2), XMHW_RK(5, 3),
+    XMHW_RK(1, 1), XMHW_RK(1, 2), XMHW_RK(1, 3), XMHW_RK(2, 1), XMHW_RK(2, 2), XMHW_RK(2, 3),
+    XMHW_RK(3, 1), XMHW_RK(3, 2), XMHW_RK(3, 3), XMHW_RK(4, 1), XMHW_RK(4, 2), XMHW_RK(4, 3),
+    XMHW_RK(7, 1), XMHW_RK(7, 2), XMHW_RK(10, 1), XMHW_RK(15, 1),
 };
 #undef XMHW_RK
 }  // namespace
