@@ -155,3 +155,39 @@ def test_float64_narrowing(dev):
     d0, t0, s0 = fast.threshold_cells_fast(x64, doy)
     npt.assert_allclose(t1, t0, rtol=1e-12, equal_nan=True)
     npt.assert_allclose(s1, s0, rtol=1e-12, equal_nan=True)
+
+
+def test_long_float64_record_narrows_onto_the_16_lane_ring(dev):
+    """61 years as float64: no float64 ring covers it; float32-representable samples still take the
+    float32 ring (16 lanes per cell), genuine float64 samples end on the generic kernel."""
+    from xmhw_amd.device import DeviceBuffer, Plan, clim_raw
+    from xmhw_amd._lib import hip
+    h = hip()
+    time, doy = _daily(1960, 2020)
+    T, C, D = time.shape[0], 9, 366
+    x32 = _series(T, C, 41, 0.01, dtype=np.float32)
+    rand = _series(T, C, 42, 0.01, dtype=np.float64)
+
+    def run(arr, kernel="auto"):
+        plan = Plan(doy, 5, kernel=kernel)
+        d_ts = DeviceBuffer.from_array(np.ascontiguousarray(arr))
+        th, se = DeviceBuffer(8 * D * C), DeviceBuffer(8 * D * C)
+        try:
+            clim_raw(plan, d_ts, arr.dtype.itemsize, C, 0.9, False, th, se)
+            h.stream_sync(0)
+            return th.to_array((D, C), np.float64), se.to_array((D, C), np.float64), plan.narrowed()
+        finally:
+            for b in (d_ts, th, se):
+                b.free()
+            plan.destroy()
+
+    t32, s32, _ = run(x32)
+    tn, sn, narrowed = run(x32.astype(np.float64))
+    assert narrowed
+    npt.assert_array_equal(tn, t32)
+    npt.assert_array_equal(sn, s32)
+    tr, sr, narrowed = run(rand)
+    assert not narrowed
+    tg, sg, _ = run(rand, kernel="generic")
+    npt.assert_array_equal(tr, tg)
+    npt.assert_array_equal(sr, sg)

@@ -165,8 +165,24 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
                                           negate, thresh, seas, ldo, st, plan->d_stats, run_flag);
         }
     } else {
-        e = xmhw::launch_generic<T>(ts, h.T, C, ld, plan->d_row_ptr, plan->d_centres, h.D, h.w, q,
-                                    negate, thresh, seas, ldo, st);
+        const uint32_t* run_flag = nullptr;
+        e = hipSuccess;
+        if constexpr (sizeof(T) == 8) {
+            // no float64 ring for this plan (e.g. a record of more than 48 tracks), but the float32 ring
+            // covers it: float32-representable data still takes the fast kernel, the generic one
+            // runs only if the narrowing gave up
+            if (plan->narrowing && plan->yps && plan->host.kernel_choice == XMHW_KERNEL_AUTO) {
+                if (!plan->d_narrow_flag) HIP_TRY(hipMalloc(&plan->d_narrow_flag, sizeof(uint32_t)));
+                e = xmhw::launch_ring_f32_narrowing(reinterpret_cast<const double*>(ts), h.T, C, ld, plan->d_table,
+                                                    h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps,
+                                                    plan->subs, q, negate, thresh, seas, ldo, st, plan->d_stats,
+                                                    plan->d_narrow_flag);
+                run_flag = plan->d_narrow_flag;
+            }
+        }
+        if (e == hipSuccess)
+            e = xmhw::launch_generic<T>(ts, h.T, C, ld, plan->d_row_ptr, plan->d_centres, h.D, h.w, q,
+                                        negate, thresh, seas, ldo, st, run_flag);
     }
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return XMHW_OK;

@@ -11,7 +11,8 @@ struct DevChunk { int32_t warm_start, begin, end; };
 template <typename T>
 hipError_t launch_generic(const T* ts, int64_t Tn, int64_t C, int64_t ld, const int32_t* row_ptr,
                           const int32_t* centres, int32_t D, int32_t w, double q, int negate,
-                          double* thresh, double* seas, int64_t ldo, hipStream_t stream);
+                          double* thresh, double* seas, int64_t ldo, hipStream_t stream,
+                          const uint32_t* run_flag = nullptr);   // non-NULL: return at once unless *run_flag != 0
 
 // ring kernel (fast path).  Returns hipErrorInvalidValue if (w, yps) is not instantiated.
 bool ring_supported(int32_t w, int32_t yps, int32_t subs, int elem_bytes);

@@ -24,7 +24,10 @@ __global__ __launch_bounds__(256) void clim_generic(const T* __restrict__ ts, in
                                                     int64_t ld, const int32_t* __restrict__ row_ptr,
                                                     const int32_t* __restrict__ centres, int32_t w,
                                                     double q, int negate, double* __restrict__ thresh,
-                                                    double* __restrict__ seas, int64_t ldo) {
+                                                    double* __restrict__ seas, int64_t ldo,
+                                                    const uint32_t* __restrict__ run_flag) {
+    // queued behind the narrowing float32 ring kernel (capi.cpp): nothing to do unless that one gave up
+    if (run_flag != nullptr && *run_flag == 0) return;
     using K = typename KeyOf<T>::type;
     const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int32_t row = blockIdx.y;
@@ -94,19 +97,20 @@ __global__ __launch_bounds__(256) void clim_generic(const T* __restrict__ ts, in
 template <typename T>
 hipError_t launch_generic(const T* ts, int64_t Tn, int64_t C, int64_t ld, const int32_t* row_ptr,
                           const int32_t* centres, int32_t D, int32_t w, double q, int negate,
-                          double* thresh, double* seas, int64_t ldo, hipStream_t stream) {
+                          double* thresh, double* seas, int64_t ldo, hipStream_t stream,
+                          const uint32_t* run_flag) {
     if (C <= 0 || D <= 0) return hipSuccess;
     dim3 grid(static_cast<unsigned>((C + 255) / 256), static_cast<unsigned>(D));
     hipLaunchKernelGGL(clim_generic<T>, grid, dim3(256), 0, stream, ts, Tn, C, ld, row_ptr, centres, w,
-                       q, negate, thresh, seas, ldo);
+                       q, negate, thresh, seas, ldo, run_flag);
     return hipGetLastError();
 }
 template hipError_t launch_generic<float>(const float*, int64_t, int64_t, int64_t, const int32_t*,
                                           const int32_t*, int32_t, int32_t, double, int, double*,
-                                          double*, int64_t, hipStream_t);
+                                          double*, int64_t, hipStream_t, const uint32_t*);
 template hipError_t launch_generic<double>(const double*, int64_t, int64_t, int64_t, const int32_t*,
                                            const int32_t*, int32_t, int32_t, double, int, double*,
-                                           double*, int64_t, hipStream_t);
+                                           double*, int64_t, hipStream_t, const uint32_t*);
 
 // ---------------------------------------------------------------------------
 // clim_finish: feb29() (identify.py:137-151 applied at :237-240, :265-268)
