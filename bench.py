@@ -275,6 +275,12 @@ def main():
         "roofline_binding_resource": valu,
         "finish_kernel_avg_launch_ms": float(np.mean(finish_ms)),
     }
+    if use_dist:
+        # kernel-only and kernel+gather side by side (rank 0's kernels; the step time is the max over ranks)
+        kernels_ms = (float(np.sum(ring_ms)) + float(np.sum(finish_ms))) / args.steps
+        result["multi_gpu"] = {"kernels_ms_per_step": kernels_ms, "step_ms": ms_per_step,
+                               "exposed_gather_ms_per_step": max(ms_per_step - kernels_ms, 0.0),
+                               "gathered_bytes_per_step_at_root": float((world - 1) * 2 * D * C * 8)}
 
     # ---- parity subset + CPU baseline (rank 0, N=1) ------------------------------------
     if rank == 0:
