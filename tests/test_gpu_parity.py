@@ -159,10 +159,11 @@ def test_extreme_values(dev):
         npt.assert_allclose(s1, s0, rtol=1e-12, equal_nan=True)
 
 
-@pytest.mark.parametrize("years", [(1960, 2020), (1931, 2020), (1925, 2020)])
-def test_long_records_use_the_16_lane_ring(dev, years):
-    """49..96 tracks: the float32 ring kernel with 16 lanes per cell (61, 90 and 96 years); bit-identical
-    raw thresholds to the generic kernel, oracle parity, also as float64 input holding float32 values."""
+@pytest.mark.parametrize("years", [(1960, 2020), (1931, 2020), (1925, 2020), (1920, 2020), (1850, 2014)])
+def test_long_records_use_the_16_and_32_lane_ring(dev, years):
+    """49..96 tracks: the float32 ring kernel with 16 lanes per cell (61, 90 and 96 years), 97..192 tracks
+    with 32 lanes per cell (101 and 165 years); bit-identical raw thresholds to the generic kernel, oracle
+    parity, also as float64 input holding float32 values."""
     time, doy = _daily(*years)
     nyears = years[1] - years[0] + 1
     x = _series(time.shape[0], 19, 23, 0.01)
@@ -181,10 +182,10 @@ def test_long_records_use_the_16_lane_ring(dev, years):
     npt.assert_array_equal(t64[1], t_ring[1])
 
 
-def test_more_than_96_tracks_fall_back_to_the_generic_kernel(dev):
-    time, doy = _daily(1920, 2020)
+def test_more_than_192_tracks_fall_back_to_the_generic_kernel(dev):
+    time, doy = _daily(1820, 2020)
     plan = dev.Plan(doy, 5)
-    assert plan.kernel == "generic" and plan.ntracks == 101
+    assert plan.kernel == "generic" and plan.ntracks == 201
     plan.destroy()
 
 

@@ -50,12 +50,17 @@ constexpr int kWavesPerBlock = 4;
 // A ts row is still read as 8 x 4 = 32 contiguous bytes per wave.
 // SUBS = 16 (records of 49..96 tracks): a cell owns a whole DPP row, lane = c * 16 + sub with 4 cells
 // per wave, one more rotation (row_ror 1) per all-reduce; the per-cell logic then serves half as
-// many cells per instruction.
+// many cells per instruction.  SUBS = 32 (97..192 tracks): two DPP rows per cell, 2 cells per wave,
+// the rows meet through one ds_swizzle (lane ^ 16) per all-reduce.
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
     return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), CTRL, 0xF, 0xF, false));
 }
 constexpr int kRor8 = 0x128, kRor4 = 0x124, kRor2 = 0x122, kRor1 = 0x121;
+// partner lane in the other DPP row of a 32-lane half (lane ^ 16): ds_swizzle BITMASK_PERM, and 0x1F, xor 0x10
+__device__ __forceinline__ uint32_t swap16(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(v), 0x401F));
+}
 
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
@@ -70,7 +75,8 @@ __device__ __forceinline__ uint32_t sub_sum(uint32_t v) {
     v += dpp_mov<kRor8>(v);
     v += dpp_mov<kRor4>(v);
     v += dpp_mov<kRor2>(v);
-    if constexpr (SUBS == 16) v += dpp_mov<kRor1>(v);
+    if constexpr (SUBS >= 16) v += dpp_mov<kRor1>(v);
+    if constexpr (SUBS == 32) v += swap16(v);
     return v;
 }
 template <int CTRL>
@@ -85,7 +91,12 @@ __device__ __forceinline__ double sub_sum(double v) {
     v += dpp_mov_f64<kRor8>(v);
     v += dpp_mov_f64<kRor4>(v);
     v += dpp_mov_f64<kRor2>(v);
-    if constexpr (SUBS == 16) v += dpp_mov_f64<kRor1>(v);
+    if constexpr (SUBS >= 16) v += dpp_mov_f64<kRor1>(v);
+    if constexpr (SUBS == 32) {
+        const uint64_t b = static_cast<uint64_t>(__double_as_longlong(v));
+        const uint32_t lo = swap16(static_cast<uint32_t>(b)), hi = swap16(static_cast<uint32_t>(b >> 32));
+        v += __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
+    }
     return v;
 }
 // merge two ascending pairs, keep the two smallest
@@ -120,7 +131,7 @@ struct TopJ {
     __device__ __forceinline__ void merge_dpp() {
         uint32_t b[J];
 #pragma unroll
-        for (int i = 0; i < J; ++i) b[i] = dpp_mov<CTRL>(m[i]);
+        for (int i = 0; i < J; ++i) b[i] = CTRL ? dpp_mov<CTRL ? CTRL : kRor1>(m[i]) : swap16(m[i]);   // CTRL 0: lane ^ 16
 #pragma unroll
         for (int i = 0; i < J; ++i) m[i] = umin(m[i], b[J - 1 - i]);
         // the J keys form an up-down sequence; embedded at offset 8-J of an 8-key bitonic
@@ -145,7 +156,8 @@ struct TopJ {
         merge_dpp<kRor8>();
         merge_dpp<kRor4>();
         merge_dpp<kRor2>();
-        if constexpr (SUBS == 16) merge_dpp<kRor1>();
+        if constexpr (SUBS >= 16) merge_dpp<kRor1>();
+        if constexpr (SUBS == 32) merge_dpp<0>();
     }
     __device__ __forceinline__ uint32_t at(uint32_t j) const {  // m[j], j uniform per cell
         uint32_t r = m[0];
@@ -181,7 +193,7 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
     }
     bool lossy = false;
     constexpr int R = 2 * W + 1;
-    static_assert(SUBS == 8 || SUBS == 16, "lane maps exist for 8 and 16 subs");
+    static_assert(SUBS == 8 || SUBS == 16 || SUBS == 32, "lane maps exist for 8, 16 and 32 subs");
     constexpr int NTP = SUBS * YPS;
     constexpr int kCells = 64 / SUBS;   // cells per wave
     constexpr uint32_t NSLOT = static_cast<uint32_t>(NTP) * R;
@@ -189,8 +201,8 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
     constexpr uint32_t SLACK = J - 2;  // a[lo], a[lo+1] are among the J keys above pl iff lo - F(pl) <= J-2
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int sub = SUBS == 8 ? (lane >> 1) & 7 : lane & 15;
-    const int cw = SUBS == 8 ? (lane & 1) | ((lane >> 4) << 1) : lane >> 4;
+    const int sub = SUBS == 8 ? (lane >> 1) & 7 : lane & (SUBS - 1);
+    const int cw = SUBS == 8 ? (lane & 1) | ((lane >> 4) << 1) : lane / SUBS;
     const int64_t cell = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave) * kCells + cw;
     const bool cell_ok = cell < C;
     const DevChunk ch = chunks[blockIdx.y];
@@ -565,6 +577,8 @@ const RingEntry kRing[] = {
     // the default window: 8 lanes per cell up to 48 tracks, 16 lanes up to 96
     XMHW_RK(5, 1, 8), XMHW_RK(5, 2, 8), XMHW_RK(5, 3, 8), XMHW_RK(5, 4, 8), XMHW_RK(5, 5, 8), XMHW_RK(5, 6, 8),
     XMHW_RK(5, 4, 16), XMHW_RK(5, 5, 16), XMHW_RK(5, 6, 16),
+    // very long records (e.g. 165-year model runs): 32 lanes per cell, up to 192 tracks
+    XMHW_RK(5, 4, 32), XMHW_RK(5, 5, 32), XMHW_RK(5, 6, 32),
     // narrower windows (pentad / coarse-step data)
     XMHW_RK(1, 1, 8), XMHW_RK(1, 2, 8), XMHW_RK(1, 4, 8), XMHW_RK(1, 6, 8),
     XMHW_RK(2, 1, 8), XMHW_RK(2, 2, 8), XMHW_RK(2, 4, 8), XMHW_RK(2, 6, 8),
@@ -606,7 +620,7 @@ bool ring_supported(int32_t w, int32_t yps, int32_t subs, int elem_bytes) {
 int32_t ring_pick(int32_t w, int32_t ntracks, int elem_bytes, int32_t* subs_out) {
     if (subs_out) *subs_out = 0;
     if (elem_bytes != 4) return 0;
-    for (int32_t subs : {8, 16}) {
+    for (int32_t subs : {8, 16, 32}) {
         int32_t best = 0;
         for (const auto& e : kRing)
             if (e.w == w && e.subs == subs && e.yps * subs >= ntracks && (best == 0 || e.yps < best)) best = e.yps;
