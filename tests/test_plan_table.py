@@ -86,7 +86,10 @@ def test_irregular_axis_gap_in_record():
 
 
 def test_too_many_tracks_falls_back_to_generic():
-    doy = np.tile(np.arange(1, 4), 100)              # 100 tracks > 8 * max yps
+    doy = np.tile(np.arange(1, 4), 100)              # 100 tracks: 32 lanes per cell (97..192 tracks)
+    p = _plan(doy, 5)
+    assert p.kernel == "ring"
+    doy = np.tile(np.arange(1, 4), 200)              # 200 tracks > 32 * max yps
     p = _plan(doy, 5)
     assert p.kernel == "generic"
 
