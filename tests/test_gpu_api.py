@@ -235,6 +235,18 @@ def test_device_side_land_mask_and_compaction_equal_host_path(oisst):
         npt.assert_array_equal(kp, kf[c0:c1])
         npt.assert_array_equal(thp, thf[:, c0:c1])
         npt.assert_array_equal(sep, sef[:, c0:c1])
+    # detect on blocks of columns with the survivor offsets a sharded run exchanges
+    full = detect_grid(stacked, False, sef, thf, doy, df, 5, True, 2, clim_stacked=True)
+    total = int(kf.sum())
+    tabs, cnts = [], []
+    for c0, c1 in ((0, 11), (11, 12), (12, 32)):
+        off = int(kf[:c0].sum())
+        r = detect_grid(stacked, False, sef, thf, doy, df, 5, True, 2, clim_stacked=True, columns=(c0, c1),
+                        exchange=lambda n, off=off, c0=c0, c1=c1: (off, total) if n == int(kf[c0:c1].sum()) else (-1, -1))
+        npt.assert_array_equal(r["keep"], kf[c0:c1])
+        tabs.append(r["table"]); cnts.append(np.diff(r["offsets"]))
+    npt.assert_array_equal(np.concatenate(tabs, axis=0), full["table"])
+    npt.assert_array_equal(np.concatenate(cnts), np.diff(full["offsets"]))
     # all land -> the reference's exception, raised after the device mask
     from xmhw_amd import XmhwException
     with pytest.raises(XmhwException):

@@ -213,3 +213,67 @@ def test_sharded_grid_path_equals_single(tmp_path, world):
     np.testing.assert_array_equal(got["seas"], ref["seas"])
     np.testing.assert_array_equal(got["lat"], ref.coords["lat"])
     np.testing.assert_array_equal(got["lon"], ref.coords["lon"])
+
+
+def _detect_grid_standin(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2,
+                         coldSpells=False, intermediate=False, clim_stacked=False, columns=None, exchange=None):
+    """numpy / oracle stand-in for detect_front.detect_grid on a block of columns"""
+    from detect_standin import oracle_detect_cells
+
+    def compact(a):
+        nan = np.isnan(a)
+        k = ~(nan.any(axis=0) if anynans else nan.all(axis=0))
+        return a[:, k], k
+    if clim_stacked:
+        seas, thresh = compact(seas)[0], compact(thresh)[0]
+    c0, c1 = columns
+    sub, keep = compact(stacked[:, c0:c1])
+    k0, total = exchange(int(keep.sum()))
+    assert total == thresh.shape[1]
+    n = int(keep.sum())
+    if n == 0:
+        return dict(table=np.zeros((0, 31)), offsets=np.zeros(1, dtype=np.int64), inter=None, keep=keep)
+    r = oracle_detect_cells(np.ascontiguousarray(sub), np.ascontiguousarray(seas[:, k0:k0 + n]),
+                            np.ascontiguousarray(thresh[:, k0:k0 + n]), doy, doys, minDuration, joinGaps, maxGap,
+                            coldSpells, False)
+    r["keep"] = keep
+    return r
+
+
+def _detect_grid_worker(rank, world, port, outdir):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from xmhw_amd.sharded import detect_sharded
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    temp, th, se = _detect_inputs()
+    out = detect_sharded(temp, th, se, _grid_compute=_detect_grid_standin, minDuration=4, maxGap=1)
+    if rank == 0:
+        np.savez(os.path.join(outdir, "detect_grid.npz"), table=out.table, offsets=out.offsets, keep=out.keep)
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_detect_grid_path_equals_single(tmp_path, world):
+    """detect() with every rank masking its own block of grid columns (blocks with different numbers
+    of ocean cells, one all-land block for world=3) = the single-rank result."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from detect_standin import oracle_detect_cells
+    from xmhw_amd.detect import _detect
+
+    mp.spawn(_detect_grid_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "detect_grid.npz")
+    temp, th, se = _detect_inputs()
+    mhw = _detect(temp, th, se, oracle_detect_cells, minDuration=4, maxGap=1)
+    assert mhw.n_events > 0
+    np.testing.assert_array_equal(got["keep"], mhw.keep)
+    np.testing.assert_array_equal(got["offsets"], mhw.offsets)
+    np.testing.assert_array_equal(got["table"], mhw.table)

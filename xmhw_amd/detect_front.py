@@ -232,13 +232,18 @@ def detect_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxG
 
 
 def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
-                intermediate=False, max_batch_bytes=None, clim_stacked=False):
+                intermediate=False, max_batch_bytes=None, clim_stacked=False, columns=None, exchange=None):
     """detect_cells() for an UNCOMPACTED stacked host series (T, N): land_check()'s mask and
     compaction run on the device (device.compact_columns), slab by slab.  The climatologies are
     either already compacted (D, C) arrays, or - clim_stacked=True - uncompacted (D, N) arrays whose
     own land masks and compaction then happen on the device as well.  Cells of the series and of
     the climatologies pair up by POSITION among the survivors (xmhw/xmhw.py:398-402, 437-443).
-    Returns detect_cells()'s dict plus keep[N]."""
+    Returns detect_cells()'s dict plus keep[N].
+    Sharded runs: ``columns=(c0, c1)`` restricts the series to a rank's block of columns; the block is
+    masked and compacted first, then ``exchange(n_kept)`` must return (offset of this block's first
+    survivor among all survivors, total number of survivors) - the climatology columns are taken at
+    that offset - and the result covers the block only (keep has c1 - c0 entries, no error for an
+    all-land block)."""
     from .device import _grid_batch, compact_columns
     stacked = np.asarray(stacked)
     if stacked.dtype not in (np.float32, np.float64):
@@ -299,33 +304,55 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
         if C != Cse:
             raise XmhwException(f"th and se do not have the same ocean cells: {C}, {Cse}")
         cb = _grid_batch(stacked, max_batch_bytes, per_cell_extra=6 * D * 8 + T // 8 + 64)
-        for lo in range(0, N, cb):
-            hi = min(N, lo + cb)
-            d_ts, keep = compact_columns(stacked, lo, hi, anynans)
-            keeps.append(keep)
-            n = int(keep.sum())
-            if d_ts is None:
-                continue
-            try:
-                if k0 + n > C:
-                    raise XmhwException(f"temp has more ocean cells than th and se ({C})")
-                tab, counts = _table_only_device(h, d_ts, isz, d_se.ptr + 8 * k0, d_th.ptr + 8 * k0, C, D, rows, T, n,
-                                                 neg, minDuration, joinGaps, maxGap)
-            finally:
-                d_ts.free()
-            tables.append(tab)
-            counts_all.append(counts)
-            k0 += n
+        c0, c1 = (0, N) if columns is None else (int(columns[0]), int(columns[1]))
+        slabs = [(lo, min(c1, lo + cb)) for lo in range(c0, c1, cb)]
+        held = []                                   # sharded: compacted slabs wait for the offset exchange
+        try:
+            if columns is not None:
+                for lo, hi in slabs:
+                    d_ts, keep = compact_columns(stacked, lo, hi, anynans)
+                    held.append((d_ts, keep))
+                k0, total = exchange(int(sum(int(k.sum()) for _, k in held)))
+                if total != C:
+                    raise XmhwException(f"temp has {total} ocean cells, th and se have {C}")
+            first = k0
+            for i, (lo, hi) in enumerate(slabs):
+                if columns is not None:
+                    d_ts, keep = held[i]
+                    held[i] = (None, keep)
+                else:
+                    d_ts, keep = compact_columns(stacked, lo, hi, anynans)
+                keeps.append(keep)
+                n = int(keep.sum())
+                if d_ts is None:
+                    continue
+                try:
+                    if k0 + n > C:
+                        raise XmhwException(f"temp has more ocean cells than th and se ({C})")
+                    tab, counts = _table_only_device(h, d_ts, isz, d_se.ptr + 8 * k0, d_th.ptr + 8 * k0, C, D, rows, T,
+                                                     n, neg, minDuration, joinGaps, maxGap)
+                finally:
+                    d_ts.free()
+                tables.append(tab)
+                counts_all.append(counts)
+                k0 += n
+        finally:
+            for d_ts, _ in held:
+                if d_ts is not None:
+                    d_ts.free()
     finally:
         for b in clim_bufs:
             b.free()
     keep = np.concatenate(keeps) if keeps else np.zeros(0, dtype=bool)
-    if not keep.any():
-        raise XmhwException("All points of grid are either land or NaN")
-    if k0 != C:
-        raise XmhwException(f"temp has {k0} ocean cells, th and se have {C}")
+    if columns is None:
+        if not keep.any():
+            raise XmhwException("All points of grid are either land or NaN")
+        if k0 != C:
+            raise XmhwException(f"temp has {k0} ocean cells, th and se have {C}")
+    k0 -= first
     offsets = np.zeros(k0 + 1, dtype=np.int64)
-    np.cumsum(np.concatenate(counts_all), out=offsets[1:])
+    if counts_all:
+        np.cumsum(np.concatenate(counts_all), out=offsets[1:])
     table = np.concatenate(tables, axis=0) if tables else np.zeros((0, len(EVENT_COLUMNS)))
     return dict(table=table, offsets=offsets, inter=None, keep=keep)
 

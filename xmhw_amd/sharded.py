@@ -253,10 +253,87 @@ def make_sharded_detect(group=None, dst=0, device=None, compute=None):
     return sharded
 
 
-def detect_sharded(temp, th, se, group=None, dst=0, device=None, _compute=None, **kwargs):
-    """detect() over all ranks of ``group`` (cells shard exactly as in threshold_sharded; the event
-    tables are gathered to rank ``dst``, which gets what detect() returns; the others get None)."""
+def make_sharded_detect_grid(group=None, dst=0, device=None, grid_compute=None):
+    """A drop-in for detect_front.detect_grid: every rank masks and compacts its own block of the
+    uncompacted series columns on its GPU; the survivor counts are all-gathered (a block's cells
+    pair up with the climatology columns at the offset of the blocks before it), then the event
+    tables travel as in make_sharded_detect and the keep masks are all-gathered."""
+    import torch
+    import torch.distributed as dist
+    from .detect_front import EVENT_COLUMNS, detect_grid
+
+    inner = grid_compute or detect_grid
+    ncol = len(EVENT_COLUMNS)
+    fallback = make_sharded_detect(group, dst, device, None)
+
+    def sharded(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
+                intermediate=False, clim_stacked=False):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        dev = _device_for(group, device)
+        N = stacked.shape[1]
+        bounds = slab_bounds(N, world)
+        lo, hi = bounds[rank]
+
+        def exchange(n_mine):
+            mine = torch.tensor([n_mine], dtype=torch.int64, device=dev)
+            parts = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine, group=group)
+            counts = [int(v.item()) for v in parts]
+            return sum(counts[:rank]), sum(counts)
+
+        if intermediate:
+            raise XmhwException("detect_sharded: intermediate=True is only available through the host "
+                                "land_check path (pass _compute)")
+        res = inner(stacked, anynans, seas, thresh, doy, doys, minDuration, joinGaps, maxGap, coldSpells, False,
+                    clim_stacked=clim_stacked, columns=(lo, hi), exchange=exchange)
+        # keep masks to everybody, per-cell event counts and the tables to dst
+        width = max(b - a for a, b in bounds)
+        mine = torch.zeros(width, dtype=torch.uint8, device=dev)
+        mine[: hi - lo] = torch.as_tensor(res["keep"].astype(np.uint8), device=dev)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        keep = np.concatenate([parts[r][: b - a].cpu().numpy() != 0 for r, (a, b) in enumerate(bounds)])
+        if not keep.any():
+            raise XmhwException("All points of grid are either land or NaN")
+        ncells = [int(keep[a:b].sum()) for a, b in bounds]
+        cmax = max(max(ncells), 1)
+        cnt = torch.zeros(cmax, dtype=torch.int64, device=dev)
+        if ncells[rank]:
+            cnt[: ncells[rank]] = torch.as_tensor(np.diff(res["offsets"]), device=dev)
+        cnts = [torch.zeros_like(cnt) for _ in range(world)] if rank == dst else None
+        dist.gather(cnt, cnts, dst=dst, group=group)
+        n_r = torch.tensor([res["table"].shape[0]], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(n_r) for _ in range(world)]
+        dist.all_gather(sizes, n_r, group=group)
+        sizes = [int(v.item()) for v in sizes]
+        pad = torch.zeros((max(max(sizes), 1), ncol), dtype=torch.float64, device=dev)
+        if sizes[rank]:
+            pad[: sizes[rank]] = torch.as_tensor(res["table"], device=dev)
+        out = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+        dist.gather(pad, out, dst=dst, group=group)
+        C = int(keep.sum())
+        if rank != dst:
+            return dict(table=np.zeros((0, ncol)), offsets=np.zeros(C + 1, dtype=np.int64), inter=None, keep=keep)
+        table = np.concatenate([out[r][: sizes[r]].cpu().numpy() for r in range(world)], axis=0)
+        counts = np.concatenate([cnts[r][: ncells[r]].cpu().numpy() for r in range(world)])
+        offsets = np.zeros(C + 1, dtype=np.int64)
+        np.cumsum(counts, out=offsets[1:])
+        return dict(table=table, offsets=offsets, inter=None, keep=keep)
+
+    return sharded
+
+
+def detect_sharded(temp, th, se, group=None, dst=0, device=None, _compute=None, _grid_compute=None, **kwargs):
+    """detect() over all ranks of ``group``; rank ``dst`` gets what detect() returns, the others None.
+    The ranks split the uncompacted grid columns and each masks / compacts its own block on its GPU
+    (survivor counts are exchanged so that every block finds its climatology columns); ``_compute``
+    (test hook, compact-array stand-in; also needed for intermediate=True) selects the older path in
+    which every rank runs land_check() on the host and the compact cells are split."""
     import torch.distributed as dist
 
-    out = _detect(temp, th, se, make_sharded_detect(group, dst, device, _compute), **kwargs)
+    if _compute is not None or kwargs.get("intermediate"):
+        out = _detect(temp, th, se, make_sharded_detect(group, dst, device, _compute), **kwargs)
+    else:
+        out = _detect(temp, th, se, make_sharded_detect(group, dst, device, None),
+                      grid_compute=make_sharded_detect_grid(group, dst, device, _grid_compute), **kwargs)
     return out if dist.get_rank(group) == dst else None
