@@ -420,7 +420,8 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
             const uint32_t p_first = p0;
             const int32_t rank_gap = static_cast<int32_t>(lo) - static_cast<int32_t>(F0);
             // probes aim at the middle of the window of acceptable ranks
-            const float aim = static_cast<float>(lo) - 0.5f * static_cast<float>(SLACK) + 0.5f;
+            // (centre of the window and the 0.75/0.25 blend below: tools/sim_tune.py, 2.71 -> 2.60 passes per wave-row)
+            const float aim = static_cast<float>(lo) - 0.5f * static_cast<float>(SLACK);
 
             bool resolved = (n == 0);
             uint32_t alo = 0, ahi = 0, pe = 0, Fe = 0;
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
                 if (rank_gap > 1 || rank_gap < -1) {
                     const float obs = (static_cast<float>(alo) - static_cast<float>(p_first)) *
                                       __builtin_amdgcn_rcpf(static_cast<float>(rank_gap));
-                    if (obs >= 1.0f && obs < 1.0e8f) kpr = 0.5f * kpr + 0.5f * obs;
+                    if (obs >= 1.0f && obs < 1.0e8f) kpr = 0.75f * kpr + 0.25f * obs;
                 }
             }
             if (n > 0 && allc) {

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void clim_ring_f64(
             }
             const uint64_t k_first = k0;
             const int32_t rank_gap = static_cast<int32_t>(lo) - static_cast<int32_t>(F0);
-            const float aim = static_cast<float>(lo) - 0.5f * static_cast<float>(SLACK) + 0.5f;
+            const float aim = static_cast<float>(lo) - 0.5f * static_cast<float>(SLACK);   // window centre (tools/sim_tune.py)
 
             bool resolved = (n == 0);
             double alo = 0.0, ahi = 0.0;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void clim_ring_f64(
                     const float dk = ka >= k_first ? static_cast<float>(ka - k_first)
                                                    : -static_cast<float>(k_first - ka);
                     const float obs = dk * __builtin_amdgcn_rcpf(static_cast<float>(rank_gap));
-                    if (obs >= 1.0f && obs < 1.0e30f) kpr = 0.5f * kpr + 0.5f * obs;
+                    if (obs >= 1.0f && obs < 1.0e30f) kpr = 0.75f * kpr + 0.25f * obs;
                 }
             }
             if (n > 0 && allc && ke >= kKeyNegInf) {
