@@ -75,7 +75,7 @@ def test_gridded_against_oracle(front, dtype):
 
 
 @pytest.mark.parametrize("T", [5, 63, 64, 65, 128, 1000])
-@pytest.mark.parametrize("params", [(5, True, 2), (2, True, 1), (3, False, 0), (1, True, 0)])
+@pytest.mark.parametrize("params", [(5, True, 2), (2, True, 1), (3, False, 0), (1, True, 0), (70, True, 3), (64, True, 5)])
 def test_table_only_path_equals_per_step_path(front, T, params):
     """The bit-packed / thread-per-event pipeline and the per-step kernels run the same per-event
     arithmetic in the same order: identical tables, for series whose runs touch both ends, span
@@ -91,6 +91,9 @@ def test_table_only_path_equals_per_step_path(front, T, params):
     x[-min(T, 7):, 3] = 10.0                     # run reaching the series end
     x[rng.random((T, C)) < 0.03] = np.nan
     x[:, 4] = np.nan
+    if T >= 200:                                 # runs longer than the opening filter's 64-step reach
+        x[20:20 + 75, 5] = 10.0; x[100:100 + 64, 5] = 10.0; x[100 + 64 + 2:100 + 64 + 2 + 90, 5] = 10.0
+        x[T - 130:, 6] = 10.0
     doy = (np.arange(T) % 366) + 1
     doys = np.arange(1, min(T, 366) + 1)
     se = rng.normal(size=(doys.shape[0], C)) * 0.1
