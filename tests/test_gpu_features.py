@@ -110,6 +110,17 @@ def test_table_only_path_equals_per_step_path(front, T, params):
                     a = front.detect_cells(x.astype(dtype), se, th, doy, doys, m, jg, gap, coldSpells=cold)
                     npt.assert_array_equal(a["offsets"], b["offsets"])
                     npt.assert_array_equal(a["table"], b["table"])
+        # and against the loop oracles, for the cells with the long runs
+        if T >= 200:
+            rows = np.searchsorted(doys, doy)
+            for c in (5, 6, 9):
+                xc = x[:, c]
+                _, s0, e0, ev = det.detect_front(xc, th[:, c], rows, m, jg, gap)
+                want = fo.event_table(xc, se[rows, c], th[rows, c], s0, e0, ev)
+                r = front.detect_cells(x, se, th, doy, doys, m, jg, gap)
+                got = r["table"][r["offsets"][c]:r["offsets"][c + 1]]
+                assert got.shape == want.shape, (c, m)
+                npt.assert_allclose(got, want, rtol=1e-9, atol=1e-11, equal_nan=True)
     finally:
         h.set_exceed_kernel(0)
 
