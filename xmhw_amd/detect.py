@@ -19,7 +19,7 @@ import numpy as np
 from . import calendar as cal
 from . import landmask
 from .api import GITHUB, GridSeries, _from_xarray, _is_xarray
-from .detect_front import EVENT_COLUMNS, INTERMEDIATE_F64, INTERMEDIATE_U8, detect_cells, detect_grid
+from .detect_front import EVENT_COLUMNS, INTERMEDIATE_U8, detect_cells, detect_grid
 from .exception import XmhwException
 
 TIME_COLUMNS = ("time_start", "time_end", "time_peak")
