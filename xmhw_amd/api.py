@@ -162,7 +162,14 @@ def _threshold(temp, compute, tdim="time", climatologyPeriod=[None, None], pctil
     if all(climatologyPeriod):                                # xmhw.py:112-119 (both truthy)
         yrs = cal.years_of(time)
         sel = (yrs >= int(climatologyPeriod[0])) & (yrs <= int(climatologyPeriod[1]))
-        values = np.compress(sel, values, axis=tax)
+        idx = np.nonzero(sel)[0]
+        if idx.size and idx[-1] - idx[0] + 1 == idx.size:
+            # a contiguous run of steps (any sorted time axis): a view, not a copy of the series
+            cut = [slice(None)] * values.ndim
+            cut[tax] = slice(int(idx[0]), int(idx[-1]) + 1)
+            values = values[tuple(cut)]
+        else:
+            values = np.compress(sel, values, axis=tax)
         time = time[sel]
     if time.shape[0] == 0:
         raise XmhwException("time axis is empty")
