@@ -270,3 +270,18 @@ def test_large_buffers_are_recycled_and_released():
     assert len(dv._POOL) == 1
     release_device_cache()
     assert dv._POOL == []
+
+
+def test_big_endian_and_integer_input(oisst):
+    """netCDF-3 style big-endian float32 keeps its width (and the float32 kernels); integers go to float64."""
+    from xmhw_amd import threshold
+    from xmhw_amd.device import native_float
+    ref = threshold(_grid(oisst))
+    be = threshold(_grid(oisst, oisst["sst"].astype(">f4")))
+    npt.assert_array_equal(be["thresh"], ref["thresh"])
+    npt.assert_array_equal(be["seas"], ref["seas"])
+    assert native_float(oisst["sst"].astype(">f4")).dtype == np.float32
+    ints = np.where(np.isnan(oisst["sst"]), -99, np.round(oisst["sst"] * 10)).astype(np.int16)
+    a = threshold(_grid(oisst, ints), smoothPercentile=False)
+    b = threshold(_grid(oisst, ints.astype(np.float64)), smoothPercentile=False)
+    npt.assert_array_equal(a["thresh"], b["thresh"])

@@ -11,7 +11,7 @@ reference-shaped entry point on top of detect_cells().
 import numpy as np
 
 from ._lib import hip
-from .device import DeviceBuffer
+from .device import DeviceBuffer, native_float
 from .exception import XmhwException
 
 
@@ -72,10 +72,7 @@ INTERMEDIATE_U8 = ["duration_moderate", "duration_strong", "duration_severe", "d
 
 
 def _check_inputs(ts, seas, thresh, doy, doys):
-    ts = np.asarray(ts)
-    if ts.dtype not in (np.float32, np.float64):
-        ts = ts.astype(np.float64)
-    ts = np.ascontiguousarray(ts)
+    ts = np.ascontiguousarray(native_float(ts))
     thresh = np.ascontiguousarray(thresh, dtype=np.float64)
     seas = np.ascontiguousarray(seas, dtype=np.float64)
     if ts.ndim != 2 or thresh.shape != seas.shape or thresh.ndim != 2 or ts.shape[1] != thresh.shape[1]:
@@ -245,10 +242,7 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
     that offset - and the result covers the block only (keep has c1 - c0 entries, no error for an
     all-land block)."""
     from .device import _grid_batch, compact_columns
-    stacked = np.asarray(stacked)
-    if stacked.dtype not in (np.float32, np.float64):
-        stacked = stacked.astype(np.float64)
-    stacked = np.ascontiguousarray(stacked)
+    stacked = np.ascontiguousarray(native_float(stacked))
     T, N = stacked.shape
 
     def host_compact(a):

@@ -8,6 +8,16 @@ from .exception import XmhwException
 KERNELS = {"auto": 0, "ring": 1, "generic": 2}
 
 
+def native_float(a):
+    """The array as native-endian float32 or float64 (what the kernels read): float32 / float64 of
+    either byte order keep their width (netCDF-3 and some GRIB decoders hand over big-endian
+    arrays), every other dtype becomes float64."""
+    a = np.asarray(a)
+    if a.dtype.kind == "f" and a.dtype.itemsize in (4, 8):
+        return a if a.dtype.isnative else a.astype(a.dtype.newbyteorder("="))
+    return a.astype(np.float64)
+
+
 # Large allocations are kept for the next call instead of being returned to the driver: hipMalloc of
 # tens of GB costs about a second (page tables), which is as much as the upload of a global grid and
 # far more than the kernels.  At most _POOL_SLOTS buffers of >= _POOL_MIN bytes are held;
@@ -159,9 +169,7 @@ def calc_clim_device(ts, doy, pctile, windowHalfWidth, smoothPercentile, smoothP
     float64 input whose samples are all float32-representable runs on the float32 ring kernel
     (decided on the device, see xmhw_plan_set_narrowing); narrowing=False forces the float64 one.
     """
-    ts = np.asarray(ts)
-    if ts.dtype not in (np.float32, np.float64):
-        ts = ts.astype(np.float64)
+    ts = native_float(ts)
     if ts.ndim != 2:
         raise XmhwException("calc_clim_device expects a (time, cell) array")
     T, C = ts.shape
@@ -276,10 +284,7 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
     (D, C) arrays of the C = keep.sum() surviving cells instead.
     ``columns=(c0, c1)`` restricts the work to that column range (a rank's slab of a sharded run:
     keep and the arrays then cover c1 - c0 columns and an all-land slab is not an error)."""
-    stacked = np.asarray(stacked)
-    if stacked.dtype not in (np.float32, np.float64):
-        stacked = stacked.astype(np.float64)
-    stacked = np.ascontiguousarray(stacked)
+    stacked = np.ascontiguousarray(native_float(stacked))
     T, N = stacked.shape
     h = hip()
     plan = Plan(doy, windowHalfWidth, kernel=kernel, nchunks=nchunks, narrowing=narrowing)
