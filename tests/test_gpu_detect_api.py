@@ -106,3 +106,28 @@ def test_intermediate_kernel_matches_reference_mhw_df():
         for k, name in enumerate(cols):
             npt.assert_array_equal(np.asarray(r["inter"][name][:, 0], dtype=np.float64), want[k],
                                    err_msg=f"case {case} {name}")
+
+
+def test_tstep_axis_end_to_end():
+    """tstep=True (labels = step of the year; no Feb-29 handling): threshold() -> detect() on a
+    365-steps-per-year axis against the oracle-driven host pipeline."""
+    from xmhw_amd import GridSeries, climatology_series, detect, threshold
+    from xmhw_amd.detect import _detect
+    t = np.arange("2001-01-01", "2010-01-01", dtype="datetime64[D]")
+    t = t[~((t.astype("datetime64[M]").astype(int) % 12 == 1) & ((t - t.astype("datetime64[M]")).astype(int) == 28))]
+    assert t.shape[0] == 9 * 365
+    rng = np.random.default_rng(12)
+    T = t.shape[0]
+    anom = np.zeros((T, 3, 4))
+    e = rng.normal(size=(T, 3, 4))
+    for k in range(1, T):
+        anom[k] = 0.9 * anom[k - 1] + e[k]
+    x = (15 + 3 * np.sin(2 * np.pi * np.arange(T)[:, None, None] / 365.0) + anom).astype(np.float32)
+    x[:, 0, 0] = np.nan
+    g = GridSeries(x, ("time", "lat", "lon"), {"time": t, "lat": np.arange(3), "lon": np.arange(4)})
+    clim = threshold(g, tstep=True, smoothPercentileWidth=11)
+    assert clim["thresh"].shape[0] == 365
+    th, se = climatology_series(clim, "thresh"), climatology_series(clim, "seas")
+    mhw = detect(g, th, se, tstep=True)
+    ref = _detect(g, th, se, oracle_detect_cells, tstep=True)
+    _compare(mhw, ref)
