@@ -50,14 +50,17 @@ def calc_clim_cell(x, doys, pools, q, tstep, smooth, width, skipna=False):
 
 
 def threshold_cells_percell(ts, doy, pctile=90, windowHalfWidth=5, smoothPercentile=True,
-                            smoothPercentileWidth=31, tstep=False, skipna=False, coldSpells=False):
+                            smoothPercentileWidth=31, tstep=False, skipna=False, coldSpells=False,
+                            pools=None):
+    """``pools``: a precomputed ``_pool_index(doy, windowHalfWidth)`` (the timed baseline builds it
+    once per worker, outside the timed region)."""
     if smoothPercentileWidth % 2 == 0:
         raise XmhwException("smoothPercentileWidth should be odd")
     ts = np.asarray(ts)
     if ts.ndim == 1:
         ts = ts[:, None]
     doy = np.asarray(doy, dtype=np.int64)
-    doys, pools = _pool_index(doy, windowHalfWidth)
+    doys, pools = pools if pools is not None else _pool_index(doy, windowHalfWidth)
     D, C = doys.shape[0], ts.shape[1]
     thresh = np.full((D, C), np.nan)
     seas = np.full((D, C), np.nan)

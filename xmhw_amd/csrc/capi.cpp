@@ -24,6 +24,12 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 int hip_fail(hipError_t e, const char* what) {
+    // out of device memory is reported as such wherever it happens (callers that cache device
+    // buffers release them and retry on XMHW_ERR_NOMEM)
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        return fail(XMHW_ERR_NOMEM, std::string(what) + ": out of device memory");
+    }
     return fail(XMHW_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 #define HIP_TRY(expr)                                        \
@@ -359,9 +365,12 @@ int exceed_bits(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* th
     if constexpr (sizeof(T) == 4) {
         // float32 series: compare against the float32 floor of the thresholds (same results, see
         // kernels_events.hip), 4 instead of 8 bytes per threshold
-        HIP_TRY(hipMalloc(&thf, sizeof(float) * static_cast<size_t>(D) * static_cast<size_t>(ldt)));
-        e = xmhw::launch_floor_to_f32(thresh, D * ldt, thf, st);
+        // only the addressed (D, C) region is converted: `thresh` may point into a wider array
+        // (column block k0 of a (D, ldt) climatology), where D * ldt elements would overrun it
+        HIP_TRY(hipMalloc(&thf, sizeof(float) * static_cast<size_t>(D) * static_cast<size_t>(C)));
+        e = xmhw::launch_floor_to_f32(thresh, D, C, ldt, thf, C, st);
     }
+    const int64_t ldtf = sizeof(T) == 4 ? C : ldt;   // leading dimension of the thresholds the kernels read
     if (e == hipSuccess && tiled) {
         DeviceI32 d_tb(ch.tile_begin, st), d_t0(ch.t0, st), d_i0(ch.i0, st), d_n(ch.n, st);
         for (const DeviceI32* d : {&d_tb, &d_t0, &d_i0, &d_n})
@@ -372,7 +381,7 @@ int exceed_bits(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* th
                                             sizeof(uint64_t) * static_cast<size_t>(C), static_cast<size_t>(W), st);
         if (e == hipSuccess) {
             if constexpr (sizeof(T) == 4)
-                e = xmhw::launch_exceed_bits_tiled<float, float, 64>(ts, C, ld, thf, ldt, D, d_tb.ptr, ch.ntiles,
+                e = xmhw::launch_exceed_bits_tiled<float, float, 64>(ts, C, ld, thf, ldtf, D, d_tb.ptr, ch.ntiles,
                                                                      d_t0.ptr, d_i0.ptr, d_n.ptr, negate, bits, ldb, st);
             else
                 e = xmhw::launch_exceed_bits_tiled<double, double, 32>(ts, C, ld, thresh, ldt, D, d_tb.ptr, ch.ntiles,
@@ -390,7 +399,7 @@ int exceed_bits(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* th
         e = rows.err;
         if (e == hipSuccess) {
             if constexpr (sizeof(T) == 4)
-                e = xmhw::launch_exceed_bits<float, float>(ts, Tn, C, ld, thf, ldt, rows.ptr, negate, bits, ldb, st);
+                e = xmhw::launch_exceed_bits<float, float>(ts, Tn, C, ld, thf, ldtf, rows.ptr, negate, bits, ldb, st);
             else
                 e = xmhw::launch_exceed_bits<double, double>(ts, Tn, C, ld, thresh, ldt, rows.ptr, negate, bits, ldb, st);
         }

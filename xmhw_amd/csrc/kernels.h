@@ -78,7 +78,8 @@ hipError_t launch_event_stats(const T* ts, int64_t Tn, int64_t C, int64_t ld, co
                               hipStream_t stream);
 
 // table-only define_events() (kernels_events.hip): exceedance bits, run walk, per-event statistics
-hipError_t launch_floor_to_f32(const double* th, int64_t n, float* out, hipStream_t stream);
+hipError_t launch_floor_to_f32(const double* th, int64_t rows, int64_t cols, int64_t ldi, float* out, int64_t ldo,
+                               hipStream_t stream);
 template <typename T, typename TH>
 hipError_t launch_exceed_bits(const T* ts, int64_t Tn, int64_t C, int64_t ld, const TH* thresh, int64_t ldt,
                               const int32_t* row_of_t, int32_t negate, uint64_t* bits, int64_t ldb,

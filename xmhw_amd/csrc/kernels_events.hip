@@ -26,14 +26,18 @@ constexpr int kBitsLoadAhead = 8;
 // float32 series: (double)x > th  <=>  x > tf with tf = the largest float32 <= th (the next float32
 // above tf is > th by construction; NaN and +-inf carry over), so the re-expanded threshold rows
 // can be read as 4-byte values without changing a single bit of the result.
-__global__ __launch_bounds__(256) void floor_to_f32(const double* __restrict__ th, int64_t n,
-                                                    float* __restrict__ out) {
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double v = th[i];
-    float f = static_cast<float>(v);                       // round to nearest
-    if (static_cast<double>(f) > v) f = nextafterf(f, -INFINITY);
-    out[i] = f;
+// (rows, cols) region of a row-major array with leading dimension ldi -> compact (rows, ldo) floats:
+// only the addressed region is read, so a column block of a wider array can be converted in place.
+__global__ __launch_bounds__(256) void floor_to_f32(const double* __restrict__ th, int64_t rows, int64_t cols,
+                                                    int64_t ldi, float* __restrict__ out, int64_t ldo) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+        const double v = th[r * ldi + c];
+        float f = static_cast<float>(v);                       // round to nearest
+        if (static_cast<double>(f) > v) f = nextafterf(f, -INFINITY);
+        out[r * ldo + c] = f;
+    }
 }
 
 template <typename T, typename TH>
@@ -304,9 +308,11 @@ __global__ __launch_bounds__(256) void event_stats_sparse(const T* __restrict__ 
     flush_event(a, Tn - 1, row);
 }
 
-hipError_t launch_floor_to_f32(const double* th, int64_t n, float* out, hipStream_t stream) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(floor_to_f32, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, th, n, out);
+hipError_t launch_floor_to_f32(const double* th, int64_t rows, int64_t cols, int64_t ldi, float* out, int64_t ldo,
+                               hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    hipLaunchKernelGGL(floor_to_f32, dim3(static_cast<unsigned>((cols + 255) / 256), static_cast<unsigned>(rows < 65535 ? rows : 65535)),
+                       dim3(256), 0, stream, th, rows, cols, ldi, out, ldo);
     return hipGetLastError();
 }
 

@@ -541,8 +541,12 @@ __global__ __launch_bounds__(256) void clim_ring_f32(
         // drift apart until the shared lines have left L2 and are fetched again: measured
         // 1.36x the input bytes at L2-miss level (TCC_EA0_RDREQ_128B), 1.03x with this
         // occasional rendezvous (+1 % time; every 4 rows: +5 %).  Trip counts are workgroup-
-        // uniform (same chunk), so the barrier is safe.
-        if ((s & 63) == 63) __syncthreads();
+        // uniform (same chunk), so the barrier is safe -- except in the narrowing instantiation,
+        // whose waves may leave the loop on their own (lossy sample, flag already set): there the
+        // rendezvous is compiled out (a wave that has left would make the barrier divergent).
+        if constexpr (!kNarrow) {
+            if ((s & 63) == 63) __syncthreads();
+        }
         // ---- rotate the software pipeline --------------------------------------------
 #pragma unroll
         for (int y = 0; y < YPS; ++y) {

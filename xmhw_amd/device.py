@@ -20,46 +20,55 @@ def native_float(a):
 
 # Large allocations are kept for the next call instead of being returned to the driver: hipMalloc of
 # tens of GB costs about a second (page tables), which is as much as the upload of a global grid and
-# far more than the kernels.  At most _POOL_SLOTS buffers of >= _POOL_MIN bytes are held;
-# release_device_cache() frees them.
+# far more than the kernels.  At most _POOL_SLOTS buffers of >= _POOL_MIN bytes and _POOL_MAX_BYTES in
+# total are held (XMHW_AMD_POOL_GB overrides the total; 0 disables the cache); entries carry the
+# device they were ALLOCATED on.  release_device_cache() frees them; every entry point of the C ABI
+# that runs out of device memory calls it and retries once (xmhw_amd._lib).
+import os as _os
+
 _POOL = []
 _POOL_SLOTS = 4
 _POOL_MIN = 1 << 30
+_POOL_MAX_BYTES = int(float(_os.environ.get("XMHW_AMD_POOL_GB", "96")) * (1 << 30))
 
 
 def release_device_cache():
-    """Return the cached large device buffers (see DeviceBuffer) to the driver."""
+    """Return the cached large device buffers (see DeviceBuffer) to the driver; the number of
+    bytes released."""
     h = hip()
+    freed = 0
     while _POOL:
-        _, ptr, _ = _POOL.pop()
+        cap, ptr, _ = _POOL.pop()
         h.free(ptr)
+        freed += cap
+    return freed
+
+
+def device_cache_bytes():
+    return sum(cap for cap, _, _ in _POOL)
 
 
 class DeviceBuffer:
     """Caller-owned HBM allocation (hipMalloc through the C ABI); buffers of a GB or more are
-    recycled through a small pool."""
+    recycled through a small, size-capped pool."""
 
     def __init__(self, nbytes):
         self._h = hip()
         self.nbytes = int(nbytes)
         self.capacity = self.nbytes
         self.ptr = 0
+        self.device = -1
         if not self.nbytes:
             return
+        self.device = self._h.get_device()      # the device this buffer lives on, recorded at allocation
         if self.nbytes >= _POOL_MIN and _POOL:
-            dev = self._h.get_device()          # a pooled buffer belongs to the device it was allocated on
-            fit = [i for i, (cap, _, d) in enumerate(_POOL) if d == dev and self.nbytes <= cap <= 2 * self.nbytes]
+            fit = [i for i, (cap, _, d) in enumerate(_POOL)
+                   if d == self.device and self.nbytes <= cap <= 2 * self.nbytes]
             if fit:
                 i = min(fit, key=lambda k: _POOL[k][0])
                 self.capacity, self.ptr, _ = _POOL.pop(i)
                 return
-        try:
-            self.ptr = self._h.malloc(self.nbytes)
-        except Exception:
-            if not _POOL:
-                raise
-            release_device_cache()          # out of memory with buffers parked in the pool: retry without
-            self.ptr = self._h.malloc(self.nbytes)
+        self.ptr = self._h.malloc(self.nbytes)   # out of memory: the pool is drained and the call retried (_lib)
 
     @classmethod
     def from_array(cls, a):
@@ -79,8 +88,9 @@ class DeviceBuffer:
 
     def free(self):
         if self.ptr:
-            if self.capacity >= _POOL_MIN and len(_POOL) < _POOL_SLOTS:
-                _POOL.append((self.capacity, self.ptr, self._h.get_device()))
+            if (self.capacity >= _POOL_MIN and len(_POOL) < _POOL_SLOTS
+                    and device_cache_bytes() + self.capacity <= _POOL_MAX_BYTES):
+                _POOL.append((self.capacity, self.ptr, self.device))
             else:
                 self._h.free(self.ptr)
             self.ptr = 0
