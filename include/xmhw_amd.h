@@ -97,9 +97,16 @@ int xmhw_plan_set_chunks(xmhw_plan *plan, int32_t nchunks); /* 0 = auto         
 int xmhw_plan_table(const xmhw_plan *plan, int32_t years_per_lane, uint32_t *table_out,
                     int32_t *ntracks_padded);
 
-/* debug: ring-kernel pass counters {rows, count passes, extractions, cold starts}
- * summed over waves since the last read; enable != 0 allocates the counters    */
-int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out4);
+/* debug: ring-kernel pass counters {rows, 32-bit count passes, extractions, cold starts,
+ * fast steps, 8-bit probes, code-ring rebuilds, 0} (per wave, summed since the last read);
+ * enable != 0 allocates the counters; out8 receives 8 values                          */
+int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out8);
+
+/* second-generation float32 ring kernel (w = 5, <= 40 tracks; xmhw_amd/csrc/kernels_ring2.hip):
+ * variant -1 = off (round-1 kernel), 0 = lean steps, +1 = 8-bit SAD probes, +2 = extraction
+ * that skips empty ring positions.  The environment variable XMHW_RING2 sets the default of new
+ * plans.  All variants return bit-identical results.                                  */
+int xmhw_plan_set_ring2(xmhw_plan *plan, int32_t variant);
 
 /* ---- the hot path ------------------------------------------------------ *
  * xmhw_clim_raw_*: for every cell, the pooled linear-interpolated quantile

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Time the ring-kernel variants on one BASELINE shape (device-resident synthetic input).
+   python tools/bench_ring2.py [--config 0.25deg|1deg|0.25deg_nan|0.05deg_tstep] [--cells N] [--variants -1 0 1 2 3]
+Prints one JSON line per variant: kernel ms (HIP events, median of --reps), pass statistics per
+wave-row, bit-identity of thresh against variant -1 on a column sample."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="0.25deg")
+    ap.add_argument("--cells", type=int, default=0)
+    ap.add_argument("--variants", type=int, nargs="*", default=[-1, 0, 1, 2, 3])
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--chunks", type=int, default=0)
+    args = ap.parse_args()
+    import xmhw_amd.device as dev
+    from xmhw_amd.calendar import add_doy
+    h = dev.hip()
+    presets = {"0.25deg": (1440 * 720, (1982, 2021), 0.0, False), "1deg": (360 * 180, (1991, 2020), 0.0, False),
+               "0.25deg_nan": (1440 * 720, (1982, 2021), 0.05, False), "0.05deg_tstep": (810000, (2001, 2020), 0.0, True)}
+    C, years, nan, tstep = presets[args.config]
+    C = args.cells or C
+    if tstep:
+        doy = np.tile(np.arange(1, 1461, dtype=np.int64), years[1] - years[0] + 1)
+    else:
+        doy = add_doy(np.arange(f"{years[0]}-01-01", f"{years[1] + 1}-01-01", dtype="datetime64[D]"))
+    T = doy.shape[0]
+    ts = dev.DeviceBuffer(4 * T * C)
+    h.synth_sst(ts.ptr, 4, T, C, C, 0, 20260103, nan, 0)
+    ref = None
+    idx = np.unique(np.linspace(0, C - 1, 2048).astype(np.int64))
+    d_idx = dev.DeviceBuffer.from_array(idx)
+    for v in args.variants:
+        plan = dev.Plan(doy, 5, nchunks=args.chunks, ring2=v)
+        D = plan.D
+        th, se = dev.DeviceBuffer(8 * D * C), dev.DeviceBuffer(8 * D * C)
+        e0, e1 = h.event_create(), h.event_create()
+        dev.clim_raw(plan, ts, 4, C, 0.9, False, th, se)      # warm-up (plan upload)
+        h.stream_sync(0)
+        h.plan_debug_stats(plan.handle, 1, False)
+        ms = []
+        for _ in range(args.reps):
+            h.event_record(e0, 0)
+            dev.clim_raw(plan, ts, 4, C, 0.9, False, th, se)
+            h.event_record(e1, 0)
+            ms.append(h.event_elapsed_ms(e0, e1))
+        st = h.plan_debug_stats(plan.handle, 1, True).astype(np.float64)
+        sub = dev.DeviceBuffer(8 * D * idx.size)
+        h.gather_cells(th.ptr, 8, D, C, d_idx.ptr, idx.size, sub.ptr, idx.size)
+        h.stream_sync(0)
+        got = sub.to_array((D, idx.size), np.float64)
+        h.gather_cells(se.ptr, 8, D, C, d_idx.ptr, idx.size, sub.ptr, idx.size)
+        h.stream_sync(0)
+        got_se = sub.to_array((D, idx.size), np.float64)
+        if ref is None:
+            ref = (got, got_se)
+        rows = max(st[0], 1.0)
+        bytes_per_cell = T * 4 + 2 * D * 8
+        med = float(np.median(ms))
+        print(json.dumps({"variant": v, "config": args.config, "cells": C, "ms": med, "ms_all": [round(m, 3) for m in ms],
+                          "algorithmic_GBs": C * bytes_per_cell / med / 1e6, "frac_of_8TBs": C * bytes_per_cell / med / 1e6 / 8000,
+                          "count_passes_per_row": st[1] / rows, "extractions_per_row": st[2] / rows,
+                          "cold_per_row": st[3] / rows, "fast_steps_per_row": st[4] / rows,
+                          "probes8_per_row": st[5] / rows, "rebases_per_row": st[6] / rows,
+                          "thresh_bit_identical_to_first": bool(np.array_equal(got, ref[0], equal_nan=True)),
+                          "seas_max_rel_diff": float(np.nanmax(np.abs(got_se - ref[1]) / np.abs(ref[1])))}), flush=True)
+        for b in (th, se, sub):
+            b.free()
+        plan.destroy()
+    ts.free()
+    dev.release_device_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -51,6 +52,10 @@ struct xmhw_plan {
     int32_t subs = 0;         // ... and its lanes per cell (8, or 16 for records of 49..96 tracks)
     int32_t nchunks = 0;
     uint32_t* d_table = nullptr;
+    int32_t yps2 = 0;         // second-generation float32 ring kernel (kernels_ring2.hip), 0: not available
+    int32_t ring2_variant = -1;   // -1: off; bit 0 = 8-bit SAD probes, bit 1 = skipping extraction
+    uint32_t* d_table2 = nullptr;
+    uint32_t* d_sflags = nullptr;
     int32_t yps64 = 0;        // float64 ring kernel tracks-per-lane (16 lanes per cell)
     uint32_t* d_table64 = nullptr;
     xmhw::DevChunk* d_chunks = nullptr;
@@ -65,6 +70,8 @@ struct xmhw_plan {
         if (d_narrow_flag) (void)hipFree(d_narrow_flag);
         if (d_table) (void)hipFree(d_table);
         if (d_table64) (void)hipFree(d_table64);
+        if (d_table2) (void)hipFree(d_table2);
+        if (d_sflags) (void)hipFree(d_sflags);
         if (d_chunks) (void)hipFree(d_chunks);
         if (d_row_ptr) (void)hipFree(d_row_ptr);
         if (d_centres) (void)hipFree(d_centres);
@@ -110,10 +117,15 @@ int upload(xmhw_plan* p, int64_t C) {
         HIP_TRY(put(&p->d_centres, h.centres));
         p->yps = xmhw::ring_pick(h.w, h.ntracks, 4, &p->subs);
         if (p->yps) HIP_TRY(put(&p->d_table, h.ring_table(p->subs, p->yps)));
+        p->yps2 = xmhw::ring2_pick_yps(h.w, h.ntracks);
+        if (p->yps2) {
+            HIP_TRY(put(&p->d_table2, h.ring_table(8, p->yps2)));
+            HIP_TRY(put(&p->d_sflags, h.step_flags()));
+        }
         p->yps64 = xmhw::ring64_pick_yps(h.w, h.ntracks);
         if (p->yps64) HIP_TRY(put(&p->d_table64, h.ring_table(16, p->yps64)));
     }
-    if (p->yps || p->yps64) {
+    if (p->yps || p->yps64 || p->yps2) {
         std::vector<xmhw::Chunk> ch = h.make_chunks(nchunks);
         std::vector<xmhw::DevChunk> dch(ch.size());
         for (size_t i = 0; i < ch.size(); ++i) dch[i] = {ch[i].warm_start, ch[i].begin, ch[i].end};
@@ -147,6 +159,11 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
     hipError_t e;
     if (kernel == XMHW_KERNEL_RING) {
         if constexpr (sizeof(T) == 4) {
+            if (plan->yps2 && plan->ring2_variant >= 0)
+                e = xmhw::launch_ring2_f32(reinterpret_cast<const float*>(ts), C, ld, h.T, plan->d_table2, plan->d_sflags,
+                                           h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps2, h.ntracks,
+                                           plan->ring2_variant, q, negate, thresh, seas, ldo, st, plan->d_stats);
+            else
             e = xmhw::launch_ring_f32(reinterpret_cast<const float*>(ts), C, ld, plan->d_table,
                                       h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps, plan->subs, q,
                                       negate, thresh, seas, ldo, st, plan->d_stats);
@@ -606,7 +623,14 @@ int xmhw_plan_create(const int32_t* doy_host, int64_t T, int32_t window_half_wid
         delete p;
         return fail(XMHW_ERR_INVALID, msg);
     }
+    if (const char* v = std::getenv("XMHW_RING2")) p->ring2_variant = std::atoi(v);
     *plan = p;
+    return XMHW_OK;
+}
+int xmhw_plan_set_ring2(xmhw_plan* plan, int32_t variant) {
+    if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
+    if (variant < -1 || variant > 3) return fail(XMHW_ERR_INVALID, "ring2 variant must be -1 (off) or 0..3");
+    plan->ring2_variant = variant;
     return XMHW_OK;
 }
 int xmhw_plan_destroy(xmhw_plan* plan) {
@@ -658,14 +682,14 @@ int xmhw_plan_set_chunks(xmhw_plan* plan, int32_t nchunks) {
 int xmhw_plan_debug_stats(xmhw_plan* plan, int enable, uint64_t* out4) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
     if (enable && !plan->d_stats) {
-        HIP_TRY(hipMalloc(&plan->d_stats, 4 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(plan->d_stats, 0, 4 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&plan->d_stats, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(plan->d_stats, 0, 8 * sizeof(unsigned long long)));
     }
     if (out4) {
         if (!plan->d_stats) return fail(XMHW_ERR_INVALID, "stats not enabled");
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(out4, plan->d_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemset(plan->d_stats, 0, 4 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemcpy(out4, plan->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(plan->d_stats, 0, 8 * sizeof(unsigned long long)));
     }
     return XMHW_OK;
 }

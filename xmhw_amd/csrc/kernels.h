@@ -25,6 +25,15 @@ hipError_t launch_ring_f32(const float* ts, int64_t C, int64_t ld, const uint32_
                            double* seas, int64_t ldo, hipStream_t stream,
                            unsigned long long* stats = nullptr);
 
+// second-generation float32 ring kernel (kernels_ring2.hip): 8 lanes per cell, tracks dealt y-major;
+// variant bit 0 = 8-bit SAD probes, bit 1 = extraction skips empty ring positions
+int32_t ring2_pick_yps(int32_t w, int32_t ntracks);   // 0 if not instantiated
+hipError_t launch_ring2_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
+                            const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,
+                            int32_t w, int32_t yps, int32_t ntracks, int32_t variant, double q, int negate,
+                            double* thresh, double* seas, int64_t ldo, hipStream_t stream,
+                            unsigned long long* stats = nullptr);
+
 // float64 input through the float32 ring kernel: zeroes narrow_flag, probes the series, runs the
 // kernel with samples narrowed on load; narrow_flag != 0 afterwards: some sample is not float32-
 // representable and the outputs are garbage (queue launch_ring_f64(..., run_flag = narrow_flag) behind)

@@ -47,6 +47,20 @@ bool Plan::build(const int32_t* doy, int64_t T_, int32_t w_) {
     return true;
 }
 
+std::vector<uint32_t> Plan::step_flags() const {
+    const std::vector<uint32_t> tab = ring_table(1, ntracks);      // [step][track]
+    std::vector<uint32_t> f(static_cast<size_t>(nsteps), 0u);
+    for (int32_t i = 0; i < nsteps; ++i) {
+        bool simple = true;
+        for (int32_t k = 0; k < ntracks; ++k) {
+            const uint32_t e = tab[static_cast<size_t>(i) * ntracks + k];
+            simple = simple && (e & 1u) && (e >> 1) >= 2u;
+        }
+        f[i] = simple ? 1u : 0u;
+    }
+    return f;
+}
+
 std::vector<uint32_t> Plan::ring_table(int32_t subs, int32_t yps) const {
     const int32_t ntp = subs * yps;
     std::vector<uint32_t> tab(static_cast<size_t>(nsteps) * ntp, make_entry(kCodeInvalid, true));

@@ -128,10 +128,11 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     });
 
     m.def("plan_debug_stats", [](uintptr_t p, int enable, bool read) {
-        py::array_t<uint64_t> out(4);
+        py::array_t<uint64_t> out(8);
         check(xmhw_plan_debug_stats(pp(p), enable, read ? out.mutable_data() : nullptr));
         return out;
     });
+    m.def("plan_set_ring2", [](uintptr_t p, int variant) { check(xmhw_plan_set_ring2(pp(p), variant)); });
 
     m.def("clim_raw", [](uintptr_t plan, uintptr_t ts, int itemsize, int64_t C, int64_t ld, double q, int negate,
                          uintptr_t th, uintptr_t se, int64_t ldo, uintptr_t stream) {

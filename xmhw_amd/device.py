@@ -105,7 +105,7 @@ class DeviceBuffer:
 class Plan:
     """Everything derived from the doy labels (xmhw_plan_* in the C ABI)."""
 
-    def __init__(self, doy, window_half_width, kernel="auto", nchunks=0, narrowing=True):
+    def __init__(self, doy, window_half_width, kernel="auto", nchunks=0, narrowing=True, ring2=None):
         self._h = hip()
         doy = np.ascontiguousarray(doy, dtype=np.int32)
         try:
@@ -115,6 +115,8 @@ class Plan:
         self._h.plan_set_kernel(self.handle, KERNELS[kernel])
         self._h.plan_set_chunks(self.handle, int(nchunks))
         self._h.plan_set_narrowing(self.handle, int(bool(narrowing)))
+        if ring2 is not None:           # None: the library default (environment XMHW_RING2)
+            self._h.plan_set_ring2(self.handle, int(ring2))
         info = self._h.plan_info(self.handle)
         self.D = info["D"]
         self.ntracks = info["ntracks"]
