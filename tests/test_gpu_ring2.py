@@ -60,7 +60,7 @@ def _raw(dev, x, doy, q=0.9, negate=False, nchunks=0, kernel="ring", ring2=-1):
         plan.destroy()
 
 
-def _compare(dev, x, doy, q=0.9, negate=False, nchunks=0, expect_fast=None):
+def _compare(dev, x, doy, q=0.9, negate=False, nchunks=1, expect_fast=None):
     t0, s0, _ = _raw(dev, x, doy, q, negate, nchunks, ring2=-1)
     tg, sg, _ = _raw(dev, x, doy, q, negate, kernel="generic")
     npt.assert_array_equal(t0, tg)
@@ -133,6 +133,8 @@ def test_partial_years_and_chunks(dev):
     x = _series(doy.shape[0], 45, 13)
     a, sa = _compare(dev, x, doy, nchunks=1)
     b, sb = _compare(dev, x, doy, nchunks=5)
+    c, sc = _compare(dev, x, doy, nchunks=0)
+    npt.assert_array_equal(a, c)
     npt.assert_array_equal(a, b)
     npt.assert_allclose(sa, sb, rtol=1e-13)
 

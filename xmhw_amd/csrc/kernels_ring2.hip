@@ -85,6 +85,12 @@ __device__ __forceinline__ uint32_t key_of_bits(uint32_t b, uint32_t negmask) {
 __device__ __forceinline__ uint32_t bits_of_key(uint32_t k) {
     return k ^ (~static_cast<uint32_t>(static_cast<int32_t>(k) >> 31) | 0x80000000u);
 }
+// identity the optimiser cannot see through: keeps the rare paths (masked rows, infinite samples)
+// from being merged with, or hoisted above, the per-row code
+__device__ __forceinline__ uint32_t opaque(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
 __device__ __forceinline__ double value_of_key(uint32_t k) {   // 0 for an invalid key
     const float f = __uint_as_float(bits_of_key(k));
     return k == kInv ? 0.0 : static_cast<double>(f);
@@ -155,7 +161,7 @@ constexpr int kBudget2 = 6;
 
 // sflags[step]: bit 0 = SIMPLE (every real track pushes a valid sample and is counted; padded
 // tracks push invalid).  ntracks = real tracks (tracks >= ntracks are padding).
-template <int W, int YPS, bool PROBE8, bool SKIPX>
+template <int W, int YPS, bool PROBE8, bool SKIPX, bool STATS>
 __global__ __launch_bounds__(256) void clim_ring2_f32(
     const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, int32_t step_min, const DevChunk* __restrict__ chunks, double q,
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
 
         // ---- advance the rings -----------------------------------------------------
         uint32_t kin[YPS], kout[YPS];
-        bool counted[YPS];
+        uint32_t cmask = (1u << YPS) - 1u;     // bit y: track y is part of this row's pool (per lane)
         bool allc = true;
         uint32_t dF = 0;
         // NaN among the loaded samples?  (the sum propagates NaN; inf - inf also lands here and
@@ -255,11 +261,10 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
         for (int y = 1; y < YPS; ++y) xs += x_cur[y];
         const bool fast = (sf & 1u) && clean && !__any(xs != xs);
         if (fast) {
-            ++st_fast;
+            if constexpr (STATS) ++st_fast;
 #pragma unroll
             for (int y = 0; y < YPS; ++y) {
                 kin[y] = key_of_bits(__float_as_uint(x_cur[y]), negmask);
-                counted[y] = true;
             }
             kin[YPS - 1] |= padmask;
 #define XMHW_R2_FAST(K)                                                    \
@@ -300,13 +305,13 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
         } else {
             bool hold[YPS];
             bool any_hold = false;
+            cmask = 0;
 #pragma unroll
             for (int y = 0; y < YPS; ++y) {
                 const uint32_t code = e_cur[y] >> 1;
-                counted[y] = (e_cur[y] & 1u) != 0;
+                cmask |= (e_cur[y] & 1u) << y;
                 hold[y] = code == kCodeHold;
                 any_hold |= hold[y];
-                allc &= counted[y];
                 const float xv = x_cur[y];
                 const bool ok = code >= 2u && cell_ok && xv == xv;
                 kin[y] = ok ? key_of_bits(__float_as_uint(xv), negmask) : kInv;
@@ -355,6 +360,7 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                 }
                 have_code = false;     // byte positions moved: rebuild the code ring
             }
+            allc = cmask == (1u << YPS) - 1u;
             clean = !__any(nval != full_valid);
         }
 
@@ -409,11 +415,13 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                     double ty = 0.0;
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
-                        cy += ring[y][k] != kInv ? 1u : 0u;
-                        ty += value_of_key(ring[y][k]);
+                        const uint32_t key = opaque(ring[y][k]);
+                        cy += key != kInv ? 1u : 0u;
+                        ty += value_of_key(key);
                     }
-                    nl += counted[y] ? cy : 0u;
-                    tl += counted[y] ? ty : 0.0;
+                    const bool cnt = (cmask >> y) & 1u;
+                    nl += cnt ? cy : 0u;
+                    tl += cnt ? ty : 0.0;
                 }
                 n = cell_sum(nl);
                 total = cell_sum(tl);
@@ -426,9 +434,9 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                 for (int y = 0; y < YPS; ++y) {
                     double ty = 0.0;
 #pragma unroll
-                    for (int k = 0; k < R; ++k) ty += value_of_key(ring[y][k]);
+                    for (int k = 0; k < R; ++k) ty += value_of_key(opaque(ring[y][k]));
                     t += ty;
-                    tl += counted[y] ? ty : 0.0;
+                    tl += ((cmask >> y) & 1u) ? ty : 0.0;
                 }
                 lsum = t;
                 total = cell_sum(tl);
@@ -455,8 +463,8 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                     for (int y = 0; y < YPS; ++y) {
                         uint32_t cy = 0;
 #pragma unroll
-                        for (int k = 0; k < R; ++k) cy += (ring[y][k] <= p) ? 1u : 0u;
-                        c += counted[y] ? cy : 0u;
+                        for (int k = 0; k < R; ++k) cy += (opaque(ring[y][k]) <= p) ? 1u : 0u;
+                        c += ((cmask >> y) & 1u) ? cy : 0u;
                     }
                 }
                 return cell_sum(c);
@@ -504,7 +512,7 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                         }
                         have_code = true;
                         Lc = 96u;
-                        ++st_rebase;
+                        if constexpr (STATS) ++st_rebase;
                     }
                     if (__all(have_code || n == 0)) {
                         // cum(L) = #{code < L} = #{key < cbase + (L << cshift)}, exact for 1 <= L <= 254
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                         const float aim = static_cast<float>(lo) - 0.5f * static_cast<float>(SLACK);
                         for (int it = 0; it < 12; ++it) {
                             const uint32_t cu = cum8(done ? 1u : L);
-                            ++st_probe8;
+                            if constexpr (STATS) ++st_probe8;
                             if (!done) {
                                 if (cu <= lo) { Ll = L; Cl = cu; } else { Lh = L; Ch = cu; }
                                 if (Ll >= 1u && lo - Cl <= SLACK) done = true;          // window hit
@@ -580,7 +588,7 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                     if (!use_c) p0 = have_c ? pc : pm;
                     const uint32_t Fr = count_le(minu(p0, 0xFFFFFFFEu));
                     if (!use_c) F0 = Fr;
-                    ++st_cold;
+                    if constexpr (STATS) ++st_cold;
                 }
                 if (p0 != 0 && p0 < 0xFFFFFFFEu) {
                     if (F0 <= lo) { pl = p0; Fl = F0; lreal = true; }
@@ -613,7 +621,7 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                     off = maxu(1u, minu(off, room - 1u));
                     const uint32_t p = settle ? pl : pl + off;
                     const uint32_t F = count_le(p);
-                    ++st_count;
+                    if constexpr (STATS) ++st_count;
                     if (!settle) {
                         if (F <= lo) { pl = p; Fl = F; lreal = true; }
                         else { ph = p; Fh = F; hreal = true; }
@@ -651,7 +659,7 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
 #pragma unroll
                                 for (int k = 0; k < R; ++k) top.insert(ring[y][k] - base);
                             top.merge_cell();
-                            ++st_extract;
+                            if constexpr (STATS) ++st_extract;
                         }
                     } else {
 #pragma unroll
@@ -665,12 +673,12 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                     for (int y = 0; y < YPS; ++y)
 #pragma unroll
                         for (int k = 0; k < R; ++k) {
-                            const uint32_t d = ring[y][k] - base;
-                            top.insert(counted[y] ? d : 0xFFFFFFFFu);
+                            const uint32_t d = opaque(ring[y][k]) - base;
+                            top.insert(((cmask >> y) & 1u) ? d : 0xFFFFFFFFu);
                         }
                     top.merge_cell();
                 }
-                ++st_extract;
+                if constexpr (STATS) ++st_extract;
                 if (!resolved) {
                     if (window) {
                         const uint32_t j = lo - Fl;
@@ -690,7 +698,7 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                 const uint32_t dj = top.m[J - 1];
                 const uint32_t pj = base + dj;
                 const uint32_t Fj = count_le(resolved ? pl : pj);
-                ++st_count;
+                if constexpr (STATS) ++st_count;
                 if (!resolved) {
                     if (Fj <= lo) {
                         pl = pj; Fl = Fj; lreal = true;
@@ -705,7 +713,7 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
             }
             (void)settled8;
 
-            ++st_rows;
+            if constexpr (STATS) ++st_rows;
             double th = make_nan(), se = make_nan();
             if (n > 0) {
                 th = numpy_lerp(static_cast<double>(__uint_as_float(bits_of_key(alo))),
@@ -746,7 +754,7 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
             x_cur[y] = x_nxt[y];
         }
     }
-    if (stats != nullptr && lane == 0) {
+    if (STATS && stats != nullptr && lane == 0) {
         atomicAdd(&stats[0], static_cast<unsigned long long>(st_rows));
         atomicAdd(&stats[1], static_cast<unsigned long long>(st_count));
         atomicAdd(&stats[2], static_cast<unsigned long long>(st_extract));
@@ -761,15 +769,16 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
 namespace {
 typedef void (*Ring2Kernel)(const float*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*, int32_t,
                             const DevChunk*, double, int, int32_t, double*, double*, int64_t, unsigned long long*);
-struct Ring2Entry { int w, yps, variant; Ring2Kernel fn; };
-// variant: bit 0 = PROBE8, bit 1 = SKIPX
-#define XMHW_R2(W, Y)                                                                      \
-    {W, Y, 0, clim_ring2_f32<W, Y, false, false>}, {W, Y, 1, clim_ring2_f32<W, Y, true, false>}, \
-    {W, Y, 2, clim_ring2_f32<W, Y, false, true>}, {W, Y, 3, clim_ring2_f32<W, Y, true, true>}
+struct Ring2Entry { int w, yps, variant; Ring2Kernel fn, fn_stats; };
+// variant: bit 0 = PROBE8, bit 1 = SKIPX; the _stats twin carries the debug pass counters
+#define XMHW_R2V(W, Y, V) {W, Y, V, clim_ring2_f32<W, Y, ((V) & 1) != 0, ((V) & 2) != 0, false>, \
+                           clim_ring2_f32<W, Y, ((V) & 1) != 0, ((V) & 2) != 0, true>}
+#define XMHW_R2(W, Y) XMHW_R2V(W, Y, 0), XMHW_R2V(W, Y, 1), XMHW_R2V(W, Y, 2), XMHW_R2V(W, Y, 3)
 const Ring2Entry kRing2[] = {
     XMHW_R2(5, 3), XMHW_R2(5, 4), XMHW_R2(5, 5),
 };
 #undef XMHW_R2
+#undef XMHW_R2V
 const Ring2Entry* find_ring2(int32_t w, int32_t yps, int32_t variant) {
     for (const auto& e : kRing2)
         if (e.w == w && e.yps == yps && e.variant == variant) return &e;
@@ -796,7 +805,7 @@ hipError_t launch_ring2_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
     if (C <= 0 || nchunks <= 0) return hipSuccess;
     const int64_t cells_per_block = 8 * kWaves2;
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
-    hipLaunchKernelGGL(e->fn, grid, dim3(64 * kWaves2), 0, stream, ts, C, ld, Tn, table, sflags, step_min, chunks, q,
+    hipLaunchKernelGGL(stats ? e->fn_stats : e->fn, grid, dim3(64 * kWaves2), 0, stream, ts, C, ld, Tn, table, sflags, step_min, chunks, q,
                        negate, ntracks, thresh, seas, ldo, stats);
     return hipGetLastError();
 }
