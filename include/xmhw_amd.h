@@ -102,10 +102,10 @@ int xmhw_plan_table(const xmhw_plan *plan, int32_t years_per_lane, uint32_t *tab
  * enable != 0 allocates the counters; out8 receives 8 values                          */
 int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out8);
 
-/* second-generation float32 ring kernel (w = 5, <= 40 tracks; xmhw_amd/csrc/kernels_ring2.hip):
- * variant -1 = off (round-1 kernel), 0 = lean steps, +1 = 8-bit SAD probes, +2 = extraction
- * that skips empty ring positions.  The environment variable XMHW_RING2 sets the default of new
- * plans.  All variants return bit-identical results.                                  */
+/* second-generation float32 ring kernel (w = 5, 17..40 tracks; xmhw_amd/csrc/kernels_ring2.hip),
+ * used by default where it is instantiated: variant 0 = lean steps (the default), 1 = + 8-bit SAD
+ * probes (measured slower, kept for the record), -1 = off (round-1 kernel).  The environment
+ * variable XMHW_RING2 sets the default of new plans.  All variants return bit-identical thresh. */
 int xmhw_plan_set_ring2(xmhw_plan *plan, int32_t variant);
 
 /* ---- the hot path ------------------------------------------------------ *

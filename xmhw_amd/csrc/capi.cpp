@@ -53,7 +53,7 @@ struct xmhw_plan {
     int32_t nchunks = 0;
     uint32_t* d_table = nullptr;
     int32_t yps2 = 0;         // second-generation float32 ring kernel (kernels_ring2.hip), 0: not available
-    int32_t ring2_variant = -1;   // -1: off; bit 0 = 8-bit SAD probes, bit 1 = skipping extraction
+    int32_t ring2_variant = 0;    // -1: off (round-1 kernel); 0: lean steps; 1: + 8-bit SAD probes (slower, kept as a measured variant)
     uint32_t* d_table2 = nullptr;
     uint32_t* d_sflags = nullptr;
     int32_t yps64 = 0;        // float64 ring kernel tracks-per-lane (16 lanes per cell)
@@ -629,7 +629,7 @@ int xmhw_plan_create(const int32_t* doy_host, int64_t T, int32_t window_half_wid
 }
 int xmhw_plan_set_ring2(xmhw_plan* plan, int32_t variant) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
-    if (variant < -1 || variant > 3) return fail(XMHW_ERR_INVALID, "ring2 variant must be -1 (off) or 0..3");
+    if (variant < -1 || variant > 1) return fail(XMHW_ERR_INVALID, "ring2 variant must be -1 (off), 0 or 1");
     plan->ring2_variant = variant;
     return XMHW_OK;
 }

@@ -22,8 +22,10 @@
 //      PROBE8  the bracket is closed on an 8-bit code ring (code = clamp((key - base) >> shift)):
 //              one probe = 2 x v_sad_u8 per 4 keys (#{code < L} = (SAD(L) - SAD(L-1) + N) / 2)
 //              instead of v_cmp + v_addc per key; the 32-bit count pass remains as the fallback.
-//      SKIPX   the extraction pass skips the insertion network at ring positions where no lane
-//              of the wave holds a key inside the target band (one v_cmp + scalar branch).
+//    (a second switch, an extraction pass that skips the insertion network at ring positions where
+//    no lane of the wave holds a key inside the target band, was measured and removed: 158 ms
+//    against 141 ms without it, profiles/r2_ring2_first_variants.jsonl -- with 64 lanes sharing an
+//    instruction a position is skipped less than half of the time and the test costs as much as it saves)
 //
 // Reference semantics restated: window_roll() (identify.py:184-209),
 // calculate_thresh()/calculate_seas() without the Feb-29 step (identify.py:233-235, :263),
@@ -81,9 +83,60 @@ __device__ __forceinline__ uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t 
 __device__ __forceinline__ uint32_t key_of_bits(uint32_t b, uint32_t negmask) {
     return b ^ (static_cast<uint32_t>(static_cast<int32_t>(b) >> 31) | 0x80000000u) ^ negmask;
 }
+// Ring registers are only ever modified through these two: the output is tied to the input register,
+// so the register allocator keeps every ring element in ONE register for the whole kernel.  (With
+// plain assignments it split the live ranges around the rare rotation path and copied all 55 ring
+// registers to a second set and back on every row.)
+__device__ __forceinline__ void ring_set(uint32_t& slot, uint32_t v) {
+    asm volatile("v_mov_b32 %0, %1" : "+v"(slot) : "v"(v));
+}
+__device__ __forceinline__ void ring_sel(uint32_t& slot, uint32_t other, unsigned long long take_other) {
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(slot) : "v"(other), "s"(take_other));
+}
+// arithmetic shift kept as a shift (the compiler turns `x >> 31` feeding a bitwise op into
+// v_cmp + v_cndmask, two quarter-rate instructions with a wait state between them)
+__device__ __forceinline__ uint32_t ashr31(uint32_t v) {
+    uint32_t r;
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(v));
+    return r;
+}
 // bits of the float a VALID key stands for (the negated sample under coldSpells)
 __device__ __forceinline__ uint32_t bits_of_key(uint32_t k) {
-    return k ^ (~static_cast<uint32_t>(static_cast<int32_t>(k) >> 31) | 0x80000000u);
+    return k ^ (~ashr31(k) | 0x80000000u);
+}
+// c + #{r[i] <= p}, 11 keys.  Hand-scheduled: a v_cmp that writes an SGPR pair needs two wait states
+// before a VALU instruction may read it; the compiler pads every pair with s_nop (167 issue slots
+// for 55 keys), here three SGPR pairs rotate so that compare i is consumed four slots later
+// (22 slots per 11 keys, no s_nop).
+__device__ __forceinline__ uint32_t count_le11(const uint32_t (&r)[11], uint32_t p, uint32_t& c, uint32_t d) {
+    // two accumulators (c, d) so that consecutive v_addc do not depend on each other
+    unsigned long long s0, s1, s2, sd;
+    asm("v_cmp_le_u32_e64 %[s0], %[k0], %[p]\n\t"
+        "v_cmp_le_u32_e64 %[s1], %[k1], %[p]\n\t"
+        "v_cmp_le_u32_e64 %[s2], %[k2], %[p]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s0]\n\t"
+        "v_cmp_le_u32_e64 %[s0], %[k3], %[p]\n\t"
+        "v_addc_co_u32_e64 %[d], %[sd], %[d], 0, %[s1]\n\t"
+        "v_cmp_le_u32_e64 %[s1], %[k4], %[p]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s2]\n\t"
+        "v_cmp_le_u32_e64 %[s2], %[k5], %[p]\n\t"
+        "v_addc_co_u32_e64 %[d], %[sd], %[d], 0, %[s0]\n\t"
+        "v_cmp_le_u32_e64 %[s0], %[k6], %[p]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s1]\n\t"
+        "v_cmp_le_u32_e64 %[s1], %[k7], %[p]\n\t"
+        "v_addc_co_u32_e64 %[d], %[sd], %[d], 0, %[s2]\n\t"
+        "v_cmp_le_u32_e64 %[s2], %[k8], %[p]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s0]\n\t"
+        "v_cmp_le_u32_e64 %[s0], %[k9], %[p]\n\t"
+        "v_addc_co_u32_e64 %[d], %[sd], %[d], 0, %[s1]\n\t"
+        "v_cmp_le_u32_e64 %[s1], %[k10], %[p]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s2]\n\t"
+        "v_addc_co_u32_e64 %[d], %[sd], %[d], 0, %[s0]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s1]"
+        : [c] "+v"(c), [d] "+v"(d), [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [sd] "=&s"(sd)
+        : [k0] "v"(r[0]), [k1] "v"(r[1]), [k2] "v"(r[2]), [k3] "v"(r[3]), [k4] "v"(r[4]), [k5] "v"(r[5]),
+          [k6] "v"(r[6]), [k7] "v"(r[7]), [k8] "v"(r[8]), [k9] "v"(r[9]), [k10] "v"(r[10]), [p] "v"(p));
+    return d;
 }
 // identity the optimiser cannot see through: keeps the rare paths (masked rows, infinite samples)
 // from being merged with, or hoisted above, the per-row code
@@ -154,26 +207,31 @@ struct Top2 {
     }
 };
 
-constexpr int kJ2 = 5;
+// extraction width: 5 keys after 32-bit count passes (each pass is ~120 instructions, so the window of
+// acceptable ranks is wide); 3 keys when the bracket is closed by 8-bit probes (a probe is ~50
+// instructions: aiming at a 2-rank window costs less than two extra insertions per key)
+constexpr int kJ2_count = 5, kJ2_probe = 3;
 constexpr int kBudget2 = 6;
 
 }  // namespace
 
 // sflags[step]: bit 0 = SIMPLE (every real track pushes a valid sample and is counted; padded
 // tracks push invalid).  ntracks = real tracks (tracks >= ntracks are padding).
-template <int W, int YPS, bool PROBE8, bool SKIPX, bool STATS>
-__global__ __launch_bounds__(256) void clim_ring2_f32(
+template <int W, int YPS, bool PROBE8, bool STATS>
+__global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, int32_t step_min, const DevChunk* __restrict__ chunks, double q,
     int negate, int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
     unsigned long long* __restrict__ stats) {
+    static_assert(W == 5, "count_le11 is written for an 11-sample window");
     constexpr int R = 2 * W + 1;
     constexpr int SUBS = 8;
     constexpr int NTP = SUBS * YPS;
-    constexpr int J = kJ2;
+    constexpr int J = PROBE8 ? kJ2_probe : kJ2_count;
     constexpr uint32_t SLACK = J - 2;
     constexpr int NK = YPS * R;                 // keys per lane
     constexpr int NW = (NK + 3) / 4;            // code words per lane
+    constexpr uint32_t ALLC = (1u << YPS) - 1u;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int sub = (lane >> 1) & 7;
@@ -224,20 +282,28 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
     }
 
     int m = (ch.warm_start - step_min) % R;
-    uint32_t pc = 0, Fc = 0;
-    bool have_c = false;
-    float kpr = 8192.0f;
+    // carried across rows, uniform over the 8 lanes of a cell (kept as integers, not as lane masks)
+    uint32_t pc = 0, Fc = 0;  // !PROBE8: pivot with its exact count #{keys <= pc}, updated from the pushed / evicted keys
+    uint32_t have_c = 0;
+    float kpr = 8192.0f;      // keys per rank near the target
     bool clean = false;       // wave-uniform: every lane's rings hold valid keys only
     uint32_t st_count = 0, st_extract = 0, st_rows = 0, st_cold = 0, st_fast = 0, st_probe8 = 0, st_rebase = 0;
 
     // PROBE8 state: 8-bit codes of the ring keys relative to (cbase, cshift); valid while have_code
     uint32_t codes[PROBE8 ? NW : 1];
-    uint32_t cbase = 0, cshift = 0;
-    bool have_code = false;
-    float lpr = 2.0f;         // levels per rank near the target (carried)
-    uint32_t Lc = 0;
+    uint32_t cbase = 0, cshift = 0, have_code = 0;
+    uint32_t Lc = 0;          // level of the previous row's pivot
+    float drift = 0.0f;       // levels per row the pivot moved lately (signed)
 
-    for (int32_t s = ch.warm_start; s < ch.end; ++s) {
+    // The row loop is cut into segments that END with a step at which some track holds: the rotation
+    // that realigns a held track rewrites all of its ring registers, and with that code inside the
+    // row loop the register allocator copied the whole ring to a second register set and back on
+    // every row.  Between two segments it costs nothing.
+    uint32_t hmask = 0;        // bit y: track y held at the last step of the segment
+    int32_t s = ch.warm_start;
+    while (s < ch.end) {
+    bool rotate = false;
+    for (; s < ch.end && !rotate; ++s) {
         // ---- prefetch: samples of step s+1, table entries of step s+2 ------------
         float x_nxt[YPS];
         uint32_t e_nn[YPS];
@@ -249,11 +315,11 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
         }
         const uint32_t sf = __builtin_amdgcn_readfirstlane(sflags[s - step_min]);
 
-        // ---- advance the rings -----------------------------------------------------
+        // ---- what this step pushes ------------------------------------------------------
         uint32_t kin[YPS], kout[YPS];
-        uint32_t cmask = (1u << YPS) - 1u;     // bit y: track y is part of this row's pool (per lane)
-        bool allc = true;
-        uint32_t dF = 0;
+        uint32_t cmask = ALLC;     // bit y: track y is part of this row's pool (per lane)
+        hmask = 0;                 // bit y: track y holds (does not advance) at this step
+        bool wave_hold = false;
         // NaN among the loaded samples?  (the sum propagates NaN; inf - inf also lands here and
         // merely takes the general step)
         float xs = x_cur[0];
@@ -263,32 +329,44 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
         if (fast) {
             if constexpr (STATS) ++st_fast;
 #pragma unroll
-            for (int y = 0; y < YPS; ++y) {
-                kin[y] = key_of_bits(__float_as_uint(x_cur[y]), negmask);
-            }
+            for (int y = 0; y < YPS; ++y) kin[y] = key_of_bits(__float_as_uint(x_cur[y]), negmask);
             kin[YPS - 1] |= padmask;
-#define XMHW_R2_FAST(K)                                                    \
-    case K:                                                                \
-        if constexpr (K < R) {                                             \
-            _Pragma("unroll") for (int y = 0; y < YPS; ++y) {              \
-                kout[y] = ring[y][K < R ? K : 0];                          \
-                ring[y][K < R ? K : 0] = kin[y];                           \
-            }                                                              \
-        }                                                                  \
-        break;
-            switch (m) {
-                XMHW_R2_FAST(0) XMHW_R2_FAST(1) XMHW_R2_FAST(2) XMHW_R2_FAST(3) XMHW_R2_FAST(4)
-                XMHW_R2_FAST(5) XMHW_R2_FAST(6) XMHW_R2_FAST(7) XMHW_R2_FAST(8) XMHW_R2_FAST(9)
-                XMHW_R2_FAST(10) XMHW_R2_FAST(11) XMHW_R2_FAST(12) XMHW_R2_FAST(13) XMHW_R2_FAST(14)
-                XMHW_R2_FAST(15) XMHW_R2_FAST(16) XMHW_R2_FAST(17) XMHW_R2_FAST(18) XMHW_R2_FAST(19)
-                XMHW_R2_FAST(20) XMHW_R2_FAST(21) XMHW_R2_FAST(22) XMHW_R2_FAST(23) XMHW_R2_FAST(24)
-                XMHW_R2_FAST(25) XMHW_R2_FAST(26) XMHW_R2_FAST(27) XMHW_R2_FAST(28) XMHW_R2_FAST(29)
-                XMHW_R2_FAST(30)
-                default: break;
+        } else {
+            cmask = 0;
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) {
+                const uint32_t code = e_cur[y] >> 1;
+                cmask |= (e_cur[y] & 1u) << y;
+                hmask |= (code == kCodeHold ? 1u : 0u) << y;
+                const float xv = x_cur[y];
+                const bool ok = code >= 2u && cell_ok && xv == xv;
+                kin[y] = ok ? key_of_bits(__float_as_uint(xv), negmask) : kInv;
             }
-#undef XMHW_R2_FAST
+            wave_hold = __any(hmask != 0);
+        }
+        // ---- the one place where the rings are written (slot m of every track) ------------
+#define XMHW_R2_PUSH(K)                                                              \
+    case K:                                                                          \
+        if constexpr (K < R) {                                                       \
+            _Pragma("unroll") for (int y = 0; y < YPS; ++y) kout[y] = opaque(ring[y][K < R ? K : 0]); \
+            if (wave_hold) {                                                         \
+                _Pragma("unroll") for (int y = 0; y < YPS; ++y)                      \
+                    kin[y] = ((hmask >> y) & 1u) ? kout[y] : kin[y];                 \
+            }                                                                        \
+            _Pragma("unroll") for (int y = 0; y < YPS; ++y) ring_set(ring[y][K < R ? K : 0], kin[y]); \
+        }                                                                            \
+        break;
+        switch (m) {
+            XMHW_R2_PUSH(0) XMHW_R2_PUSH(1) XMHW_R2_PUSH(2) XMHW_R2_PUSH(3) XMHW_R2_PUSH(4)
+            XMHW_R2_PUSH(5) XMHW_R2_PUSH(6) XMHW_R2_PUSH(7) XMHW_R2_PUSH(8) XMHW_R2_PUSH(9)
+            XMHW_R2_PUSH(10)
+            default: break;
+        }
+#undef XMHW_R2_PUSH
+        uint32_t dF = 0;
+        if (fast) {
             // running sum: + new samples - evicted samples (padded slot: both are masked to +0.0)
-            double din = 0.0, dout = 0.0;
+            double din, dout;
 #pragma unroll
             for (int y = 0; y < YPS; ++y) {
                 uint32_t bi = __float_as_uint(x_cur[y]) ^ (negmask & 0x80000000u);
@@ -297,87 +375,44 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                     bi &= ~padmask;
                     bo &= ~padmask;
                 }
-                din += static_cast<double>(__uint_as_float(bi));
-                dout += static_cast<double>(__uint_as_float(bo));
+                const double di = static_cast<double>(__uint_as_float(bi));
+                const double dq = static_cast<double>(__uint_as_float(bo));
+                din = y == 0 ? di : din + di;
+                dout = y == 0 ? dq : dout + dq;
                 if constexpr (!PROBE8) dF += (kin[y] <= pc ? 1u : 0u) - (kout[y] <= pc ? 1u : 0u);
             }
             lsum += din - dout;
         } else {
-            bool hold[YPS];
-            bool any_hold = false;
-            cmask = 0;
 #pragma unroll
             for (int y = 0; y < YPS; ++y) {
-                const uint32_t code = e_cur[y] >> 1;
-                cmask |= (e_cur[y] & 1u) << y;
-                hold[y] = code == kCodeHold;
-                any_hold |= hold[y];
-                const float xv = x_cur[y];
-                const bool ok = code >= 2u && cell_ok && xv == xv;
-                kin[y] = ok ? key_of_bits(__float_as_uint(xv), negmask) : kInv;
+                // a held track contributes kin == kout: nothing changes
+                lsum += value_of_key(kin[y]);
+                lsum -= value_of_key(kout[y]);
+                nval += (kin[y] != kInv ? 1u : 0u) - (kout[y] != kInv ? 1u : 0u);
+                if constexpr (!PROBE8) dF += (kin[y] <= pc ? 1u : 0u) - (kout[y] <= pc ? 1u : 0u);
             }
-#define XMHW_R2_GEN(K)                                                     \
-    case K:                                                                \
-        if constexpr (K < R) {                                             \
-            _Pragma("unroll") for (int y = 0; y < YPS; ++y) {              \
-                const uint32_t o = ring[y][K < R ? K : 0];                 \
-                kout[y] = o;                                               \
-                ring[y][K < R ? K : 0] = hold[y] ? o : kin[y];             \
-            }                                                              \
-        }                                                                  \
-        break;
-            switch (m) {
-                XMHW_R2_GEN(0) XMHW_R2_GEN(1) XMHW_R2_GEN(2) XMHW_R2_GEN(3) XMHW_R2_GEN(4)
-                XMHW_R2_GEN(5) XMHW_R2_GEN(6) XMHW_R2_GEN(7) XMHW_R2_GEN(8) XMHW_R2_GEN(9)
-                XMHW_R2_GEN(10) XMHW_R2_GEN(11) XMHW_R2_GEN(12) XMHW_R2_GEN(13) XMHW_R2_GEN(14)
-                XMHW_R2_GEN(15) XMHW_R2_GEN(16) XMHW_R2_GEN(17) XMHW_R2_GEN(18) XMHW_R2_GEN(19)
-                XMHW_R2_GEN(20) XMHW_R2_GEN(21) XMHW_R2_GEN(22) XMHW_R2_GEN(23) XMHW_R2_GEN(24)
-                XMHW_R2_GEN(25) XMHW_R2_GEN(26) XMHW_R2_GEN(27) XMHW_R2_GEN(28) XMHW_R2_GEN(29)
-                XMHW_R2_GEN(30)
-                default: break;
-            }
-#undef XMHW_R2_GEN
-#pragma unroll
-            for (int y = 0; y < YPS; ++y) {
-                if (!hold[y]) {
-                    lsum += value_of_key(kin[y]);
-                    lsum -= value_of_key(kout[y]);
-                    nval += (kin[y] != kInv ? 1u : 0u) - (kout[y] != kInv ? 1u : 0u);
-                    dF += (kin[y] <= pc ? 1u : 0u) - (kout[y] <= pc ? 1u : 0u);
-                } else {
-                    kin[y] = kout[y];      // nothing changed in this track (code ring update below)
-                }
-            }
-            if (__any(any_hold)) {
-                // a held track did not advance: rotate its window one slot so that its oldest
-                // sample sits where the next step's PUSH will land
-#pragma unroll
-                for (int y = 0; y < YPS; ++y) {
-                    const uint32_t last = ring[y][R - 1];
-#pragma unroll
-                    for (int k = R - 1; k >= 1; --k) ring[y][k] = hold[y] ? ring[y][k - 1] : ring[y][k];
-                    ring[y][0] = hold[y] ? last : ring[y][0];
-                }
-                have_code = false;     // byte positions moved: rebuild the code ring
-            }
-            allc = cmask == (1u << YPS) - 1u;
+            rotate = wave_hold;
             clean = !__any(nval != full_valid);
         }
 
         // ---- 8-bit code ring: the slot written this step ------------------------------
         if constexpr (PROBE8) {
-            if (have_code) {
+            if (__any(have_code != 0)) {
                 // code = min((key -sat base) >> shift, 254); the byte of slot (y, m) is byte
                 // (y*R + m) & 3 of word (y*R + m) >> 2 -- m is wave-uniform, so this is a scalar switch
+                // (lanes without a code ring write garbage codes that nothing reads)
+                uint32_t cin[YPS];
+#pragma unroll
+                for (int y = 0; y < YPS; ++y)
+                    cin[y] = minu(__builtin_elementwise_sub_sat(kin[y], cbase) >> cshift, 254u);
 #define XMHW_R2_CODE(K)                                                                          \
     case K:                                                                                      \
         if constexpr (K < R) {                                                                   \
             _Pragma("unroll") for (int y = 0; y < YPS; ++y) {                                    \
-                const int pos = y * R + (K < R ? K : 0);                                          \
-                const uint32_t c = minu(__builtin_elementwise_sub_sat(kin[y], cbase) >> cshift, 254u); \
+                const int pos = y * R + (K < R ? K : 0);                                         \
                 const uint32_t sel = pos % 4 == 0 ? 0x07060500u : pos % 4 == 1 ? 0x07060004u    \
-                                         : pos % 4 == 2 ? 0x07000504u : 0x00060504u;             \
-                codes[pos / 4] = perm_b32(codes[pos / 4], c, sel);                               \
+                                     : pos % 4 == 2 ? 0x07000504u : 0x00060504u;                 \
+                codes[pos / 4] = perm_b32(codes[pos / 4], cin[y], sel);                          \
             }                                                                                    \
         }                                                                                        \
         break;
@@ -385,11 +420,7 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                 switch (m) {
                     XMHW_R2_CODE(0) XMHW_R2_CODE(1) XMHW_R2_CODE(2) XMHW_R2_CODE(3) XMHW_R2_CODE(4)
                     XMHW_R2_CODE(5) XMHW_R2_CODE(6) XMHW_R2_CODE(7) XMHW_R2_CODE(8) XMHW_R2_CODE(9)
-                    XMHW_R2_CODE(10) XMHW_R2_CODE(11) XMHW_R2_CODE(12) XMHW_R2_CODE(13) XMHW_R2_CODE(14)
-                    XMHW_R2_CODE(15) XMHW_R2_CODE(16) XMHW_R2_CODE(17) XMHW_R2_CODE(18) XMHW_R2_CODE(19)
-                    XMHW_R2_CODE(20) XMHW_R2_CODE(21) XMHW_R2_CODE(22) XMHW_R2_CODE(23) XMHW_R2_CODE(24)
-                    XMHW_R2_CODE(25) XMHW_R2_CODE(26) XMHW_R2_CODE(27) XMHW_R2_CODE(28) XMHW_R2_CODE(29)
-                    XMHW_R2_CODE(30)
+                    XMHW_R2_CODE(10)
                     default: break;
                 }
 #undef XMHW_R2_CODE
@@ -399,7 +430,7 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
 
         // ---- select + output (not during warm-up) ---------------------------------
         if (s >= ch.begin) {
-            const bool wallc = __all(allc);
+            const bool wallc = __all(cmask == ALLC);
             uint32_t n;
             double total;
             if (wallc) {
@@ -441,7 +472,7 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                 lsum = t;
                 total = cell_sum(tl);
             }
-            Fc += cell_sum(dF);
+            if constexpr (!PROBE8) Fc += cell_sum(dF);
 
             const uint32_t nn = n ? n : 1u;
             const double vi = static_cast<double>(nn - 1) * q;
@@ -454,10 +485,10 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
             auto count_le = [&](uint32_t p) -> uint32_t {
                 uint32_t c = 0;
                 if (wallc) {
+                    uint32_t c2 = 0;
 #pragma unroll
-                    for (int y = 0; y < YPS; ++y)
-#pragma unroll
-                        for (int k = 0; k < R; ++k) c += (ring[y][k] <= p) ? 1u : 0u;
+                    for (int y = 0; y < YPS; ++y) c2 = count_le11(ring[y], p, c, c2);
+                    c += c2;
                 } else {
 #pragma unroll
                     for (int y = 0; y < YPS; ++y) {
@@ -471,32 +502,36 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
             };
 
             uint32_t pl = 0, Fl = 0, ph = 0xFFFFFFFFu, Fh = nn;
-            bool lreal = false, hreal = false;
+            uint32_t lreal = 0, hreal = 0;
             float grow = 1.0f;
             bool resolved = (n == 0);
             uint32_t p_first = 0;
             int32_t rank_gap = 0;
-            bool settled8 = false;     // PROBE8: the bracket came out of the code ring, ready for extraction
 
             if constexpr (PROBE8) {
                 // ---------- close the bracket on the 8-bit code ring ----------------------
-                // (re)build the code ring when there is none, or when the previous row's level came
-                // close to an edge of the 254-level window
-                const bool usable = wallc;     // masked rows take the 32-bit path
-                if (usable) {
-                    const bool want = have_c;                    // an estimate of the target exists
-                    bool rebase = want && (!have_code || Lc < 24u || Lc > 230u);
-                    if (__any(rebase) && __all(want || n == 0)) {
-                        // window: 254 levels of 2^shift keys; aim at ~2 levels per rank, the carried
-                        // pivot at level 96 (the target drifts either way by ~13 ranks a day)
-                        const float lw = fmaxf(kpr * 0.5f, 1.0f);
-                        uint32_t sh = 31u - static_cast<uint32_t>(__builtin_clz(static_cast<uint32_t>(lw)));
-                        sh = minu(sh, 23u);
-                        const uint32_t span = 96u << sh;
+                // masked rows (not all tracks pooled) take the 32-bit path
+                if (wallc) {
+                    // (re)build the code ring when there is none, or when the previous row's level came
+                    // close to an edge of the 254-level window
+                    const bool want = have_c != 0 && n != 0;
+                    const bool rebase = want && (have_code == 0 || Lc < 20u || Lc > 234u);
+                    if (__any(rebase)) {
+                        // window: 254 levels of 2^shift keys, about one rank per level; the carried
+                        // pivot goes to level 72 when the target has been rising, 182 when falling
+                        const float lw = fmaxf(kpr, 1.0f);
+                        uint32_t sh = 31u - static_cast<uint32_t>(__builtin_clz(static_cast<uint32_t>(fminf(lw, 8.0e6f))));
+                        const uint32_t at = drift >= 0.0f ? 72u : 182u;
+                        const uint32_t span = at << sh;
                         uint32_t nb = pc > span ? pc - span : 0u;
                         nb = minu(nb, 0xFFFFFFFFu - (256u << sh));
-                        cbase = nb;
-                        cshift = sh;
+                        if (rebase) {
+                            cbase = nb;
+                            cshift = sh;
+                            have_code = 1;
+                            Lc = minu(static_cast<uint32_t>((pc - nb) >> sh) + 1u, 254u);
+                        }
+                        // every lane of the wave converts (cells that keep their window recompute the same codes)
 #pragma unroll
                         for (int wd = 0; wd < NW; ++wd) {
                             uint32_t word = 0;
@@ -510,11 +545,9 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                             }
                             codes[wd] = word;
                         }
-                        have_code = true;
-                        Lc = 96u;
                         if constexpr (STATS) ++st_rebase;
                     }
-                    if (__all(have_code || n == 0)) {
+                    if (__any(have_code != 0 && n != 0)) {
                         // cum(L) = #{code < L} = #{key < cbase + (L << cshift)}, exact for 1 <= L <= 254
                         auto cum8 = [&](uint32_t L) -> uint32_t {
                             const uint32_t b1 = L * 0x01010101u, b0 = b1 - 0x01010101u;
@@ -527,94 +560,110 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                             const uint32_t d = cell_sum(a1 - a0);
                             return (d + static_cast<uint32_t>(8 * 4 * NW)) >> 1;
                         };
+                        const bool active = have_code != 0 && n != 0;
+                        // levels per rank near the target
+                        const float lpr = fminf(fmaxf(kpr * __builtin_ldexpf(1.0f, -static_cast<int>(cshift)), 0.25f), 16.0f);
                         uint32_t Ll = 0, Cl = 0, Lh = 255u, Ch = nn;     // cum(Ll) <= lo < cum(Lh); ends virtual
-                        uint32_t L = minu(maxu(Lc, 1u), 254u);
-                        bool done = (n == 0), fail = false;
+                        const float start = static_cast<float>(Lc) + drift;
+                        uint32_t L = static_cast<uint32_t>(fminf(fmaxf(start, 1.0f), 254.0f));
+                        bool done = !active;
                         const float aim = static_cast<float>(lo) - 0.5f * static_cast<float>(SLACK);
-                        for (int it = 0; it < 12; ++it) {
+                        for (int it = 0; it < 14; ++it) {
                             const uint32_t cu = cum8(done ? 1u : L);
                             if constexpr (STATS) ++st_probe8;
                             if (!done) {
                                 if (cu <= lo) { Ll = L; Cl = cu; } else { Lh = L; Ch = cu; }
                                 if (Ll >= 1u && lo - Cl <= SLACK) done = true;          // window hit
-                                else if (Lh - Ll <= 1u) { done = true; fail = true; }   // a level holds > J-1 keys
+                                else if (Lh - Ll <= 1u) done = true;                     // a level holds > J-1 keys, or off the window
                                 else {
-                                    // secant in level space from the probed end, with the carried slope
+                                    // secant in level space from the end just probed; one-sided: carried slope
                                     const bool both = Ll >= 1u && Lh <= 254u;
                                     const float slope = both ? static_cast<float>(Lh - Ll) *
                                                                    __builtin_amdgcn_rcpf(static_cast<float>(Ch - Cl))
                                                              : lpr;
-                                    const bool from_l = cu <= lo;
+                                    const bool from_l = Ll >= 1u && (cu <= lo || Lh > 254u);
                                     const float ranks = from_l ? aim - static_cast<float>(Cl) : static_cast<float>(Ch) - aim;
-                                    float stf = fmaxf(ranks * slope, 1.0f);
-                                    uint32_t st = static_cast<uint32_t>(fminf(stf, 255.0f));
-                                    if (it >= 6) st = maxu((Lh - Ll) >> 1, 1u);
+                                    const float stf = fminf(fmaxf(ranks * slope, 1.0f), 255.0f);
+                                    uint32_t st = static_cast<uint32_t>(stf);
+                                    if (it >= 5) st = maxu((Lh - Ll) >> 1, 1u);
                                     uint32_t Ln = from_l ? Ll + st : (Lh > st ? Lh - st : 0u);
-                                    Ln = minu(maxu(Ln, Ll + 1u), Lh - 1u);
-                                    L = Ln;
+                                    L = minu(maxu(Ln, Ll + 1u), Lh - 1u);
                                 }
                             }
                             if (__all(done)) break;
                         }
-                        // outside the window (Ll == 0: target below level 1; Lh == 255 with Ll == 254:
-                        // above it) or an overfull level: the 32-bit path finishes from this bracket
-                        if (n != 0) {
+                        if (active) {
+                            // hand the bracket to the 32-bit code below: inside the window it is settled
+                            // (one extraction); off the window or on an overfull level count passes finish it
                             if (Ll >= 1u) {
-                                pl = cbase + (Ll << cshift) - 1u; Fl = Cl; lreal = true;
+                                pl = cbase + (Ll << cshift) - 1u; Fl = Cl; lreal = 1;
                             }
                             if (Lh <= 254u) {
-                                ph = cbase + (Lh << cshift) - 1u; Fh = Ch; hreal = true;
+                                ph = cbase + (Lh << cshift) - 1u; Fh = Ch; hreal = 1;
                             }
-                            settled8 = done && !fail && Ll >= 1u;
-                            if (settled8) {
-                                // carry: levels per rank seen on this row, and the level to start from
-                                lpr = 0.75f * lpr + 0.25f * fminf(fmaxf(static_cast<float>(Ll > Lc ? Ll - Lc : Lc - Ll) *
-                                                                         __builtin_amdgcn_rcpf(13.0f), 0.25f), 8.0f);
+                            if (Ll >= 1u && lo - Cl <= SLACK) {
+                                const float moved = static_cast<float>(Ll) - static_cast<float>(Lc);
+                                drift = 0.5f * drift + 0.5f * fminf(fmaxf(moved, -64.0f), 64.0f);
                                 Lc = Ll;
                             } else {
-                                have_code = false;     // next row rebuilds the window around the new answer
+                                have_code = 0;     // next row rebuilds the window around the new answer
+                                drift = 0.0f;
                             }
                         }
-                        (void)fail;
                     }
                 }
                 p_first = pc;
             } else {
-                const bool use_c = have_c && wallc;
+                const bool use_c = have_c != 0 && wallc;
                 uint32_t p0 = pc, F0 = 0;
                 if (use_c) F0 = Fc;
                 if (!__all(use_c || n == 0)) {
                     uint32_t pm = key_of_bits(__float_as_uint(static_cast<float>(total / static_cast<double>(nn))), 0u);
-                    if (!use_c) p0 = have_c ? pc : pm;
+                    if (!use_c) p0 = have_c != 0 ? pc : pm;
                     const uint32_t Fr = count_le(minu(p0, 0xFFFFFFFEu));
                     if (!use_c) F0 = Fr;
                     if constexpr (STATS) ++st_cold;
                 }
                 if (p0 != 0 && p0 < 0xFFFFFFFEu) {
-                    if (F0 <= lo) { pl = p0; Fl = F0; lreal = true; }
-                    else { ph = p0; Fh = F0; hreal = true; }
+                    if (F0 <= lo) { pl = p0; Fl = F0; lreal = 1; }
+                    else { ph = p0; Fh = F0; hreal = 1; }
                 }
                 p_first = p0;
                 rank_gap = static_cast<int32_t>(lo) - static_cast<int32_t>(F0);
             }
             const float aim = static_cast<float>(lo) - 0.5f * static_cast<float>(SLACK);
 
-            uint32_t alo = 0, ahi = 0, pe = 0, Fe = 0;
+            if constexpr (PROBE8) {
+                // no bracket at all (first row of a chunk, masked row, no code ring yet): one 32-bit
+                // pass at the pool mean gives the secant loop below something to start from
+                if (!__all(lreal != 0 || hreal != 0 || n == 0)) {
+                    uint32_t pm = key_of_bits(__float_as_uint(static_cast<float>(total / static_cast<double>(nn))), 0u);
+                    pm = minu(maxu(pm, 1u), 0xFFFFFFFEu);
+                    const bool cold = lreal == 0 && hreal == 0 && n != 0;
+                    const uint32_t Fm = count_le(cold ? pm : pl);
+                    if (cold) {
+                        if (Fm <= lo) { pl = pm; Fl = Fm; lreal = 1; }
+                        else { ph = pm; Fh = Fm; hreal = 1; }
+                    }
+                    if constexpr (STATS) ++st_cold;
+                }
+            }
+            uint32_t alo = 0, ahi = 0, pe = 0, Fe = 0, top_span = 0;
             int budget = kBudget2;
             for (;;) {
                 // ---- 32-bit count passes until every cell can be settled by one extraction ----
                 for (int it = 0;; ++it) {
-                    const bool settle = resolved || (lreal && lo - Fl <= SLACK) || (ph - pl <= 1u) ||
-                                        (!lreal && lo <= SLACK && Fl == 0);
+                    const bool settle = resolved || (lo - Fl <= SLACK) || (ph - pl <= 1u);
                     if (__all(settle) || it >= budget) break;
                     const uint32_t room = ph - pl;
-                    const bool both = lreal && hreal;
+                    const bool both = lreal != 0 && hreal != 0;
+                    const bool from_l = lreal != 0 || hreal == 0;
                     const float roomf = static_cast<float>(room);
                     const float slope = both ? roomf * __builtin_amdgcn_rcpf(static_cast<float>(Fh - Fl))
                                              : kpr * grow;
-                    const float ranks = (lreal || !hreal) ? aim - static_cast<float>(Fl) : static_cast<float>(Fh) - aim;
+                    const float ranks = from_l ? aim - static_cast<float>(Fl) : static_cast<float>(Fh) - aim;
                     float stf = fminf(fmaxf(ranks * slope, 1.0f), 2.0e9f);
-                    stf = (lreal || !hreal) ? stf : roomf - stf;
+                    stf = from_l ? stf : roomf - stf;
                     stf = fminf(fmaxf(stf, 1.0f), 4.0e9f);
                     uint32_t off = (it < 5) ? static_cast<uint32_t>(stf) : (room >> 1);
                     grow = both ? grow : grow * 2.0f;
@@ -623,8 +672,8 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                     const uint32_t F = count_le(p);
                     if constexpr (STATS) ++st_count;
                     if (!settle) {
-                        if (F <= lo) { pl = p; Fl = F; lreal = true; }
-                        else { ph = p; Fh = F; hreal = true; }
+                        if (F <= lo) { pl = p; Fl = F; lreal = 1; }
+                        else { ph = p; Fh = F; hreal = 1; }
                     }
                 }
                 // ---- extraction: the J smallest keys above the pivot --------------------
@@ -635,39 +684,10 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                 Top2<J> top;
                 top.reset();
                 if (wallc) {
-                    if constexpr (SKIPX) {
-                        // band: keys within (px, px + width] can be among the J smallest; positions at
-                        // which no lane of the wave holds such a key skip the insertion network.
-                        // width is a guess (8 ranks' worth of keys); the result is checked below.
-                        const uint32_t width = static_cast<uint32_t>(fminf(kpr * 8.0f, 1.0e9f));
 #pragma unroll
-                        for (int y = 0; y < YPS; ++y)
+                    for (int y = 0; y < YPS; ++y)
 #pragma unroll
-                            for (int k = 0; k < R; ++k) {
-                                const uint32_t d = ring[y][k] - base;
-                                if (__any(d <= width)) top.insert(d);
-                            }
-                        top.merge_cell();
-                        // valid iff the entries that will be read lie inside the band (every key of
-                        // the band was inserted); otherwise redo the pass in full
-                        const uint32_t jn = window ? (lo - Fl) + (need2 ? 1u : 0u) : 0u;
-                        const bool bad = !resolved && (top.at(minu(jn, J - 1u)) > width || !window);
-                        if (__any(bad)) {
-                            top.reset();
-#pragma unroll
-                            for (int y = 0; y < YPS; ++y)
-#pragma unroll
-                                for (int k = 0; k < R; ++k) top.insert(ring[y][k] - base);
-                            top.merge_cell();
-                            if constexpr (STATS) ++st_extract;
-                        }
-                    } else {
-#pragma unroll
-                        for (int y = 0; y < YPS; ++y)
-#pragma unroll
-                            for (int k = 0; k < R; ++k) top.insert(ring[y][k] - base);
-                        top.merge_cell();
-                    }
+                        for (int k = 0; k < R; ++k) top.insert(ring[y][k] - base);
                 } else {
 #pragma unroll
                     for (int y = 0; y < YPS; ++y)
@@ -676,8 +696,8 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                             const uint32_t d = opaque(ring[y][k]) - base;
                             top.insert(((cmask >> y) & 1u) ? d : 0xFFFFFFFFu);
                         }
-                    top.merge_cell();
                 }
+                top.merge_cell();
                 if constexpr (STATS) ++st_extract;
                 if (!resolved) {
                     if (window) {
@@ -685,6 +705,7 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                         alo = base + top.at(j);
                         ahi = need2 ? base + top.at(j + 1u) : alo;
                         pe = pl; Fe = Fl;
+                        top_span = top.m[J - 1] - top.m[0];
                         resolved = true;
                     } else if (adjacent) {
                         alo = ph;
@@ -701,17 +722,16 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                 if constexpr (STATS) ++st_count;
                 if (!resolved) {
                     if (Fj <= lo) {
-                        pl = pj; Fl = Fj; lreal = true;
+                        pl = pj; Fl = Fj; lreal = 1;
                     } else {
-                        ph = pj; Fh = Fj; hreal = true;
+                        ph = pj; Fh = Fj; hreal = 1;
                         Fl = Fl + top.count_below(dj);
                         pl = pj - 1u;
-                        lreal = true;
+                        lreal = 1;
                     }
                 }
                 budget = 2;
             }
-            (void)settled8;
 
             if constexpr (STATS) ++st_rows;
             double th = make_nan(), se = make_nan();
@@ -726,17 +746,17 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
                         if (obs >= 1.0f && obs < 1.0e8f) kpr = 0.75f * kpr + 0.25f * obs;
                     }
                 } else {
-                    // keys per rank from the extracted neighbours (local density at the target)
-                    const float obs = static_cast<float>(ahi - alo);
-                    if (need2 && obs >= 1.0f && obs < 1.0e8f) kpr = 0.9f * kpr + 0.1f * obs;
+                    // keys per rank: spread of the extracted list (J - 1 gaps above the pivot)
+                    const float obs = static_cast<float>(top_span) * (1.0f / static_cast<float>(J - 1));
+                    if (obs >= 1.0f && obs < 1.0e8f) kpr = 0.875f * kpr + 0.125f * obs;
                 }
             }
             if (n > 0 && wallc) {
                 pc = pe;
                 Fc = Fe;
-                have_c = true;
+                have_c = 1;
             } else {
-                have_c = false;
+                have_c = 0;
                 pc = 0;
                 Fc = 0;
             }
@@ -754,6 +774,21 @@ __global__ __launch_bounds__(256) void clim_ring2_f32(
             x_cur[y] = x_nxt[y];
         }
     }
+    if (rotate) {
+        // a held track did not advance: rotate its window one slot so that its oldest sample sits
+        // where the next step's PUSH will land
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) {
+            const unsigned long long hy = __builtin_amdgcn_ballot_w64(((hmask >> y) & 1u) != 0);
+            const uint32_t last = opaque(ring[y][R - 1]);
+            asm volatile("s_nop 1");     // hy may come straight from a v_cmp: two wait states before a VALU read
+#pragma unroll
+            for (int k = R - 1; k >= 1; --k) ring_sel(ring[y][k], ring[y][k - 1], hy);
+            ring_sel(ring[y][0], last, hy);
+        }
+        have_code = 0;         // byte positions moved: rebuild the code ring
+    }
+    }
     if (STATS && stats != nullptr && lane == 0) {
         atomicAdd(&stats[0], static_cast<unsigned long long>(st_rows));
         atomicAdd(&stats[1], static_cast<unsigned long long>(st_count));
@@ -770,10 +805,9 @@ namespace {
 typedef void (*Ring2Kernel)(const float*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*, int32_t,
                             const DevChunk*, double, int, int32_t, double*, double*, int64_t, unsigned long long*);
 struct Ring2Entry { int w, yps, variant; Ring2Kernel fn, fn_stats; };
-// variant: bit 0 = PROBE8, bit 1 = SKIPX; the _stats twin carries the debug pass counters
-#define XMHW_R2V(W, Y, V) {W, Y, V, clim_ring2_f32<W, Y, ((V) & 1) != 0, ((V) & 2) != 0, false>, \
-                           clim_ring2_f32<W, Y, ((V) & 1) != 0, ((V) & 2) != 0, true>}
-#define XMHW_R2(W, Y) XMHW_R2V(W, Y, 0), XMHW_R2V(W, Y, 1), XMHW_R2V(W, Y, 2), XMHW_R2V(W, Y, 3)
+// variant: bit 0 = PROBE8; the _stats twin carries the debug pass counters
+#define XMHW_R2V(W, Y, V) {W, Y, V, clim_ring2_f32<W, Y, ((V) & 1) != 0, false>, clim_ring2_f32<W, Y, ((V) & 1) != 0, true>}
+#define XMHW_R2(W, Y) XMHW_R2V(W, Y, 0), XMHW_R2V(W, Y, 1)
 const Ring2Entry kRing2[] = {
     XMHW_R2(5, 3), XMHW_R2(5, 4), XMHW_R2(5, 5),
 };
