@@ -33,6 +33,7 @@ extern "C" {
 #define XMHW_ERR_HIP 2         /* HIP runtime error / no device                     */
 #define XMHW_ERR_UNSUPPORTED 3 /* configuration outside every kernel's limits       */
 #define XMHW_ERR_NOMEM 4
+#define XMHW_ERR_COMM 5        /* RCCL could not be loaded / a collective failed     */
 
 /* kernel selector for xmhw_plan_set_kernel() / reported by xmhw_plan_info() */
 #define XMHW_KERNEL_AUTO 0
@@ -57,6 +58,9 @@ int xmhw_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes, void *str
 /* a block of columns of a row-major host array into a dense device array (hipMemcpy2D):
  * `height` rows of `width_bytes`, rows `spitch` bytes apart on the host, `dpitch` on the device */
 int xmhw_memcpy2d_h2d(void *dev_dst, size_t dpitch, const void *host_src, size_t spitch,
+                      size_t width_bytes, size_t height, void *stream);
+/* the inverse for results: a dense device array into a block of columns of a row-major host array */
+int xmhw_memcpy2d_d2h(void *host_dst, size_t dpitch, const void *dev_src, size_t spitch,
                       size_t width_bytes, size_t height, void *stream);
 int xmhw_memset(void *dev_dst, int value, size_t bytes, void *stream);
 int xmhw_stream_create(void **stream);
@@ -292,6 +296,37 @@ int xmhw_synth_sst_f32(float *ts_dev, int64_t T, int64_t C, int64_t ld, int64_t 
                        uint64_t seed, double nan_frac, void *stream);
 int xmhw_synth_sst_f64(double *ts_dev, int64_t T, int64_t C, int64_t ld, int64_t cell0,
                        uint64_t seed, double nan_frac, void *stream);
+
+/* ---- the sharded path: cells split across the GPUs of a node, ONE gather at the end ------- *
+ * Replaces the reference's collect, dask.compute(climls) + xr.concat(dim='cell')
+ * (xmhw/xmhw.py:197, :210-211).  Cells are independent (xmhw/xmhw.py:184-196), so rank r runs the
+ * hot path above on its own contiguous block of columns [c0_r, c0_r + cols_r) -- the caller simply
+ * passes that block's device pointer and width to xmhw_clim_raw_* / xmhw_clim_finish -- and the
+ * (rows, cols_r) float64 result blocks are gathered device-to-device over RCCL / xGMI.
+ * One process per GPU; RCCL is loaded (dlopen) at the first call of this section.             */
+typedef struct xmhw_comm xmhw_comm;
+#define XMHW_UNIQUE_ID_BYTES 128
+/* rank 0 creates the 128-byte id and hands it to the other ranks by any out-of-band means
+ * (xmhw_amd/bootstrap.py uses a TCP socket; MPI_Bcast or a shared file work as well)          */
+int xmhw_comm_unique_id(void *id_out);
+/* collective over all ranks, on each rank's CURRENT device (xmhw_set_device first)             */
+int xmhw_comm_create(int rank, int nranks, const void *id, xmhw_comm **comm);
+int xmhw_comm_destroy(xmhw_comm *comm);
+int xmhw_comm_info(const xmhw_comm *comm, int *rank, int *nranks);
+/* metadata: every rank contributes one int64 (cell counts, table sizes, error flags) and gets
+ * all of them back on the host; synchronises `stream`                                           */
+int xmhw_comm_allgather_i64(xmhw_comm *comm, int64_t value, int64_t *out_host, void *stream);
+/* equal-sized byte blocks (land-mask slabs): recv_dev holds nranks * bytes_per_rank; asynchronous */
+int xmhw_comm_allgather_bytes(xmhw_comm *comm, const void *send_dev, void *recv_dev,
+                              size_t bytes_per_rank, void *stream);
+/* THE gather: rank r sends its dense (rows, cols) float64 block; on `root`, recv_dev receives the
+ * blocks one after the other in rank order, block r being (rows, cols_of_rank[r]) contiguous
+ * (cols_of_rank is read on the root only and cols_of_rank[root] must equal cols; empty blocks
+ * are allowed).  Grouped ncclSend / ncclRecv on `stream`, asynchronous; the caller places the
+ * blocks (xmhw_memcpy2d_d2h writes block r straight into columns [c0_r, c0_r + cols_r) of a
+ * row-major host array).                                                                        */
+int xmhw_gather_blocks(xmhw_comm *comm, const double *send_dev, int64_t rows, int64_t cols,
+                       double *recv_dev, const int64_t *cols_of_rank, int root, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,6 @@
-"""N>1 host logic on CPU: world_size-2 gloo process group, the device stage
-replaced by the oracle (test hook).  The sharded result must be bit-identical
-to the unsharded one."""
+"""N>1 host logic on CPU: world_size-2/3 gloo process groups behind the transport interface of
+xmhw_amd.sharded (tests/gloo_transport.py stands in for the RCCL transport), the device stage
+replaced by the oracle (test hook).  The sharded result must be bit-identical to the unsharded one."""
 import os
 import socket
 import sys
@@ -20,12 +20,13 @@ def _free_port():
 
 
 def _worker(rank, world, port, outdir):
-    for p in (ROOT, os.path.join(ROOT, "oracle")):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
+    from gloo_transport import GlooTransport
     import oracle_fast as fast
     from xmhw_amd import GridSeries
     from xmhw_amd.sharded import threshold_sharded, slab_bounds
@@ -39,7 +40,7 @@ def _worker(rank, world, port, outdir):
     g = np.load(os.path.join(ROOT, "tests", "golden", "oisst_2003_2004.npz"))
     time = np.datetime64("2003-01-01") + g["time"].astype("timedelta64[D]")
     temp = GridSeries(g["sst"], ("time", "lat", "lon"), {"time": time, "lat": g["lat"], "lon": g["lon"]})
-    ds = threshold_sharded(temp, _compute=compute, smoothPercentileWidth=11)
+    ds = threshold_sharded(temp, GlooTransport(), _compute=compute, smoothPercentileWidth=11)
     assert slab_bounds(12, world)[rank] == ((0, 6), (6, 12))[rank]
     if rank == 0:
         np.savez(os.path.join(outdir, "sharded.npz"), thresh=ds["thresh"], seas=ds["seas"])
@@ -87,12 +88,13 @@ def _detect_worker(rank, world, port, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
+    from gloo_transport import GlooTransport
     from detect_standin import oracle_detect_cells
     from xmhw_amd.sharded import detect_sharded
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     temp, th, se = _detect_inputs()
-    out = detect_sharded(temp, th, se, _compute=oracle_detect_cells, intermediate=True, minDuration=4, maxGap=1)
+    out = detect_sharded(temp, th, se, GlooTransport(), _compute=oracle_detect_cells, intermediate=True, minDuration=4, maxGap=1)
     if rank == 0:
         mhw, inter = out
         np.savez(os.path.join(outdir, "detect.npz"), table=mhw.table, offsets=mhw.offsets,
@@ -165,6 +167,7 @@ def _grid_worker(rank, world, port, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
+    from gloo_transport import GlooTransport
     from xmhw_amd import GridSeries, XmhwException
     from xmhw_amd.sharded import threshold_sharded
 
@@ -172,7 +175,7 @@ def _grid_worker(rank, world, port, outdir):
     g = np.load(os.path.join(ROOT, "tests", "golden", "oisst_2003_2004.npz"))
     time = np.datetime64("2003-01-01") + g["time"].astype("timedelta64[D]")
     temp = GridSeries(g["sst"], ("time", "lat", "lon"), {"time": time, "lat": g["lat"], "lon": g["lon"]})
-    ds = threshold_sharded(temp, _grid_compute=_grid_standin, smoothPercentileWidth=11)
+    ds = threshold_sharded(temp, GlooTransport(), _grid_compute=_grid_standin, smoothPercentileWidth=11)
     if rank == 0:
         np.savez(os.path.join(outdir, "grid.npz"), thresh=ds["thresh"], seas=ds["seas"], lat=ds.coords["lat"],
                  lon=ds.coords["lon"])
@@ -182,7 +185,7 @@ def _grid_worker(rank, world, port, outdir):
     land = GridSeries(np.full((731, 3, 2), np.nan, np.float32), ("time", "lat", "lon"),
                       {"time": time, "lat": np.arange(3), "lon": np.arange(2)})
     try:
-        threshold_sharded(land, _grid_compute=_grid_standin)
+        threshold_sharded(land, GlooTransport(), _grid_compute=_grid_standin)
         raise AssertionError("expected XmhwException")
     except XmhwException:
         pass
@@ -247,11 +250,12 @@ def _detect_grid_worker(rank, world, port, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
+    from gloo_transport import GlooTransport
     from xmhw_amd.sharded import detect_sharded
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     temp, th, se = _detect_inputs()
-    out = detect_sharded(temp, th, se, _grid_compute=_detect_grid_standin, minDuration=4, maxGap=1)
+    out = detect_sharded(temp, th, se, GlooTransport(), _grid_compute=_detect_grid_standin, minDuration=4, maxGap=1)
     if rank == 0:
         np.savez(os.path.join(outdir, "detect_grid.npz"), table=out.table, offsets=out.offsets, keep=out.keep)
     else:
@@ -277,3 +281,74 @@ def test_sharded_detect_grid_path_equals_single(tmp_path, world):
     np.testing.assert_array_equal(got["keep"], mhw.keep)
     np.testing.assert_array_equal(got["offsets"], mhw.offsets)
     np.testing.assert_array_equal(got["table"], mhw.table)
+
+
+def _failing_worker(rank, world, port, outdir):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from gloo_transport import GlooTransport
+    from xmhw_amd import GridSeries, XmhwException
+    from xmhw_amd.sharded import threshold_sharded, detect_sharded
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def broken(stacked, doy, anynans, *a, columns=None, **k):
+        if rank == 1:
+            raise MemoryError("simulated hipMalloc failure on rank 1")
+        return _grid_standin(stacked, doy, anynans, *a, columns=columns, **k)
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "oisst_2003_2004.npz"))
+    time = np.datetime64("2003-01-01") + g["time"].astype("timedelta64[D]")
+    temp = GridSeries(g["sst"], ("time", "lat", "lon"), {"time": time, "lat": g["lat"], "lon": g["lon"]})
+    try:
+        threshold_sharded(temp, GlooTransport(), _grid_compute=broken)
+        raise AssertionError("expected XmhwException on every rank")
+    except XmhwException as e:
+        msg = str(e)
+    assert ("rank 1" in msg) or ("rank(s) [1]" in msg), msg
+
+    def broken_detect(stacked, anynans, *a, columns=None, exchange=None, **k):
+        if rank == 0:
+            raise RuntimeError("simulated failure before the survivor-count exchange")
+        return _detect_grid_standin(stacked, anynans, *a, columns=columns, exchange=exchange, **k)
+
+    t2, th, se = _detect_inputs()
+    try:
+        detect_sharded(t2, th, se, GlooTransport(), _grid_compute=broken_detect, minDuration=4, maxGap=1)
+        raise AssertionError("expected XmhwException on every rank")
+    except XmhwException:
+        pass
+    # the group is still usable afterwards
+    ds = threshold_sharded(temp, GlooTransport(), _grid_compute=_grid_standin, smoothPercentileWidth=11)
+    assert (ds is None) == (rank != 0)
+    open(os.path.join(outdir, f"ok{rank}"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_failure_on_one_rank_raises_on_all_ranks(tmp_path):
+    """A rank that fails in its local stage (out of memory, a bad block) must not leave the others
+    waiting in the next collective: the error flag is all-gathered and every rank raises."""
+    import torch.multiprocessing as mp
+    mp.spawn(_failing_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def _bootstrap_worker(rank, world, port, outdir):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from xmhw_amd import bootstrap
+    got = bootstrap.share_bytes(rank, world, (lambda: bytes(range(128))) if rank == 0 else None,
+                                addr="127.0.0.1", port=port)
+    assert got == bytes(range(128))
+    open(os.path.join(outdir, f"b{rank}"), "w").write("ok")
+
+
+def test_bootstrap_hands_the_unique_id_to_every_rank(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_bootstrap_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    assert all((tmp_path / f"b{r}").exists() for r in range(3))

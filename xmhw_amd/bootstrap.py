@@ -1,0 +1,68 @@
+"""Out-of-band exchange of a few bytes between the ranks of a sharded run (the 128-byte RCCL id).
+
+RCCL needs every rank to call ``ncclCommInitRank`` with the SAME unique id, created on one rank.
+How the id travels is not RCCL's business; here rank 0 listens on a TCP port and hands the payload
+to the other ranks -- the same star a process launcher's rendezvous uses, in ~40 lines of sockets,
+so that the product path needs neither MPI nor PyTorch.  On one node the address is 127.0.0.1.
+"""
+import os
+import socket
+import struct
+import time
+
+_MAGIC = b"XMHW"
+
+
+def default_port():
+    if os.environ.get("XMHW_BOOTSTRAP_PORT"):
+        return int(os.environ["XMHW_BOOTSTRAP_PORT"])
+    # next to the launcher's own rendezvous port (torchrun hosts a store ON MASTER_PORT, so not that one)
+    return (int(os.environ.get("MASTER_PORT", "29400")) + 17) % 65536 or 29417
+
+
+def _recv_exact(conn, n):
+    buf = b""
+    while len(buf) < n:
+        chunk = conn.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("bootstrap peer closed the connection")
+        buf += chunk
+    return buf
+
+
+def share_bytes(rank, size, make_payload, addr=None, port=None, timeout=120.0):
+    """Rank 0 calls ``make_payload()`` and every rank returns those bytes."""
+    if size == 1:
+        return make_payload()
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(port) if port else default_port()
+    if rank == 0:
+        payload = make_payload()
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind(("0.0.0.0" if addr not in ("127.0.0.1", "localhost") else "127.0.0.1", port))
+        srv.listen(size)
+        srv.settimeout(timeout)
+        served = 0
+        try:
+            while served < size - 1:
+                conn, _ = srv.accept()
+                with conn:
+                    if _recv_exact(conn, 4) != _MAGIC:
+                        continue
+                    conn.sendall(struct.pack("<I", len(payload)) + payload)
+                    served += 1
+        finally:
+            srv.close()
+        return payload
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as conn:
+                conn.sendall(_MAGIC)
+                (n,) = struct.unpack("<I", _recv_exact(conn, 4))
+                return _recv_exact(conn, n)
+        except (ConnectionRefusedError, ConnectionResetError, socket.timeout, OSError):
+            if time.monotonic() > deadline:
+                raise
+            time.sleep(0.05)

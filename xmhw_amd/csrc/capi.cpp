@@ -33,6 +33,10 @@ int hip_fail(hipError_t e, const char* what) {
     }
     return fail(XMHW_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
+}  // namespace
+// shared with comm.cpp
+int xmhw_set_error_(int code, const std::string& msg) { return fail(code, msg); }
+namespace {
 #define HIP_TRY(expr)                                        \
     do {                                                     \
         hipError_t _e = (expr);                              \

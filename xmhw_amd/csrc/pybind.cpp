@@ -15,12 +15,14 @@ namespace {
 
 struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
 struct InvalidError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct CommError : std::runtime_error { using std::runtime_error::runtime_error; };
 
 void check(int rc) {
     if (rc == XMHW_OK) return;
     std::string msg = xmhw_last_error();
     if (rc == XMHW_ERR_INVALID) throw InvalidError(msg);
     if (rc == XMHW_ERR_NOMEM) throw std::bad_alloc();
+    if (rc == XMHW_ERR_COMM) throw CommError(msg);
     throw HipError(msg + " (code " + std::to_string(rc) + ")");
 }
 
@@ -35,6 +37,7 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     m.doc() = "C-ABI bindings of the gfx950 xmhw threshold() path";
     py::register_exception<HipError>(m, "HipError");
     py::register_exception<InvalidError>(m, "InvalidArgument");
+    py::register_exception<CommError>(m, "CommError");
 
     m.attr("KERNEL_AUTO") = XMHW_KERNEL_AUTO;
     m.attr("KERNEL_RING") = XMHW_KERNEL_RING;
@@ -334,6 +337,58 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     }, py::arg("ts"), py::arg("itemsize"), py::arg("T"), py::arg("C"), py::arg("ld"), py::arg("seas"), py::arg("thresh"),
        py::arg("ldc"), py::arg("row_of_t"), py::arg("negate"), py::arg("events"), py::arg("ldo"), py::arg("out"),
        py::arg("ldv"), py::arg("dur"), py::arg("stream") = 0);
+
+    // ---- sharded path: RCCL communicator + the one gather ---------------------------------
+    m.def("comm_unique_id", []() {
+        std::string id(XMHW_UNIQUE_ID_BYTES, '\0');
+        check(xmhw_comm_unique_id(&id[0]));
+        return py::bytes(id);
+    });
+    m.def("comm_create", [](int rank, int nranks, py::bytes id) {
+        std::string sid = id;
+        if (sid.size() != XMHW_UNIQUE_ID_BYTES) throw InvalidError("unique id must be 128 bytes");
+        xmhw_comm* c = nullptr;
+        {
+            py::gil_scoped_release r;
+            check(xmhw_comm_create(rank, nranks, sid.data(), &c));
+        }
+        return reinterpret_cast<uintptr_t>(c);
+    });
+    m.def("comm_destroy", [](uintptr_t c) { check(xmhw_comm_destroy(reinterpret_cast<xmhw_comm*>(c))); });
+    m.def("comm_allgather_i64", [](uintptr_t c, int64_t value, uintptr_t stream) {
+        xmhw_comm* cc = reinterpret_cast<xmhw_comm*>(c);
+        int rank = 0, n = 0;
+        check(xmhw_comm_info(cc, &rank, &n));
+        py::array_t<int64_t> out(n);
+        {
+            py::gil_scoped_release r;
+            check(xmhw_comm_allgather_i64(cc, value, out.mutable_data(), vp(stream)));
+        }
+        return out;
+    }, py::arg("comm"), py::arg("value"), py::arg("stream") = 0);
+    m.def("comm_allgather_bytes", [](uintptr_t c, uintptr_t send, uintptr_t recv, size_t n, uintptr_t stream) {
+        check(xmhw_comm_allgather_bytes(reinterpret_cast<xmhw_comm*>(c), vp(send), vp(recv), n, vp(stream)));
+    }, py::arg("comm"), py::arg("send"), py::arg("recv"), py::arg("bytes_per_rank"), py::arg("stream") = 0);
+    m.def("gather_blocks", [](uintptr_t c, uintptr_t send, int64_t rows, int64_t cols, uintptr_t recv,
+                              py::array_t<int64_t, py::array::c_style | py::array::forcecast> cols_of_rank, int root,
+                              uintptr_t stream) {
+        check(xmhw_gather_blocks(reinterpret_cast<xmhw_comm*>(c), static_cast<const double*>(vp(send)), rows, cols,
+                                 static_cast<double*>(vp(recv)), cols_of_rank.size() ? cols_of_rank.data() : nullptr, root,
+                                 vp(stream)));
+    }, py::arg("comm"), py::arg("send"), py::arg("rows"), py::arg("cols"), py::arg("recv"), py::arg("cols_of_rank"),
+       py::arg("root") = 0, py::arg("stream") = 0);
+    m.def("memcpy2d_d2h", [](py::buffer dst, int64_t col0, int64_t ncols, uintptr_t src, uintptr_t stream) {
+        // dense (rows, ncols) device array -> columns [col0, col0 + ncols) of a C-contiguous 2-D host array
+        py::buffer_info bi = dst.request(true);
+        if (bi.ndim != 2 || bi.strides[1] != bi.itemsize || bi.strides[0] != bi.itemsize * bi.shape[1])
+            throw InvalidError("memcpy2d_d2h needs a C-contiguous 2-D array");
+        if (col0 < 0 || ncols < 0 || col0 + ncols > bi.shape[1]) throw InvalidError("column range outside the array");
+        const size_t isz = static_cast<size_t>(bi.itemsize);
+        py::gil_scoped_release r;
+        check(xmhw_memcpy2d_d2h(static_cast<char*>(bi.ptr) + isz * col0, isz * static_cast<size_t>(bi.shape[1]), vp(src),
+                                isz * static_cast<size_t>(ncols), isz * static_cast<size_t>(ncols),
+                                static_cast<size_t>(bi.shape[0]), vp(stream)));
+    }, py::arg("dst"), py::arg("col0"), py::arg("ncols"), py::arg("src"), py::arg("stream") = 0);
 
     m.def("synth_sst", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
                           double nan_frac, uintptr_t stream) {

@@ -285,9 +285,59 @@ def _grid_batch(stacked, max_batch_bytes, per_cell_extra=0):
     return int(max(1, min(N, max_batch_bytes // max(per_cell, 1))))
 
 
+def _grid_block_on_device(plan, stacked, c0, c1, anynans, pctile, coldSpells, feb29_fix, smooth, width):
+    """One rank's column block: mask, compact, climatology, placement back on the block's grid --
+    results stay on the device as a dense (2D, w) block.  Returns (keep, doys, DeviceBuffer, None)."""
+    h = hip()
+    D, w = plan.D, c1 - c0
+    isz = stacked.dtype.itemsize
+    block = DeviceBuffer(8 * 2 * D * max(w, 1))
+    bufs = []
+    try:
+        if w == 0:
+            return np.zeros(0, dtype=bool), plan.doys.copy(), block, None
+        d_ts, keep = compact_columns(stacked, c0, c1, anynans)
+        n = int(keep.sum())
+        if d_ts is None:
+            h.scatter_cells(0, 2 * D, 1, 0, 0, block.ptr, w)          # all land: a block of NaN
+            h.stream_sync(0)
+            return keep, plan.doys.copy(), block, None
+        bufs.append(d_ts)
+        raw_th, raw_se = DeviceBuffer(8 * D * n), DeviceBuffer(8 * D * n)
+        bufs += [raw_th, raw_se]
+        clim_raw(plan, d_ts, isz, n, pctile / 100.0, coldSpells, raw_th, raw_se)
+        finish = feb29_fix or smooth
+        th_ptr, se_ptr = block.ptr, block.ptr + 8 * D * w
+        if n == w:
+            # no land in the block: the finish kernel (or a copy) writes the block directly
+            if finish:
+                clim_finish(plan, raw_th, raw_se, n, feb29_fix, smooth, width, th_ptr, se_ptr)
+            else:
+                idx = DeviceBuffer.from_array(np.arange(n, dtype=np.int64)); bufs.append(idx)
+                h.scatter_cells(raw_th.ptr, D, n, idx.ptr, n, th_ptr, w)
+                h.scatter_cells(raw_se.ptr, D, n, idx.ptr, n, se_ptr, w)
+        else:
+            out_th, out_se = raw_th, raw_se
+            if finish:
+                out_th, out_se = DeviceBuffer(8 * D * n), DeviceBuffer(8 * D * n)
+                bufs += [out_th, out_se]
+                clim_finish(plan, raw_th, raw_se, n, feb29_fix, smooth, width, out_th, out_se)
+            idx = DeviceBuffer.from_array(np.nonzero(keep)[0].astype(np.int64)); bufs.append(idx)
+            h.scatter_cells(out_th.ptr, D, n, idx.ptr, n, th_ptr, w)
+            h.scatter_cells(out_se.ptr, D, n, idx.ptr, n, se_ptr, w)
+        h.stream_sync(0)
+        out, block = block, None
+        return keep, plan.doys.copy(), out, None
+    finally:
+        for b in bufs:
+            b.free()
+        if block is not None:
+            block.free()
+
+
 def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
                           tstep, coldSpells=False, kernel="auto", nchunks=0, max_batch_bytes=None,
-                          narrowing=True, columns=None, scatter=True):
+                          narrowing=True, columns=None, scatter=True, device_block=False):
     """land_check() + calc_clim() for an UNCOMPACTED stacked host array (T, N): the land mask, the
     compaction and the placement of the results back on the grid (what unstack('cell') does) run on
     the device, so the host only hands the array over (for a global grid numpy's dropna and
@@ -295,8 +345,13 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
     thresh[D, N], seas[D, N]) with NaN at the dropped cells; scatter=False returns the compact
     (D, C) arrays of the C = keep.sum() surviving cells instead.
     ``columns=(c0, c1)`` restricts the work to that column range (a rank's slab of a sharded run:
-    keep and the arrays then cover c1 - c0 columns and an all-land slab is not an error)."""
-    stacked = np.ascontiguousarray(native_float(stacked))
+    keep and the arrays then cover c1 - c0 columns and an all-land slab is not an error).
+    ``device_block=True`` (sharded runs) leaves the result on the device: the third return value is
+    a DeviceBuffer holding ONE dense (2D, c1 - c0) float64 block -- the D thresh rows, then the D seas
+    rows, on the grid with NaN at the dropped cells -- ready for xmhw_gather_blocks; the fourth is None."""
+    if not (isinstance(stacked, np.ndarray) and stacked.dtype.kind == "f" and stacked.dtype.itemsize in (4, 8)
+            and stacked.dtype.isnative and stacked.flags.c_contiguous):
+        stacked = np.ascontiguousarray(native_float(stacked))       # (a memmap of floats passes through untouched)
     T, N = stacked.shape
     h = hip()
     plan = Plan(doy, windowHalfWidth, kernel=kernel, nchunks=nchunks, narrowing=narrowing)
@@ -308,6 +363,12 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
     try:
         cb = _grid_batch(stacked, max_batch_bytes, per_cell_extra=4 * D * 8)
         c0, c1 = (0, N) if columns is None else (int(columns[0]), int(columns[1]))
+        if device_block:
+            if c1 - c0 > cb:
+                raise XmhwException(f"a block of {c1 - c0} columns does not fit this device in one piece "
+                                    f"({cb} columns do): use more ranks")
+            return _grid_block_on_device(plan, stacked, c0, c1, anynans, pctile, coldSpells, feb29_fix,
+                                         smoothPercentile, smoothPercentileWidth)
         for lo in range(c0, c1, cb):
             hi = min(c1, lo + cb)
             d_ts, keep = compact_columns(stacked, lo, hi, anynans)

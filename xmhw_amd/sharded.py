@@ -1,23 +1,34 @@
 """Multi-GPU threshold() and detect(): cells shard across ranks, one gather at the end.
 
-The reference treats every grid cell as an independent task
-(xmhw/xmhw.py:184-197), so the path shards with no exchange during compute:
-the compacted ocean-cell axis is cut into ``world_size`` contiguous slabs, each
-rank runs the HIP path on its slab, and the (D, slab) float64 result blocks are
-gathered to rank 0 (``torch.distributed.gather``; backend "nccl" = RCCL over
-xGMI on MI355X, "gloo" in the CPU tests).  The assembled result is
-bit-identical to the single-GPU one: the kernels do the same arithmetic per
-cell whatever the slab.
+The reference treats every grid cell as an independent task (xmhw/xmhw.py:184-197) and collects
+with ``dask.compute(climls)`` + ``xr.concat(dim='cell')`` (xmhw/xmhw.py:197, :210-211).  Here the
+stacked grid columns are cut into ``size`` contiguous blocks, one process per GPU runs the HIP path
+on its block (mask, compaction, climatology -- nothing is exchanged during compute), and the
+(D, block) float64 results travel once, device to device, to the root: ``xmhw_gather_blocks`` of
+the C ABI, i.e. grouped ncclSend / ncclRecv over RCCL / xGMI on the kernels' own output buffers.
+The assembled result is bit-identical to the single-GPU one (same per-cell arithmetic).
 
-torch is used for the process group and the collective only; the kernels are
-called through the C ABI.
+No PyTorch anywhere: the communicator is the C ABI's (``xmhw_comm_*``); the 128-byte RCCL id is
+handed round by ``xmhw_amd.bootstrap`` (a TCP socket).  Everything the sharded entry points need
+from the group goes through a small transport object (rank, size, all-gather of an int64 / of byte
+masks, gather of float64 blocks, an error agreement), so that the CPU tests can drive the same code
+with a stand-in transport (tests/gloo_transport.py) and stand-in device stages.
+
+Only a rank's own column block of ``temp`` is ever touched: pass an ``np.memmap`` (or any ndarray
+view of a file) and each process reads 1/size of it.
+
+Failure on one rank between two collectives would leave the others blocked: every local stage runs
+under ``transport.agree()``, which all-gathers an error flag and raises on ALL ranks together.
 """
+import os
+
 import numpy as np
 
 from . import api
 from .detect import INTER_VARIABLES, _detect
-from .device import calc_clim_device, calc_clim_grid_device
+from .device import DeviceBuffer, calc_clim_device, calc_clim_grid_device
 from .exception import XmhwException
+from ._lib import hip
 
 
 def slab_bounds(ncells, world_size):
@@ -31,208 +42,254 @@ def slab_bounds(ncells, world_size):
     return bounds
 
 
-def gather_blocks(th, se, ncells, group=None, dst=0, device=None):
-    """Gather per-rank (D, slab_r) blocks to ``dst``; returns (th, se) of shape
-    (D, ncells) on dst, (None, None) elsewhere."""
-    import torch
-    import torch.distributed as dist
+class RcclTransport:
+    """The product transport: an ``xmhw_comm`` (RCCL) on this process's current device."""
 
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    bounds = slab_bounds(ncells, world)
-    width = max(hi - lo for lo, hi in bounds)
-    D = th.shape[0]
-    if device is None:
-        # RCCL ("nccl") moves device memory only; gloo (CPU tests) takes host tensors
-        if dist.get_backend(group) == "nccl":
-            device = torch.device("cuda", torch.cuda.current_device())
+    def __init__(self, rank, size, unique_id, stream=0):
+        self._h = hip()
+        self.rank, self.size = int(rank), int(size)
+        self.stream = stream
+        self._comm = self._h.comm_create(self.rank, self.size, unique_id)
+
+    def close(self):
+        if self._comm:
+            self._h.comm_destroy(self._comm)
+            self._comm = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- metadata -------------------------------------------------------------------------
+    def allgather_i64(self, value):
+        return np.asarray(self._h.comm_allgather_i64(self._comm, int(value), self.stream), dtype=np.int64)
+
+    def allgather_u8(self, arr):
+        """variable-length uint8 vectors -> list of the ranks' vectors (every rank gets all)"""
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        counts = self.allgather_i64(arr.shape[0])
+        width = int(max(int(counts.max()), 1))
+        send = DeviceBuffer(width)
+        recv = DeviceBuffer(width * self.size)
+        try:
+            if arr.shape[0]:
+                self._h.memcpy_h2d(send.ptr, arr)
+            self._h.comm_allgather_bytes(self._comm, send.ptr, recv.ptr, width, self.stream)
+            self._h.stream_sync(self.stream)
+            flat = recv.to_array((self.size, width), np.uint8)
+        finally:
+            send.free()
+            recv.free()
+        return [flat[r, : int(counts[r])].copy() for r in range(self.size)]
+
+    def agree(self, error=None):
+        """Collective: raise XmhwException on every rank if any rank reports an error."""
+        flags = self.allgather_i64(0 if error is None else 1)
+        if flags.any():
+            bad = [int(r) for r in np.nonzero(flags)[0]]
+            if error is not None:
+                raise error
+            raise XmhwException(f"sharded run aborted: rank(s) {bad} failed in their local stage")
+
+    # -- bulk -------------------------------------------------------------------------------
+    def gather_columns(self, block, rows, dst=0):
+        """Per-rank dense (rows, cols_r) float64 blocks -> (rows, sum cols_r) host array on ``dst``
+        (blocks side by side in rank order), None elsewhere.  ``block`` is a DeviceBuffer holding
+        the dense block (the kernels' output, nothing is copied before it travels) or a host array."""
+        own = None
+        if isinstance(block, DeviceBuffer):
+            cols = block.nbytes // (8 * rows) if rows else 0
+            dev = block
         else:
-            device = torch.device("cpu")
-    dev = device
-    block = torch.full((2, D, width), float("nan"), dtype=torch.float64, device=dev)
-    n_r = bounds[rank][1] - bounds[rank][0]
-    if n_r:
-        block[0, :, :n_r] = torch.as_tensor(th, device=dev)
-        block[1, :, :n_r] = torch.as_tensor(se, device=dev)
-    out = [torch.empty_like(block) for _ in range(world)] if rank == dst else None
-    dist.gather(block, out, dst=dst, group=group)
-    if rank != dst:
-        return None, None
-    full = np.empty((2, D, ncells), dtype=np.float64)
-    for r, (lo, hi) in enumerate(bounds):
-        full[:, :, lo:hi] = out[r][:, :, : hi - lo].cpu().numpy()
-    return full[0], full[1]
+            a = np.ascontiguousarray(block, dtype=np.float64)
+            cols = a.shape[1] if a.ndim == 2 else 0
+            dev = own = DeviceBuffer.from_array(a)
+        counts = self.allgather_i64(cols)
+        total = int(counts.sum())
+        recv = None
+        try:
+            if self.rank == dst:
+                recv = DeviceBuffer(8 * rows * max(total, 1))
+            self._h.gather_blocks(self._comm, dev.ptr, rows, cols, recv.ptr if recv else 0,
+                                  counts if self.rank == dst else np.zeros(0, dtype=np.int64), dst, self.stream)
+            self._h.stream_sync(self.stream)
+            if self.rank != dst:
+                return None
+            out = np.empty((rows, total), dtype=np.float64)
+            off_bytes, c0 = 0, 0
+            for r in range(self.size):
+                n = int(counts[r])
+                if n and rows:
+                    self._h.memcpy2d_d2h(out, c0, n, recv.ptr + off_bytes, self.stream)
+                off_bytes += 8 * rows * n
+                c0 += n
+            return out
+        finally:
+            if own is not None:
+                own.free()
+            if recv is not None:
+                recv.free()
+
+    def gather_rows(self, table, dst=0):
+        """Per-rank (n_r, ncol) float64 tables -> (sum n_r, ncol) on ``dst`` (rank order), None elsewhere."""
+        table = np.ascontiguousarray(table, dtype=np.float64)
+        ncol = table.shape[1]
+        flat = self.gather_columns(table.reshape(1, -1), 1, dst)
+        return None if flat is None else flat.reshape(-1, ncol)
 
 
-def make_sharded_compute(group=None, dst=0, device=None, compute=None):
-    """A drop-in for device.calc_clim_device that computes only this rank's slab
-    and gathers.  ``compute`` defaults to the HIP path; the CPU tests of the
-    sharding logic inject a stand-in."""
-    import torch.distributed as dist
+def init_rccl(rank=None, size=None, local_rank=None, addr=None, port=None):
+    """One process per GPU: select the device, share the RCCL id, build the communicator.
+    Defaults come from the launcher's environment (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR;
+    the id travels on XMHW_BOOTSTRAP_PORT, default MASTER_PORT + 17)."""
+    from . import bootstrap
+    rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+    size = int(os.environ.get("WORLD_SIZE", "1")) if size is None else int(size)
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank))) if local_rank is None else int(local_rank)
+    h = hip()
+    h.set_device(local_rank)
+    uid = bootstrap.share_bytes(rank, size, h.comm_unique_id if rank == 0 else None, addr=addr, port=port)
+    return RcclTransport(rank, size, uid)
 
+
+def _stage(transport, fn):
+    """Run a rank-local stage; if it raises on any rank, all ranks raise together."""
+    err = None
+    out = None
+    try:
+        out = fn()
+    except Exception as e:      # noqa: BLE001 -- reported to every rank, then re-raised
+        err = e if isinstance(e, XmhwException) else XmhwException(f"rank {transport.rank}: {type(e).__name__}: {e}")
+    transport.agree(err)
+    return out
+
+
+def make_sharded_compute(transport, dst=0, compute=None):
+    """A drop-in for device.calc_clim_device that computes only this rank's slab of the COMPACT
+    cells and gathers.  ``compute`` defaults to the HIP path; the CPU tests inject a stand-in."""
     inner = compute or calc_clim_device
 
     def sharded(ts, doy, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
                 tstep, coldSpells=False):
-        world = dist.get_world_size(group)
-        rank = dist.get_rank(group)
         C = ts.shape[1]
-        lo, hi = slab_bounds(C, world)[rank]
-        slab = np.ascontiguousarray(ts[:, lo:hi])
-        if hi > lo:
-            doys, th, se = inner(slab, doy, pctile, windowHalfWidth, smoothPercentile,
-                                 smoothPercentileWidth, tstep, coldSpells)
+        lo, hi = slab_bounds(C, transport.size)[transport.rank]
+        doys = np.unique(np.asarray(doy, dtype=np.int64))
+
+        def local():
+            if hi <= lo:
+                return np.empty((doys.shape[0], 0)), np.empty((doys.shape[0], 0))
+            _, th, se = inner(np.ascontiguousarray(ts[:, lo:hi]), doy, pctile, windowHalfWidth, smoothPercentile,
+                              smoothPercentileWidth, tstep, coldSpells)
+            return th, se
+
+        th_r, se_r = _stage(transport, local)
+        D = doys.shape[0]
+        both = transport.gather_columns(np.concatenate([th_r, se_r], axis=0), 2 * D, dst)
+        if transport.rank != dst:
+            th = se = np.full((D, C), np.nan)       # placeholder of the right shape
         else:
-            doys = np.unique(np.asarray(doy, dtype=np.int64))
-            th = se = np.empty((doys.shape[0], 0))
-        th, se = gather_blocks(th, se, C, group=group, dst=dst, device=device)
-        if rank != dst:
-            # non-root ranks return a placeholder of the right shape
-            th = se = np.full((doys.shape[0], C), np.nan)
+            th, se = both[:D], both[D:]
         return doys, th, se
 
     return sharded
 
 
-def make_sharded_grid_compute(group=None, dst=0, device=None, grid_compute=None):
+def make_sharded_grid_compute(transport, dst=0, grid_compute=None):
     """A drop-in for device.calc_clim_grid_device: every rank takes a contiguous block of the
-    UNCOMPACTED stacked columns, masks / compacts / computes it on its own GPU (so no rank runs
-    land_check() over the whole grid on the host), then the masks are all-gathered (every rank
-    needs the surviving cells for the output grid) and the variable-width result blocks gathered
-    to ``dst``."""
-    import torch
-    import torch.distributed as dist
-
+    UNCOMPACTED stacked columns, masks / compacts / computes it on its own GPU (no rank runs
+    land_check() over the whole grid, no rank touches another rank's columns of ``stacked``), the
+    keep masks are all-gathered (N bytes: every rank needs the surviving cells for the output grid,
+    and an all-land grid raises on every rank alike), then ONE gather of the (2D, block) results."""
     inner = grid_compute or calc_clim_grid_device
 
     def sharded(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
                 tstep, coldSpells=False):
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
-        dev = _device_for(group, device)
         N = stacked.shape[1]
-        bounds = slab_bounds(N, world)
-        lo, hi = bounds[rank]
-        keep_r, doys, th_r, se_r = inner(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile,
-                                         smoothPercentileWidth, tstep, coldSpells, columns=(lo, hi))
+        lo, hi = slab_bounds(N, transport.size)[transport.rank]
+
+        def local():
+            return inner(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile,
+                         smoothPercentileWidth, tstep, coldSpells, columns=(lo, hi))
+
+        keep_r, doys, th_r, se_r = _stage(transport, local)
         D = doys.shape[0]
-        width = max(b - a for a, b in bounds)
-        mine = torch.zeros(width, dtype=torch.uint8, device=dev)
-        mine[: hi - lo] = torch.as_tensor(keep_r.astype(np.uint8), device=dev)
-        parts = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine, group=group)
-        keep = np.concatenate([parts[r][: b - a].cpu().numpy() != 0 for r, (a, b) in enumerate(bounds)])
+        keep = np.concatenate(transport.allgather_u8(keep_r.astype(np.uint8))) != 0
         if not keep.any():
             raise XmhwException("All points of grid are either land or NaN")     # on every rank alike
-        # the blocks come back on the grid (NaN at dropped cells), so they all have their slab's width
-        block = torch.full((2, D, width), float("nan"), dtype=torch.float64, device=dev)
-        if hi > lo:
-            block[0, :, : hi - lo] = torch.as_tensor(th_r, device=dev)
-            block[1, :, : hi - lo] = torch.as_tensor(se_r, device=dev)
-        out = [torch.empty_like(block) for _ in range(world)] if rank == dst else None
-        dist.gather(block, out, dst=dst, group=group)
-        if rank != dst:
+        # the blocks come back on the grid (NaN at dropped cells): each has its slab's width
+        if isinstance(th_r, DeviceBuffer):
+            block = th_r              # device-resident (2D, w) block from the HIP stage
+        else:
+            block = np.concatenate([th_r, se_r], axis=0)
+        both = transport.gather_columns(block, 2 * D, dst)
+        if isinstance(th_r, DeviceBuffer):
+            th_r.free()
+        if transport.rank != dst:
             th = se = np.full((D, N), np.nan)
         else:
-            full = np.concatenate([out[r][:, :, : b - a].cpu().numpy() for r, (a, b) in enumerate(bounds)], axis=2)
-            th, se = full[0], full[1]
+            th, se = both[:D], both[D:]
         return keep, doys, th, se
 
     return sharded
 
 
-def threshold_sharded(temp, group=None, dst=0, device=None, _compute=None, _grid_compute=None, **kwargs):
-    """threshold() over all ranks of ``group``; every rank passes the same ``temp``; rank ``dst``
-    gets the Dataset, the others None.  The ranks split the uncompacted grid columns and each
-    masks and compacts its own block on its GPU; ``_compute`` (test hook, compact-array stand-in)
-    selects the older path in which every rank runs land_check() on the host first."""
-    import torch.distributed as dist
+def _device_grid_compute(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
+                         tstep, coldSpells=False, columns=None):
+    """calc_clim_grid_device for one rank's block with the results LEFT ON THE DEVICE as one dense
+    (2D, w) float64 block (thresh rows, then seas rows), ready for xmhw_gather_blocks."""
+    return calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile,
+                                 smoothPercentileWidth, tstep, coldSpells, columns=columns, device_block=True)
 
+
+def threshold_sharded(temp, transport, dst=0, _compute=None, _grid_compute=None, **kwargs):
+    """threshold() over all ranks of ``transport``; every rank passes the same ``temp`` description
+    (only its own column block of the values is read); rank ``dst`` gets the Dataset, the others
+    None.  ``_compute`` / ``_grid_compute`` are test hooks (device-stage stand-ins)."""
     if _compute is not None:
-        ds = api._threshold(temp, make_sharded_compute(group, dst, device, _compute), **kwargs)
+        ds = api._threshold(temp, make_sharded_compute(transport, dst, _compute), **kwargs)
     else:
         # a single-point series has no grid to split: the compact-array path handles it
-        ds = api._threshold(temp, make_sharded_compute(group, dst, device, None),
-                            grid_compute=make_sharded_grid_compute(group, dst, device, _grid_compute), **kwargs)
-    return ds if dist.get_rank(group) == dst else None
+        ds = api._threshold(temp, make_sharded_compute(transport, dst, None),
+                            grid_compute=make_sharded_grid_compute(transport, dst, _grid_compute or _device_grid_compute),
+                            **kwargs)
+    return ds if transport.rank == dst else None
 
 
-def _device_for(group, device):
-    import torch
-    import torch.distributed as dist
-    if device is not None:
-        return device
-    if dist.get_backend(group) == "nccl":
-        return torch.device("cuda", torch.cuda.current_device())
-    return torch.device("cpu")
-
-
-def _gather_columns(block, ncells, group, dst, device):
-    """Gather per-rank (rows, slab_r) float64 blocks into (rows, ncells) on dst (None elsewhere)."""
-    import torch
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    bounds = slab_bounds(ncells, world)
-    width = max(hi - lo for lo, hi in bounds)
-    rows = block.shape[0]
-    pad = torch.zeros((rows, width), dtype=torch.float64, device=device)
-    n_r = bounds[rank][1] - bounds[rank][0]
-    if n_r:
-        pad[:, :n_r] = torch.as_tensor(np.ascontiguousarray(block, dtype=np.float64), device=device)
-    out = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, out, dst=dst, group=group)
-    if rank != dst:
-        return None
-    full = np.empty((rows, ncells), dtype=np.float64)
-    for r, (lo, hi) in enumerate(bounds):
-        full[:, lo:hi] = out[r][:, : hi - lo].cpu().numpy()
-    return full
-
-
-def make_sharded_detect(group=None, dst=0, device=None, compute=None):
+def make_sharded_detect(transport, dst=0, compute=None):
     """A drop-in for detect_front.detect_cells that runs only this rank's slab of cells and gathers
-    the event tables (variable length per rank: sizes first, then one padded gather) and, if asked
-    for, the per-step columns.  Rank dst returns the full result, the others an empty one."""
-    import torch
-    import torch.distributed as dist
-    from .detect_front import EVENT_COLUMNS, detect_cells
+    the event tables (variable length per rank) and, if asked for, the per-step columns.  Rank dst
+    returns the full result, the others an empty one."""
+    from .detect_front import EVENT_COLUMNS, INTERMEDIATE_U8, detect_cells
 
-    from .detect_front import INTERMEDIATE_U8
     inner = compute or detect_cells
     ncol = len(EVENT_COLUMNS)
     BOOL_VARIABLES = set(INTERMEDIATE_U8) | {"bthresh"}
 
     def sharded(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
                 intermediate=False):
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
-        dev = _device_for(group, device)
         T, C = ts.shape
-        lo, hi = slab_bounds(C, world)[rank]
-        if hi > lo:
-            res = inner(np.ascontiguousarray(ts[:, lo:hi]), np.ascontiguousarray(seas[:, lo:hi]),
-                        np.ascontiguousarray(thresh[:, lo:hi]), doy, doys, minDuration, joinGaps, maxGap,
-                        coldSpells, intermediate)
-        else:
-            res = dict(table=np.zeros((0, ncol)), offsets=np.zeros(1, dtype=np.int64), inter=None)
+        lo, hi = slab_bounds(C, transport.size)[transport.rank]
+
+        def local():
+            if hi <= lo:
+                return dict(table=np.zeros((0, ncol)), offsets=np.zeros(1, dtype=np.int64), inter=None)
+            return inner(np.ascontiguousarray(ts[:, lo:hi]), np.ascontiguousarray(seas[:, lo:hi]),
+                         np.ascontiguousarray(thresh[:, lo:hi]), doy, doys, minDuration, joinGaps, maxGap,
+                         coldSpells, intermediate)
+
+        res = _stage(transport, local)
         counts = np.diff(res["offsets"]).astype(np.float64)[None, :]
-        all_counts = _gather_columns(counts, C, group, dst, dev)
-        # table rows: every rank learns the largest table, pads to it, one gather
-        n_r = torch.tensor([res["table"].shape[0]], dtype=torch.int64, device=dev)
-        sizes = [torch.zeros_like(n_r) for _ in range(world)]
-        dist.all_gather(sizes, n_r, group=group)
-        sizes = [int(v.item()) for v in sizes]
-        nmax = max(max(sizes), 1)
-        pad = torch.zeros((nmax, ncol), dtype=torch.float64, device=dev)
-        if sizes[rank]:
-            pad[: sizes[rank]] = torch.as_tensor(res["table"], device=dev)
-        out = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-        dist.gather(pad, out, dst=dst, group=group)
+        all_counts = transport.gather_columns(counts, 1, dst)
+        table = transport.gather_rows(res["table"], dst)
         inter = None
         if intermediate:
             inter = {}
             for k in INTER_VARIABLES:
                 blk = res["inter"][k] if hi > lo else np.zeros((T, 0))
-                full = _gather_columns(blk, C, group, dst, dev)
-                if rank != dst:
+                full = transport.gather_columns(np.asarray(blk, dtype=np.float64), T, dst)
+                if transport.rank != dst:
                     continue
                 if k in BOOL_VARIABLES:
                     inter[k] = full != 0
@@ -240,12 +297,11 @@ def make_sharded_detect(group=None, dst=0, device=None, compute=None):
                     inter[k] = full.astype(ts.dtype)        # float32 values survive the float64 transport
                 else:
                     inter[k] = full
-        if rank != dst:
+        if transport.rank != dst:
             return dict(table=np.zeros((0, ncol)), offsets=np.zeros(C + 1, dtype=np.int64),
                         inter=None if not intermediate else
                         {k: np.zeros((T, C), dtype=bool if k in BOOL_VARIABLES else np.float64)
                          for k in INTER_VARIABLES})
-        table = np.concatenate([out[r][: sizes[r]].cpu().numpy() for r in range(world)], axis=0)
         offsets = np.zeros(C + 1, dtype=np.int64)
         np.cumsum(all_counts[0].astype(np.int64), out=offsets[1:])
         return dict(table=table, offsets=offsets, inter=inter)
@@ -253,87 +309,68 @@ def make_sharded_detect(group=None, dst=0, device=None, compute=None):
     return sharded
 
 
-def make_sharded_detect_grid(group=None, dst=0, device=None, grid_compute=None):
+def make_sharded_detect_grid(transport, dst=0, grid_compute=None):
     """A drop-in for detect_front.detect_grid: every rank masks and compacts its own block of the
     uncompacted series columns on its GPU; the survivor counts are all-gathered (a block's cells
     pair up with the climatology columns at the offset of the blocks before it), then the event
     tables travel as in make_sharded_detect and the keep masks are all-gathered."""
-    import torch
-    import torch.distributed as dist
     from .detect_front import EVENT_COLUMNS, detect_grid
 
     inner = grid_compute or detect_grid
     ncol = len(EVENT_COLUMNS)
-    fallback = make_sharded_detect(group, dst, device, None)
 
     def sharded(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
                 intermediate=False, clim_stacked=False):
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
-        dev = _device_for(group, device)
         N = stacked.shape[1]
-        bounds = slab_bounds(N, world)
-        lo, hi = bounds[rank]
-
-        def exchange(n_mine):
-            mine = torch.tensor([n_mine], dtype=torch.int64, device=dev)
-            parts = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine, group=group)
-            counts = [int(v.item()) for v in parts]
-            return sum(counts[:rank]), sum(counts)
-
+        lo, hi = slab_bounds(N, transport.size)[transport.rank]
         if intermediate:
             raise XmhwException("detect_sharded: intermediate=True is only available through the host "
                                 "land_check path (pass _compute)")
-        res = inner(stacked, anynans, seas, thresh, doy, doys, minDuration, joinGaps, maxGap, coldSpells, False,
-                    clim_stacked=clim_stacked, columns=(lo, hi), exchange=exchange)
-        # keep masks to everybody, per-cell event counts and the tables to dst
-        width = max(b - a for a, b in bounds)
-        mine = torch.zeros(width, dtype=torch.uint8, device=dev)
-        mine[: hi - lo] = torch.as_tensor(res["keep"].astype(np.uint8), device=dev)
-        parts = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine, group=group)
-        keep = np.concatenate([parts[r][: b - a].cpu().numpy() != 0 for r, (a, b) in enumerate(bounds)])
+
+        # the positional pairing with the climatology needs every rank's survivor count in the middle
+        # of the local stage: that exchange is itself a collective, so a rank that fails before it
+        # still takes part (with a count of 0) and reports its error at the agreement that follows
+        state = {"exchanged": False}
+
+        def exchange(n_mine):
+            state["exchanged"] = True
+            counts = transport.allgather_i64(n_mine)
+            return int(counts[: transport.rank].sum()), int(counts.sum())
+
+        def local():
+            try:
+                return inner(stacked, anynans, seas, thresh, doy, doys, minDuration, joinGaps, maxGap, coldSpells,
+                             False, clim_stacked=clim_stacked, columns=(lo, hi), exchange=exchange)
+            except Exception:
+                if not state["exchanged"]:
+                    exchange(0)
+                raise
+
+        res = _stage(transport, local)
+        keep = np.concatenate(transport.allgather_u8(res["keep"].astype(np.uint8))) != 0
         if not keep.any():
             raise XmhwException("All points of grid are either land or NaN")
-        ncells = [int(keep[a:b].sum()) for a, b in bounds]
-        cmax = max(max(ncells), 1)
-        cnt = torch.zeros(cmax, dtype=torch.int64, device=dev)
-        if ncells[rank]:
-            cnt[: ncells[rank]] = torch.as_tensor(np.diff(res["offsets"]), device=dev)
-        cnts = [torch.zeros_like(cnt) for _ in range(world)] if rank == dst else None
-        dist.gather(cnt, cnts, dst=dst, group=group)
-        n_r = torch.tensor([res["table"].shape[0]], dtype=torch.int64, device=dev)
-        sizes = [torch.zeros_like(n_r) for _ in range(world)]
-        dist.all_gather(sizes, n_r, group=group)
-        sizes = [int(v.item()) for v in sizes]
-        pad = torch.zeros((max(max(sizes), 1), ncol), dtype=torch.float64, device=dev)
-        if sizes[rank]:
-            pad[: sizes[rank]] = torch.as_tensor(res["table"], device=dev)
-        out = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-        dist.gather(pad, out, dst=dst, group=group)
+        counts = transport.gather_columns(np.diff(res["offsets"]).astype(np.float64)[None, :], 1, dst)
+        table = transport.gather_rows(res["table"], dst)
         C = int(keep.sum())
-        if rank != dst:
+        if transport.rank != dst:
             return dict(table=np.zeros((0, ncol)), offsets=np.zeros(C + 1, dtype=np.int64), inter=None, keep=keep)
-        table = np.concatenate([out[r][: sizes[r]].cpu().numpy() for r in range(world)], axis=0)
-        counts = np.concatenate([cnts[r][: ncells[r]].cpu().numpy() for r in range(world)])
         offsets = np.zeros(C + 1, dtype=np.int64)
-        np.cumsum(counts, out=offsets[1:])
+        np.cumsum(counts[0].astype(np.int64), out=offsets[1:])
         return dict(table=table, offsets=offsets, inter=None, keep=keep)
 
     return sharded
 
 
-def detect_sharded(temp, th, se, group=None, dst=0, device=None, _compute=None, _grid_compute=None, **kwargs):
-    """detect() over all ranks of ``group``; rank ``dst`` gets what detect() returns, the others None.
-    The ranks split the uncompacted grid columns and each masks / compacts its own block on its GPU
-    (survivor counts are exchanged so that every block finds its climatology columns); ``_compute``
-    (test hook, compact-array stand-in; also needed for intermediate=True) selects the older path in
-    which every rank runs land_check() on the host and the compact cells are split."""
-    import torch.distributed as dist
-
+def detect_sharded(temp, th, se, transport, dst=0, _compute=None, _grid_compute=None, **kwargs):
+    """detect() over all ranks of ``transport``; rank ``dst`` gets what detect() returns, the others
+    None.  The ranks split the uncompacted grid columns and each masks / compacts its own block on
+    its GPU (survivor counts are exchanged so that every block finds its climatology columns);
+    ``_compute`` (test hook, compact-array stand-in; also needed for intermediate=True) selects the
+    older path in which every rank runs land_check() on the host and the compact cells are split."""
     if _compute is not None or kwargs.get("intermediate"):
-        out = _detect(temp, th, se, make_sharded_detect(group, dst, device, _compute), **kwargs)
+        out = _detect(temp, th, se, make_sharded_detect(transport, dst, _compute), **kwargs)
     else:
-        out = _detect(temp, th, se, make_sharded_detect(group, dst, device, None),
-                      grid_compute=make_sharded_detect_grid(group, dst, device, _grid_compute), **kwargs)
-    return out if dist.get_rank(group) == dst else None
+        out = _detect(temp, th, se, make_sharded_detect(transport, dst, None),
+                      grid_compute=make_sharded_detect_grid(transport, dst, _grid_compute), **kwargs)
+    return out if transport.rank == dst else None
