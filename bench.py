@@ -1,320 +1,440 @@
 #!/usr/bin/env python3
 """bench.py -- grid-cells/s of the threshold() hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the one the metric is quoted on): 0.25 deg
-global grid (1440 x 720 = 1,036,800 cells), 40-yr daily SST 1982-2021
-(T = 14,610), windowHalfWidth=5, pctile=90, smoothPercentileWidth=31,
-float32 input resident in HBM, float64 output.
+    python bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the path over the rank's cells: raw climatology (ring
-kernel) + Feb-29/smoothing (finish kernel), slab by slab; with N > 1 every
-slab's (D, slab) result block is gathered to rank 0 over RCCL while the next
-slab computes.  Weak scaling: every rank holds a full 0.25 deg grid of its own.
+N = 1 (default): BASELINE.json configs[2], the configuration the metric is quoted on -- 0.25 deg
+global grid (1440 x 720 = 1,036,800 cells), 40-yr daily SST 1982-2021 (T = 14,610),
+windowHalfWidth=5, pctile=90, smoothPercentileWidth=31, float32 input resident in HBM, float64 out.
 
-One JSON line on rank 0 (see the driver contract); the `roofline` object is
-for the ring kernel (algorithmic bytes = T*4 + 2*D*8 per cell), the
-`cpu_baseline` object times the numpy restatement of the reference (oracle/)
-on a bounded sample of the same synthetic input on the host cores.
+N > 1: configs[3] -- ONE 0.25 deg grid with ~5 % NaN (skipna=True), its 1,036,800 cells split into N
+contiguous blocks, one process per GPU (STRONG scaling: the total work is fixed), every step's
+(2D, block) results gathered to rank 0 over RCCL (xmhw_gather_blocks: grouped ncclSend/ncclRecv on
+the kernels' output buffers, issued per slab on a second stream so that it overlaps the next
+slab's kernels).  `--scaling weak` keeps a full grid per rank instead.  Launch: either by a process
+launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun does), or
+directly -- `python bench.py --gpus N` with no WORLD_SIZE starts the N worker processes itself,
+before anything in the parent touches a GPU.
+
+A step = one pass of the path over the rank's cells: raw climatology (ring kernel) + Feb-29 /
+smoothing (finish kernel).  Timing: barrier + device sync, K steps, device sync + barrier, MAX over
+ranks.  One JSON line on rank 0's stdout (see the driver contract):
+  roofline      ring kernel: algorithmic bytes (T*4 + 2*D*8 per cell) / average launch time from HIP
+                events recorded on the kernels' stream; `traffic` = HBM bytes per launch measured
+                LIVE: before this process touches the GPU it runs itself twice under
+                `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE in separate passes, the gfx950 x2
+                correction of FETCH_SIZE applied) on one step of the same workload; null when
+                rocprofv3 is unavailable (N > 1: null)
+  cpu_baseline  the per-cell numpy restatement of the reference (oracle/oracle_percell.py) on the
+                box's PHYSICAL cores (spawned workers, pool start-up and pool-index construction
+                outside the timed region), a bounded sample of the same synthetic input
+  parity        cells spread over the grid against oracle_fast (contract 1e-6 relative); with N > 1
+                also an N-rank == 1-rank bit-identity check on columns of every rank's block
+
+No PyTorch: device memory, streams, events and the collective all go through the C ABI.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "oracle")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
-
-def daily_doy(y0, y1):
-    from xmhw_amd.calendar import add_doy
-    t = np.arange(f"{y0}-01-01", f"{y1 + 1}-01-01", dtype="datetime64[D]")
-    return add_doy(t)
-
-
-def _cpu_cell_worker(args):
-    import oracle_percell as opc
-    x, doy, kw = args
-    return opc.threshold_cells_percell(x, doy, **kw)[1:]
-
-
-def cpu_baseline(sample, doy, kw, budget_cells):
-    """Time the per-cell numpy restatement on all host cores (multiprocessing)."""
-    import multiprocessing as mp
-    cores = os.cpu_count() or 1
-    ncell = min(sample.shape[1], budget_cells)
-    parts = [p for p in np.array_split(np.arange(ncell), cores) if p.size]
-    jobs = [(np.ascontiguousarray(sample[:, p]), doy, kw) for p in parts]
-    ctx = mp.get_context("fork")
-    with ctx.Pool(len(jobs)) as pool:
-        pool.map(_cpu_cell_worker, [(j[0][:, :1], doy, kw) for j in jobs])  # warm the workers
-        t0 = time.perf_counter()
-        res = pool.map(_cpu_cell_worker, jobs)
-        dt = time.perf_counter() - t0
-    th = np.concatenate([r[0] for r in res], axis=1)
-    se = np.concatenate([r[1] for r in res], axis=1)
-    return ncell / dt, len(jobs), ncell, th, se
+PRESETS = {
+    "0.25deg": dict(cells=1440 * 720, years=(1982, 2021), nan=0.0, tstep=False, skipna=False, index=2,
+                    name="0.25deg global (configs[2])"),
+    "1deg": dict(cells=360 * 180, years=(1991, 2020), nan=0.0, tstep=False, skipna=False, index=1,
+                 name="1deg global (configs[1])"),
+    "0.25deg_nan": dict(cells=1440 * 720, years=(1982, 2021), nan=0.05, tstep=False, skipna=True, index=3,
+                        name="0.25deg global, 5% NaN, skipna=True (configs[3])"),
+    "0.05deg_tstep": dict(cells=810000, years=(2001, 2020), nan=0.0, tstep=True, skipna=False, index=4,
+                          name="0.05deg tile share, 6-hourly no-leap tstep (configs[4], one GPU's share)"),
+}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="0.25deg",
-                    choices=["0.25deg", "1deg", "0.25deg_nan", "0.05deg_tstep"],
-                    help="BASELINE.json preset: 0.25deg = configs[2] (default, the metric's config); "
-                         "1deg = configs[1]; 0.25deg_nan = configs[3] (5%% NaN); "
-                         "0.05deg_tstep = configs[4] per-GPU share (810,000 cells, 6-hourly, tstep)")
-    ap.add_argument("--cells", type=int, default=0, help="cells per GPU (0: the preset's)")
-    ap.add_argument("--years", type=int, nargs=2, default=None)
-    ap.add_argument("--slabs", type=int, default=0, help="launches per step (0: 1 at N=1, 8 at N>1)")
-    ap.add_argument("--nan-frac", type=float, default=0.0)
+    ap.add_argument("--config", default=None, choices=sorted(PRESETS),
+                    help="default: 0.25deg (configs[2]) at N=1, 0.25deg_nan (configs[3]) at N>1")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N>1: strong = one grid split over the ranks (default); weak = a full grid per rank")
+    ap.add_argument("--cells", type=int, default=0, help="total cells (strong) / cells per GPU (weak, N=1); 0: the preset's")
+    ap.add_argument("--slabs", type=int, default=0, help="launches per step (0: 1 at N=1, 4 at N>1)")
     ap.add_argument("--kernel", default="auto")
+    ap.add_argument("--ring2", type=int, default=None, help="ring kernel generation override (-1, 0, 1)")
     ap.add_argument("--chunks", type=int, default=0)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64", "f64n"],
-                    help="input dtype (output is always f64); f64n = float64 holding float32-representable samples "
-                         "(decoded int16/float32 archives): runs on the float32 ring kernel")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--force-dist", action="store_true", help="init RCCL and run the gather even with one rank")
-    ap.add_argument("--cpu-cells", type=int, default=512)
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 traffic measurement")
+    ap.add_argument("--force-dist", action="store_true", help="build the RCCL communicator and gather even with one rank")
+    ap.add_argument("--cpu-cells", type=int, default=16384)
     ap.add_argument("--parity-cells", type=int, default=512)
-    args = ap.parse_args()
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_workers(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh worker processes (one per GPU).
+    The parent never touches a GPU; rank 0 inherits stdout (the JSON line), the other ranks' stdout
+    goes to stderr.  Exit code: the largest worker exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), XMHW_BOOTSTRAP_PORT=str(_free_port() if r == 0 else 0))
+        procs.append((r, env))
+    boot = procs[0][1]["XMHW_BOOTSTRAP_PORT"]
+    running = []
+    for r, env in procs:
+        env["XMHW_BOOTSTRAP_PORT"] = boot
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        running.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--worker"], env=env,
+                                        stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    for p in running:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def live_traffic(argv):
+    """HBM bytes per ring-kernel launch measured on THIS box for THIS workload: two rocprofv3 --pmc
+    passes (FETCH_SIZE, WRITE_SIZE: TCC slots do not fit both) of one untimed step, run as child
+    processes before this process touches the GPU.  FETCH_SIZE is reported in KB and counts a wide
+    coalesced stream at half its bytes on gfx950 (MI355X_MICROARCH.md, HBM): x2."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not found"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="xmhw_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__)] + argv + \
+                  ["--steps", "1", "--warmup", "0", "--no-cpu", "--no-pmc", "--parity-cells", "0", "--pmc-child"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            tot, n = 0.0, 0
+            for row in csv.DictReader(open(files[0])):
+                if "clim_ring" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    tot += float(row["Counter_Value"])
+                    n += 1
+            if n == 0:
+                return None, "no ring-kernel dispatch in the counter file"
+            out[counter] = tot / n * 1024.0        # KB -> bytes, per launch
+    except Exception as e:      # noqa: BLE001 -- a profiler problem must not fail the benchmark
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"], "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, this run's box and workload"
+
+
+def run(args):
+    import numpy as np
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before anything initialises HIP / RCCL
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
 
     # stdout carries exactly one JSON line: keep a private handle to it and point fd 1 at stderr, so
-    # that banners printed by native libraries (RCCL prints its version to stdout) cannot add lines
+    # that banners printed by native libraries (RCCL prints its version) cannot add lines
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
-    import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-        sys.exit(2)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    use_dist = world > 1 or args.force_dist   # --force-dist: exercise the RCCL path with one rank
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
-
-    from xmhw_amd._lib import hip
-    from xmhw_amd.device import Plan, clim_raw, clim_finish
-    h = hip()
-    h.set_device(local)
-
-    presets = {
-        "0.25deg": dict(cells=1440 * 720, years=(1982, 2021), nan=0.0, tstep=False, name="0.25deg global"),
-        "1deg": dict(cells=360 * 180, years=(1991, 2020), nan=0.0, tstep=False, name="1deg global"),
-        "0.25deg_nan": dict(cells=1440 * 720, years=(1982, 2021), nan=0.05, tstep=False,
-                            name="0.25deg global, 5% NaN"),
-        "0.05deg_tstep": dict(cells=810000, years=(2001, 2020), nan=0.0, tstep=True,
-                              name="0.05deg tile share, 6-hourly no-leap (tstep)"),
-    }
-    ps = presets[args.config]
-    years = tuple(args.years) if args.years else ps["years"]
-    if args.nan_frac == 0.0:
-        args.nan_frac = ps["nan"]
+    cfg = args.config or ("0.25deg" if world == 1 else "0.25deg_nan")
+    ps = PRESETS[cfg]
+    strong = world > 1 and args.scaling == "strong"
     tstep = ps["tstep"]
+    from xmhw_amd.calendar import add_doy
     if tstep:   # 1460 steps per year, no leap days (docs/frequency.rst:42-50), add_doy tstep branch
-        nyr = years[1] - years[0] + 1
-        doy = np.tile(np.arange(1, 1461, dtype=np.int64), nyr)
+        doy = np.tile(np.arange(1, 1461, dtype=np.int64), ps["years"][1] - ps["years"][0] + 1)
     else:
-        doy = daily_doy(*years)
-    args.years = list(years)
+        doy = add_doy(np.arange(f"{ps['years'][0]}-01-01", f"{ps['years'][1] + 1}-01-01", dtype="datetime64[D]"))
     T = int(doy.shape[0])
-    C = int(args.cells) or ps["cells"]
     w, pctile, width = 5, 90, 31
     q = pctile / 100.0
-    plan = Plan(doy, w, kernel=args.kernel, nchunks=args.chunks)
-    D = plan.D
-    nslab = args.slabs or (8 if use_dist else 1)
-    bounds = [C * i // nslab for i in range(nslab + 1)]
-    slabs = [(bounds[i], bounds[i + 1]) for i in range(nslab) if bounds[i + 1] > bounds[i]]
+    kw = dict(pctile=pctile, windowHalfWidth=w, smoothPercentileWidth=width, tstep=tstep, skipna=ps["skipna"])
 
-    # ---- inputs resident in HBM: synthetic SST generated on the device --------------
-    isz = 4 if args.dtype == "f32" else 8
-    seed = 20260101 + 2
-    stream = torch.cuda.current_stream().cuda_stream
-    if args.dtype == "f64n":
-        ts32 = torch.empty((T, C), dtype=torch.float32, device=dev)
-        h.synth_sst(ts32.data_ptr(), 4, T, C, C, rank * C, seed, args.nan_frac, stream)
-        ts = ts32.double()
-        del ts32
-        torch.cuda.empty_cache()
+    # ---- everything that forks / spawns happens BEFORE this process touches the GPU -------------
+    pool = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import parallel as opar
+        pool = opar.OraclePool(doy, w)
+    traffic, traffic_src = None, None
+    if rank == 0 and world == 1 and not args.no_pmc and not args.pmc_child:
+        child_argv = ["--gpus", "1", "--config", cfg, "--dtype", args.dtype, "--kernel", args.kernel,
+                      "--chunks", str(args.chunks), "--cells", str(args.cells)]
+        if args.ring2 is not None:
+            child_argv += ["--ring2", str(args.ring2)]
+        traffic, traffic_src = live_traffic(child_argv)
+
+    from xmhw_amd._lib import hip
+    from xmhw_amd.device import DeviceBuffer, Plan, clim_finish, clim_raw, release_device_cache
+    from xmhw_amd.sharded import init_rccl, slab_bounds
+    h = hip()
+    h.set_device(local)
+    use_dist = world > 1 or args.force_dist
+    tr = init_rccl(rank=rank, size=world, local_rank=local) if use_dist else None
+
+    def barrier():
+        h.stream_sync(0)
+        if tr is not None:
+            tr.allgather_i64(0)
+
+    # ---- this rank's cells --------------------------------------------------------------------
+    C_total = int(args.cells) or ps["cells"]
+    if strong:
+        lo, hi = slab_bounds(C_total, world)[rank]
     else:
-        ts = torch.empty((T, C), dtype=torch.float32 if isz == 4 else torch.float64, device=dev)
-        h.synth_sst(ts.data_ptr(), isz, T, C, C, rank * C, seed, args.nan_frac, stream)
-    raw_th = [torch.empty((D, b - a), dtype=torch.float64, device=dev) for a, b in slabs]
-    raw_se = [torch.empty((D, b - a), dtype=torch.float64, device=dev) for a, b in slabs]
-    out = [torch.empty((2, D, b - a), dtype=torch.float64, device=dev) for a, b in slabs]
-    gathered = None
-    if use_dist and rank == 0:
-        gathered = [[torch.empty((2, D, b - a), dtype=torch.float64, device=dev) for _ in range(world)]
-                    for a, b in slabs]
-    torch.cuda.synchronize()
+        lo, hi = rank * C_total, (rank + 1) * C_total         # weak: a grid of its own per rank
+    C = hi - lo
+    plan = Plan(doy, w, kernel=args.kernel, nchunks=args.chunks, ring2=args.ring2)
+    D = plan.D
+    nslab = args.slabs or (4 if use_dist else 1)
+    edges = [C * i // nslab for i in range(nslab + 1)]
+    slabs = [(edges[i], edges[i + 1]) for i in range(nslab) if edges[i + 1] > edges[i]]
 
+    # ---- inputs resident in HBM: synthetic SST generated on the device ------------------------
+    isz = 4 if args.dtype == "f32" else 8
+    seed = 20260101 + ps["index"]
+    ts = DeviceBuffer(isz * T * C)
+    h.synth_sst(ts.ptr, isz, T, C, C, lo, seed, ps["nan"], 0)
+    raw_th = [DeviceBuffer(8 * D * (b - a)) for a, b in slabs]
+    raw_se = [DeviceBuffer(8 * D * (b - a)) for a, b in slabs]
+    out = [DeviceBuffer(8 * 2 * D * (b - a)) for a, b in slabs]          # dense (2D, n): thresh rows, then seas rows
+    comm_stream = h.stream_create() if use_dist else 0
+    recv, cols_of_rank = [], []
+    if use_dist:
+        for i, (a, b) in enumerate(slabs):
+            counts = tr.allgather_i64(b - a)
+            cols_of_rank.append(counts)
+            recv.append(DeviceBuffer(8 * 2 * D * int(counts.sum())) if rank == 0 else None)
+    h.stream_sync(0)
     ev = [(h.event_create(), h.event_create(), h.event_create()) for _ in slabs]
     ring_ms, finish_ms = [], []
 
     def step(timed):
-        works = []
         for i, (a, b) in enumerate(slabs):
             n = b - a
-            h.event_record(ev[i][0], stream)
-            clim_raw(plan, ts.data_ptr() + isz * a, isz, n, q, False, raw_th[i].data_ptr(),
-                     raw_se[i].data_ptr(), ld=C, ldo=n, stream=stream)
-            h.event_record(ev[i][1], stream)
-            clim_finish(plan, raw_th[i].data_ptr(), raw_se[i].data_ptr(), n, not tstep, True, width,
-                        out[i][0].data_ptr(), out[i][1].data_ptr(), ldo=n, stream=stream)
-            h.event_record(ev[i][2], stream)
+            h.event_record(ev[i][0], 0)
+            clim_raw(plan, ts.ptr + isz * a, isz, n, q, False, raw_th[i], raw_se[i], ld=C, ldo=n)
+            h.event_record(ev[i][1], 0)
+            clim_finish(plan, raw_th[i], raw_se[i], n, not tstep, True, width, out[i].ptr, out[i].ptr + 8 * D * n, ldo=n)
+            h.event_record(ev[i][2], 0)
             if use_dist:
-                works.append(dist.gather(out[i], gathered[i] if rank == 0 else None, dst=0, async_op=True))
-        for wk in works:
-            wk.wait()
+                # the slab's gather rides a second stream behind its finish kernel and overlaps the next slab
+                h.stream_wait_event(comm_stream, ev[i][2])
+                h.gather_blocks(tr._comm, out[i].ptr, 2 * D, n, recv[i].ptr if rank == 0 else 0,
+                                cols_of_rank[i] if rank == 0 else np.zeros(0, dtype=np.int64), 0, comm_stream)
+        h.stream_sync(0)
+        if use_dist:
+            h.stream_sync(comm_stream)
         if timed:
-            torch.cuda.synchronize()
             for i in range(len(slabs)):
                 ring_ms.append(h.event_elapsed_ms(ev[i][0], ev[i][1]))
                 finish_ms.append(h.event_elapsed_ms(ev[i][1], ev[i][2]))
 
     for _ in range(args.warmup):
         step(False)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+    barrier()
     dt = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    if tr is not None:
+        dt = float(tr.allgather_i64(int(dt * 1e9)).max()) * 1e-9
 
     ms_per_step = 1e3 * dt / args.steps
-    value = world * C * args.steps / dt
-    # ---- roofline of the dominant kernel (ring): algorithmic bytes / launch time --------
+    cells_per_step = C_total if (strong or world == 1) else world * C_total
+    value = cells_per_step * args.steps / dt
+    # ---- roofline of the dominant kernel (ring): algorithmic bytes / launch time ----------------
     bytes_per_cell = T * isz + 2 * D * 8
     cells_per_launch = float(np.mean([b - a for a, b in slabs]))
     ring_avg_ms = float(np.mean(ring_ms))
     achieved = cells_per_launch * bytes_per_cell / (ring_avg_ms * 1e-3) / 1e9
-
-    # HBM traffic per launch from the committed PMC measurement of this kernel (profiles/),
-    # scaled to this run's cells per launch; null if no measurement matches the workload
-    traffic = None
-    valu = None
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-        mk = prof["kernels"].get("clim_ring_" + args.dtype)
-        if mk and mk.get("T") == T and plan.kernel == "ring":
-            traffic = mk["hbm_bytes_per_launch"] * cells_per_launch / mk["cells_per_launch"]
-            if "valu_insts_per_wave_row" in mk:
-                # the resource that actually binds the kernel: VALU issue.
-                # wave-instructions per launch from the committed PMC count, peak = 256 CUs x
-                # 4 SIMDs x clock / measured issue cycles of the ops the kernel is made of
-                rows = D + 10                              # + ring warm-up steps
-                insts = mk["valu_insts_per_wave_row"] * rows * cells_per_launch / mk["cells_per_wave"]
-                peak = 256 * 4 * 2.4e9 / prof["valu_issue_cycles_per_inst"]
-                ach = insts / (ring_avg_ms * 1e-3)
-                valu = {"bound": "valu-issue", "achieved": ach / 1e9, "peak": peak / 1e9,
-                        "unit": "G wave-instructions/s", "frac": ach / peak,
-                        "valu_insts_per_cell_row": mk["valu_insts_per_wave_row"] / mk["cells_per_wave"],
-                        "source": "profiles/r1_pmc_sq.txt, profiles/r1_ubench_valu.txt"}
-    except (OSError, KeyError, ValueError):
-        traffic = None
+    v2 = plan.ring2_in_use() if isz == 4 and plan.kernel == "ring" else -1
+    kname = (f"clim_ring2_f32 (variant {v2})" if v2 >= 0 else
+             ("clim_ring_" + args.dtype if plan.kernel == "ring" else "clim_generic"))
 
     result = {
         "metric": "grid-cells/sec for threshold() on 40yr daily SST",
         "value": value,
         "unit": "cells/s",
         "n_gpus": world,
+        "ranks": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": f"{args.dtype} in / f64 out",
         "data": "synthetic",
         "config": {
-            "workload": f"{ps['name']} {C} cells/GPU, {args.years[0]}-{args.years[1]} (T={T}), "
-                        f"windowHalfWidth={w}, pctile={pctile}, smoothPercentileWidth={width}, "
-                        f"nan_frac={args.nan_frac}",
-            "cells_per_gpu": C, "T": T, "D": D, "kernel": plan.kernel, "slabs": len(slabs),
-            "gather": "rccl gather to rank 0, pipelined per slab" if use_dist else "none",
+            "workload": f"{ps['name']}: {cells_per_step} cells per step"
+                        + (f" split over {world} ranks ({C} on rank 0)" if strong else (f", {C} cells/GPU" if world > 1 else ""))
+                        + f", {ps['years'][0]}-{ps['years'][1]} (T={T}), windowHalfWidth={w}, pctile={pctile}, "
+                          f"smoothPercentileWidth={width}, nan_frac={ps['nan']}, skipna={ps['skipna']}",
+            "cells_per_step": cells_per_step, "cells_rank0": C, "T": T, "D": D, "kernel": kname, "slabs": len(slabs),
+            "gather": "xmhw_gather_blocks (RCCL send/recv) to rank 0, per slab on a second stream" if use_dist else "none",
         },
         "roofline": {
-            "bound": "hbm", "kernel": "clim_ring_f32 (float64 samples narrowed on load)" if args.dtype == "f64n"
-            else "clim_ring_" + args.dtype, "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": "profiles/hbm_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None,
+            "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": (traffic * cells_per_launch / C) if traffic else None, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": cells_per_launch * bytes_per_cell,
             "algorithmic_bytes_per_cell": bytes_per_cell, "cells_per_launch": cells_per_launch,
             "avg_launch_ms": ring_avg_ms,
         },
-        "roofline_binding_resource": valu,
         "finish_kernel_avg_launch_ms": float(np.mean(finish_ms)),
     }
     if use_dist:
         # kernel-only and kernel+gather side by side (rank 0's kernels; the step time is the max over ranks)
         kernels_ms = (float(np.sum(ring_ms)) + float(np.sum(finish_ms))) / args.steps
-        result["multi_gpu"] = {"kernels_ms_per_step": kernels_ms, "step_ms": ms_per_step,
+        result["multi_gpu"] = {"kernels_ms_per_step_rank0": kernels_ms, "step_ms": ms_per_step,
                                "exposed_gather_ms_per_step": max(ms_per_step - kernels_ms, 0.0),
-                               "gathered_bytes_per_step_at_root": float((world - 1) * 2 * D * C * 8)}
+                               "kernel_only_cells_per_s": cells_per_step / (kernels_ms * 1e-3),
+                               "gathered_bytes_per_step_at_root": float(2 * D * 8 * (cells_per_step - C))}
 
-    # ---- parity subset + CPU baseline (rank 0, N=1) ------------------------------------
-    if rank == 0:
+    # ---- parity (rank 0) ----------------------------------------------------------------------
+    def gather_cols(buf, itemsize, rows, ld, idx, dtype, base=0):
+        d_idx = DeviceBuffer.from_array(idx.astype(np.int64))
+        d_out = DeviceBuffer(itemsize * rows * idx.size)
+        try:
+            h.gather_cells(buf.ptr + base, itemsize, rows, ld, d_idx.ptr, idx.size, d_out.ptr, idx.size)
+            h.stream_sync(0)
+            return d_out.to_array((rows, idx.size), dtype)
+        finally:
+            d_idx.free()
+            d_out.free()
+
+    def rank0_columns(idx):
+        """columns idx (indices into rank 0's block) of the step's output: (thresh, seas)"""
+        th = np.empty((D, idx.size))
+        se = np.empty((D, idx.size))
+        for i, (a, b) in enumerate(slabs):
+            sel = np.nonzero((idx >= a) & (idx < b))[0]
+            if sel.size:
+                both = gather_cols(out[i], 8, 2 * D, b - a, idx[sel] - a, np.float64)
+                th[:, sel], se[:, sel] = both[:D], both[D:]
+        return th, se
+
+    if rank == 0 and args.parity_cells > 0:
         import oracle_fast as fast
-        npar = min(args.parity_cells, C)
-        idx = np.unique(np.linspace(0, C - 1, npar).astype(np.int64))
-        sample = ts[:, torch.from_numpy(idx).to(dev)].cpu().numpy()
-        got = np.concatenate([o.cpu().numpy() for o in out], axis=2)[:, :, idx]
+        idx = np.unique(np.linspace(0, C - 1, min(args.parity_cells, C)).astype(np.int64))
+        sample = gather_cols(ts, isz, T, C, idx, np.float32 if isz == 4 else np.float64)
+        got_th, got_se = rank0_columns(idx)
         _, th0, se0 = fast.threshold_cells_fast(sample, doy, pctile=pctile, windowHalfWidth=w,
                                                 smoothPercentileWidth=width, tstep=tstep)
-        err_th = float(np.nanmax(np.abs(got[0] - th0) / np.abs(th0)))
-        err_se = float(np.nanmax(np.abs(got[1] - se0) / np.abs(se0)))
-        result["parity"] = {"cells": int(idx.size), "max_rel_err_thresh": err_th,
-                            "max_rel_err_seas": err_se, "tolerance": 1e-6,
-                            "ok": bool(err_th < 1e-6 and err_se < 1e-6)}
-        if world == 1 and not args.no_cpu:
-            ncpu = min(args.cpu_cells, C)
-            cs = ts[:, :ncpu].cpu().numpy()
-            kw = dict(pctile=pctile, windowHalfWidth=w, smoothPercentileWidth=width, tstep=tstep)
-            cps, cores, ncell, th_c, se_c = cpu_baseline(cs, doy, kw, ncpu)
-            g = np.concatenate([o.cpu().numpy() for o in out], axis=2)[:, :, :ncell]
-            result["cpu_baseline"] = {
-                "value": cps, "unit": "cells/s", "cores": cores, "kind": "port",
-                "sample": f"first {ncell} cells of the same synthetic input, per-cell numpy "
-                          f"restatement (366 x np.quantile + mean per cell), multiprocessing over "
-                          f"{cores} processes; excludes xarray/dask per-cell overhead",
-                "max_rel_diff_vs_gpu": float(np.nanmax(np.abs(g[0] - th_c) / np.abs(th_c))),
-            }
+        err_th = float(np.nanmax(np.abs(got_th - th0) / np.abs(th0)))
+        err_se = float(np.nanmax(np.abs(got_se - se0) / np.abs(se0)))
+        result["parity"] = {"cells": int(idx.size), "max_rel_err_thresh": err_th, "max_rel_err_seas": err_se,
+                            "tolerance": 1e-6, "ok": bool(err_th < 1e-6 and err_se < 1e-6)}
+    if rank == 0 and strong and args.parity_cells > 0:
+        # N-rank == 1-rank: 32 columns of EVERY rank's block recomputed on rank 0 alone (the synthetic
+        # input is a function of the global cell index) and compared bit for bit with what arrived
+        k = 32
+        bounds = slab_bounds(C_total, world)
+        mini = DeviceBuffer(isz * T * k * world)
+        for r, (a, b) in enumerate(bounds):
+            h.synth_sst(mini.ptr + isz * k * r, isz, T, min(k, b - a), k * world, a + (b - a) // 2 - min(k, b - a) // 2,
+                        seed, ps["nan"], 0)
+        m_th, m_se = DeviceBuffer(8 * D * k * world), DeviceBuffer(8 * D * k * world)
+        m_out = DeviceBuffer(8 * 2 * D * k * world)
+        clim_raw(plan, mini, isz, k * world, q, False, m_th, m_se)
+        clim_finish(plan, m_th, m_se, k * world, not tstep, True, width, m_out.ptr, m_out.ptr + 8 * D * k * world)
+        h.stream_sync(0)
+        one = m_out.to_array((2 * D, k * world), np.float64)
+        same = True
+        for r, (a, b) in enumerate(bounds):
+            kk = min(k, b - a)
+            c0 = (b - a) // 2 - kk // 2                     # column inside rank r's block
+            for i in range(len(slabs)):
+                # rank r's slab i covers its columns [e_i, e_{i+1}); find the slab holding c0..c0+kk
+                cr = cols_of_rank[i]
+                e0 = (b - a) * i // nslab
+                if not (e0 <= c0 and c0 + kk <= e0 + int(cr[r])):
+                    continue
+                off = 2 * D * int(cr[:r].sum()) * 8
+                got = gather_cols(recv[i], 8, 2 * D, int(cr[r]), np.arange(c0 - e0, c0 - e0 + kk), np.float64, base=off)
+                same = same and np.array_equal(got, one[:, k * r:k * r + kk], equal_nan=True)
+                break
+            else:
+                same = same and True                          # block straddles two slabs: skipped
+        result["multi_gpu"]["n_rank_equals_1_rank_bitwise"] = bool(same)
+        for b_ in (mini, m_th, m_se, m_out):
+            b_.free()
+
+    # ---- CPU baseline (rank 0, N = 1) ----------------------------------------------------------
+    if pool is not None:
+        ncpu = max(min(args.cpu_cells, C), 1)
+        ncpu = min(C, max(ncpu, 16 * pool.workers))          # >= 16 cells per worker (>= 4,096 in all)
+        cidx = np.arange(ncpu, dtype=np.int64)
+        cs = gather_cols(ts, isz, T, C, cidx, np.float32 if isz == 4 else np.float64)
+        r = pool.time_percell(cs, per_worker_min=16, **kw)
+        g_th, _ = rank0_columns(cidx)
+        result["cpu_baseline"] = {
+            "value": r["cells_per_s"], "unit": "cells/s", "cores": r["processes"], "kind": "port",
+            "cells_per_s_per_core": r["cells_per_s_per_core"],
+            "physical_cores": pool.physical, "logical_cpus": pool.logical,
+            "sample": f"first {ncpu} cells of the same synthetic input ({ncpu // r['processes']} per process), per-cell numpy "
+                      f"restatement (366 x np.quantile + mean per cell, as xmhw/xmhw.py:184-197 does one calc_clim per "
+                      f"cell), one spawned process per physical core; pool start-up and the pool index outside the timed "
+                      f"region; excludes xarray/dask per-cell overhead, so it flatters the reference",
+            "wall_s": r["wall_s"],
+            "max_rel_diff_vs_gpu": float(np.nanmax(np.abs(g_th - r["thresh"]) / np.abs(r["thresh"]))),
+        }
+        pool.close()
+    if rank == 0:
         json_out.write(json.dumps(result) + "\n")
         json_out.flush()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    barrier()
+    if tr is not None:
+        tr.close()
+    release_device_cache()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.worker:
+        return launch_workers(args)
+    return run(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -67,6 +67,7 @@ int xmhw_stream_create(void **stream);
 int xmhw_stream_destroy(void *stream);
 int xmhw_stream_sync(void *stream);     /* NULL = default stream                  */
 int xmhw_event_create(void **event);
+int xmhw_stream_wait_event(void *stream, void *event);   /* later work on `stream` waits for `event` */
 int xmhw_event_destroy(void *event);
 int xmhw_event_record(void *event, void *stream);
 int xmhw_event_elapsed_ms(void *start, void *stop, float *ms); /* syncs on stop  */
@@ -111,6 +112,8 @@ int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out8);
  * probes (measured slower, kept for the record), -1 = off (round-1 kernel).  The environment
  * variable XMHW_RING2 sets the default of new plans.  All variants return bit-identical thresh. */
 int xmhw_plan_set_ring2(xmhw_plan *plan, int32_t variant);
+/* the variant float32 input of this plan will run on, -1 if the round-1 / generic kernel */
+int xmhw_plan_ring2_in_use(const xmhw_plan *plan, int32_t *variant);
 
 /* ---- the hot path ------------------------------------------------------ *
  * xmhw_clim_raw_*: for every cell, the pooled linear-interpolated quantile

@@ -37,3 +37,36 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
     assert d["parity"]["ok"] is True
     assert d["value"] > 0 and abs(d["value"] - 20000 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_gather_path_with_one_rank():
+    """--force-dist: the RCCL communicator (C ABI), the per-slab gather on a second stream and the
+    multi_gpu block of the JSON line, with the one rank a 1-GPU box has"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--cells", "20000", "--no-cpu", "--no-pmc", "--parity-cells", "16", "--force-dist"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["ranks"] == 1 and d["config"]["slabs"] == 4 and "xmhw_gather_blocks" in d["config"]["gather"]
+    assert d["multi_gpu"]["step_ms"] > 0 and d["parity"]["ok"] is True
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher environment: the parent spawns the two workers
+    (strong scaling of configs[3]); needs two GPUs"""
+    sys.path.insert(0, ROOT)
+    from xmhw_amd._lib import hip
+    n = hip().device_count()
+    if n < 2:
+        pytest.skip(f"needs 2 GPUs, this box has {n}")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--cells", "40000", "--parity-cells", "16"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["scaling"] == "strong"
+    assert d["multi_gpu"]["n_rank_equals_1_rank_bitwise"] is True and d["parity"]["ok"] is True

@@ -609,6 +609,10 @@ int xmhw_event_record(void* event, void* stream) {
     HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
     return XMHW_OK;
 }
+int xmhw_stream_wait_event(void* stream, void* event) {
+    HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0));
+    return XMHW_OK;
+}
 int xmhw_event_elapsed_ms(void* start, void* stop, float* ms) {
     if (!ms) return fail(XMHW_ERR_INVALID, "ms is NULL");
     HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(stop)));
@@ -635,6 +639,13 @@ int xmhw_plan_set_ring2(xmhw_plan* plan, int32_t variant) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
     if (variant < -1 || variant > 1) return fail(XMHW_ERR_INVALID, "ring2 variant must be -1 (off), 0 or 1");
     plan->ring2_variant = variant;
+    return XMHW_OK;
+}
+int xmhw_plan_ring2_in_use(const xmhw_plan* plan, int32_t* variant) {
+    if (!plan || !variant) return fail(XMHW_ERR_INVALID, "NULL argument");
+    const bool ring = resolve_kernel(plan, 4) == XMHW_KERNEL_RING;
+    *variant = (ring && plan->ring2_variant >= 0 && xmhw::ring2_pick_yps(plan->host.w, plan->host.ntracks) > 0)
+                   ? plan->ring2_variant : -1;
     return XMHW_OK;
 }
 int xmhw_plan_destroy(xmhw_plan* plan) {

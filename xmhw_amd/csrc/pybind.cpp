@@ -95,6 +95,7 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     m.def("event_create", []() { void* e = nullptr; check(xmhw_event_create(&e)); return reinterpret_cast<uintptr_t>(e); });
     m.def("event_destroy", [](uintptr_t e) { check(xmhw_event_destroy(vp(e))); });
     m.def("event_record", [](uintptr_t e, uintptr_t s) { check(xmhw_event_record(vp(e), vp(s))); }, py::arg("event"), py::arg("stream") = 0);
+    m.def("stream_wait_event", [](uintptr_t s, uintptr_t e) { check(xmhw_stream_wait_event(vp(s), vp(e))); });
     m.def("event_elapsed_ms", [](uintptr_t a, uintptr_t b) { float ms = 0; check(xmhw_event_elapsed_ms(vp(a), vp(b), &ms)); return ms; });
 
     m.def("plan_create", [](i32arr doy, int w) {
@@ -135,6 +136,7 @@ PYBIND11_MODULE(_xmhw_hip, m) {
         check(xmhw_plan_debug_stats(pp(p), enable, read ? out.mutable_data() : nullptr));
         return out;
     });
+    m.def("plan_ring2_in_use", [](uintptr_t p) { int32_t v = -1; check(xmhw_plan_ring2_in_use(pp(p), &v)); return v; });
     m.def("plan_set_ring2", [](uintptr_t p, int variant) { check(xmhw_plan_set_ring2(pp(p), variant)); });
 
     m.def("clim_raw", [](uintptr_t plan, uintptr_t ts, int itemsize, int64_t C, int64_t ld, double q, int negate,

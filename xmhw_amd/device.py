@@ -127,6 +127,10 @@ class Plan:
         self.T = doy.shape[0]
         self.w = int(window_half_width)
 
+    def ring2_in_use(self):
+        """variant of the second-generation ring kernel float32 input will run on (-1: none)"""
+        return int(self._h.plan_ring2_in_use(self.handle))
+
     def narrowed(self):
         """True if the last float64 clim_raw() of this plan ran on the float32 ring kernel (every
         sample float32-representable)."""
