@@ -409,7 +409,8 @@ def run(args):
         g_th, _ = rank0_columns(cidx)
         result["cpu_baseline"] = {
             "value": r["cells_per_s"], "unit": "cells/s", "cores": r["processes"], "kind": "port",
-            "cells_per_s_per_core": r["cells_per_s_per_core"],
+            "cells_per_s_per_core": r["cells_per_s_per_core"], "cells_per_cpu_second": r["cells_per_cpu_s"],
+            "cpu_seconds": r["cpu_s"], "summed_worker_wall_s": r["busy_s"], "cgroup_cpu_quota": r["cpu_quota"],
             "physical_cores": pool.physical, "logical_cpus": pool.logical,
             "sample": f"first {ncpu} cells of the same synthetic input ({ncpu // r['processes']} per process), per-cell numpy "
                       f"restatement (366 x np.quantile + mean per cell, as xmhw/xmhw.py:184-197 does one calc_clim per "

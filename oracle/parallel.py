@@ -48,6 +48,24 @@ def physical_cores():
     return logical, logical
 
 
+def cpu_quota():
+    """CPUs' worth of time the cgroup grants this process (cpu.max), None if unlimited / unknown"""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] == "max":
+                    return None
+                return float(txt[0]) / float(txt[1])
+            q = float(txt[0])
+            if q <= 0:
+                return None
+            return q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
 def _init(oracle_dir, doy, w):
     import sys
     if oracle_dir not in sys.path:
@@ -73,9 +91,9 @@ def _percell_job(args):
     finally:
         del x
         shm.close()
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     _, th, se = opc.threshold_cells_percell(cols, _STATE["doy"], pools=_STATE["pools"], **kw)
-    return a, b, th, se, time.perf_counter() - t0
+    return a, b, th, se, (time.perf_counter() - t0, time.process_time() - c0)
 
 
 def _fast_job(args):
@@ -88,7 +106,7 @@ def _fast_job(args):
         del x
         shm.close()
     _, th, se = fast.threshold_cells_fast(cols, _STATE["doy"], **kw)
-    return a, b, th, se, 0.0
+    return a, b, th, se, (0.0, 0.0)
 
 
 def _noop(_):
@@ -155,12 +173,13 @@ class OraclePool:
         D = res[0][2].shape[0]
         th = np.empty((D, C))
         se = np.empty((D, C))
-        busy = 0.0
+        busy = cpu = 0.0
         for a, b, t, s, dt in res:
             th[:, a:b] = t
             se[:, a:b] = s
-            busy += dt
-        return th, se, wall, busy
+            busy += dt[0]
+            cpu += dt[1]
+        return th, se, wall, (busy, cpu)
 
     def blocks(self, C, per_worker_min=16):
         n = max(1, min(self.workers, C // max(1, per_worker_min)))
@@ -181,7 +200,10 @@ class OraclePool:
         in-worker compute seconds, and the results."""
         C = sample.shape[1]
         blocks = self.blocks(C, per_worker_min)
-        th, se, wall, busy = self._run(_percell_job, sample, blocks, kw)
-        return {"cells": C, "wall_s": wall, "busy_s": busy, "processes": len(blocks),
+        th, se, wall, (busy, cpu) = self._run(_percell_job, sample, blocks, kw)
+        # busy = summed in-worker wall time, cpu = summed in-worker CPU time: cpu << busy means the
+        # processes did not get a core each (a cgroup CPU quota, other tenants on the box)
+        return {"cells": C, "wall_s": wall, "busy_s": busy, "cpu_s": cpu, "processes": len(blocks),
                 "cells_per_s": C / wall, "cells_per_s_per_core": C / busy if busy > 0 else float("nan"),
+                "cells_per_cpu_s": C / cpu if cpu > 0 else float("nan"), "cpu_quota": cpu_quota(),
                 "thresh": th, "seas": se}
