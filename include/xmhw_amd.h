@@ -63,6 +63,22 @@ int xmhw_memcpy2d_h2d(void *dev_dst, size_t dpitch, const void *host_src, size_t
 int xmhw_memcpy2d_d2h(void *host_dst, size_t dpitch, const void *dev_src, size_t spitch,
                       size_t width_bytes, size_t height, void *stream);
 int xmhw_memset(void *dev_dst, int value, size_t bytes, void *stream);
+/* ---- ingest: file bytes -> samples on the device ------------------------ *
+ * The reference leaves reading and CF decoding to xarray (docs/gettingstarted.rst:30-33).  Here the
+ * RAW bytes of a column slab cross PCIe (pinned staging: xmhw_host_alloc, asynchronous pitched
+ * copy) and are decoded in HBM: byte order (netCDF classic is big-endian), CF packing
+ * `raw * scale_factor + add_offset` in the arithmetic of the decoded type (float32 result: two
+ * float32 roundings, as xarray computes it for float32 attributes), `_FillValue` -> NaN.
+ * raw_itemsize 2 = int16, 4 = float32, 8 = float64; pairs: int16->float32/float64,
+ * float32->float32, float64->float64.                                                          */
+int xmhw_host_alloc(void **host_ptr, size_t bytes);        /* page-locked host memory */
+int xmhw_host_free(void *host_ptr);
+int xmhw_memcpy2d_h2d_async(void *dev_dst, size_t dpitch, const void *host_src, size_t spitch,
+                            size_t width_bytes, size_t height, void *stream);
+int xmhw_memcpy_d2h_async(void *host_dst, const void *dev_src, size_t bytes, void *stream);
+int xmhw_decode(const void *raw_dev, int raw_itemsize, int big_endian, int64_t rows, int64_t cols,
+                int64_t ld_raw, void *out_dev, int out_itemsize, int64_t ld_out, int has_scale,
+                double scale_factor, double add_offset, int has_fill, double fill_value, void *stream);
 int xmhw_stream_create(void **stream);
 int xmhw_stream_destroy(void *stream);
 int xmhw_stream_sync(void *stream);     /* NULL = default stream                  */

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""End-to-end time of threshold() on a large netCDF classic file that is memory-mapped from /dev/shm
+(page cache speed: the disk is not what is being measured).
+   python tools/time_ingest.py [--kind f32|i16] [--lat 720 --lon 1440 --years 1982 2021] [--keep]
+The file is synthesised on the DEVICE (counter-based SST of SURVEY 8d) and written once; then
+open_series() + threshold() is timed twice (the second call reuses cached device buffers).
+Prints one JSON line: file GB, seconds, GB/s of file bytes and of float32-equivalent samples."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kind", default="f32", choices=["f32", "i16"])
+    ap.add_argument("--lat", type=int, default=720)
+    ap.add_argument("--lon", type=int, default=1440)
+    ap.add_argument("--years", type=int, nargs=2, default=[1982, 2021])
+    ap.add_argument("--dir", default="/dev/shm")
+    ap.add_argument("--keep", action="store_true")
+    args = ap.parse_args()
+    import xmhw_amd
+    from xmhw_amd import ingest, netcdf3
+    from xmhw_amd.device import DeviceBuffer, hip
+    h = hip()
+    t = np.arange(f"{args.years[0]}-01-01", f"{args.years[1] + 1}-01-01", dtype="datetime64[D]")
+    T, N = t.shape[0], args.lat * args.lon
+    path = os.path.join(args.dir, f"xmhw_ingest_{args.kind}_{args.lat}x{args.lon}_{T}.nc")
+    isz = 4 if args.kind == "f32" else 2
+    t0 = time.perf_counter()
+    # header through the writer (a 1-step file), then the data written in place through a memmap
+    vat = {"units": "degC"} if args.kind == "f32" else {"scale_factor": np.float32(0.01), "add_offset": np.float32(15.0),
+                                                       "_FillValue": np.int16(-32768)}
+    dt = ">f4" if args.kind == "f32" else ">i2"
+    netcdf3.write_classic(path, {"time": T, "lat": args.lat, "lon": args.lon}, {
+        "time": (("time",), (t - t[0]).astype(np.float64), {"units": f"days since {args.years[0]}-01-01", "calendar": "standard"}),
+        "lat": (("lat",), np.linspace(-89.875, 89.875, args.lat).astype(np.float32), {}),
+        "lon": (("lon",), np.linspace(0.125, 359.875, args.lon).astype(np.float32), {}),
+        "sst": (("time", "lat", "lon"), np.zeros((1, args.lat, args.lon), dtype=dt), vat)})
+    f = netcdf3.File(path)
+    begin = f.variables["sst"].data.__array_interface__["data"][0] - np.frombuffer(f._mm, dtype=np.uint8).__array_interface__["data"][0]
+    f.close()
+    with open(path, "r+b") as fh:
+        fh.truncate(begin + isz * T * N)
+    mm = np.memmap(path, dtype=dt, mode="r+", offset=begin, shape=(T, N))
+    rows = max(1, (2 << 30) // (4 * N))
+    buf = DeviceBuffer(4 * rows * N)
+    land = np.zeros(N, dtype=bool)
+    land[:: 6] = True                              # a sixth of the cells is land
+    for r0 in range(0, T, rows):
+        r1 = min(T, r0 + rows)
+        # the generator is a function of (cell, t): generate rows r0..r1 of all cells
+        h.synth_sst_rows(buf.ptr, r0, r1 - r0, N, 20260102) if hasattr(h, "synth_sst_rows") else None
+        a = buf.to_array((r1 - r0, N), np.float32) if hasattr(h, "synth_sst_rows") else \
+            (15 + 5 * np.sin(2 * np.pi * (np.arange(r0, r1)[:, None] - (np.arange(N) % 365)[None, :]) / 365.25)
+             + np.random.default_rng(r0).normal(size=(r1 - r0, N)).astype(np.float32)).astype(np.float32)
+        if args.kind == "f32":
+            a[:, land] = np.nan
+            mm[r0:r1] = a
+        else:
+            q = np.round((a - 15.0) / 0.01).astype(np.int16)
+            q[:, land] = -32768
+            mm[r0:r1] = q
+    mm.flush()
+    del mm
+    buf.free()
+    t_write = time.perf_counter() - t0
+    fbytes = os.path.getsize(path)
+    out = {"file": path, "kind": args.kind, "file_GB": fbytes / 1e9, "T": T, "cells": N, "write_s": t_write}
+    for k in (1, 2):
+        t0 = time.perf_counter()
+        temp = ingest.open_series(path, "sst")
+        ds = xmhw_amd.threshold(temp)
+        dt_s = time.perf_counter() - t0
+        out[f"threshold_s_{k}"] = dt_s
+        out[f"file_GBps_{k}"] = fbytes / 1e9 / dt_s
+        out[f"float32_equiv_GBps_{k}"] = 4 * T * N / 1e9 / dt_s
+        out["ocean_cells"] = int((~np.isnan(ds["thresh"][0])).sum())
+        del ds, temp
+    print(json.dumps(out))
+    if not args.keep:
+        os.remove(path)
+
+
+if __name__ == "__main__":
+    main()

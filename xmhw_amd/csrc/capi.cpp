@@ -574,6 +574,45 @@ int xmhw_memcpy2d_h2d(void* dst, size_t dpitch, const void* src, size_t spitch, 
     HIP_TRY(hipStreamSynchronize(st));
     return XMHW_OK;
 }
+int xmhw_host_alloc(void** host_ptr, size_t bytes) {
+    if (!host_ptr) return fail(XMHW_ERR_INVALID, "host_ptr is NULL");
+    *host_ptr = nullptr;
+    if (bytes == 0) return XMHW_OK;
+    hipError_t e = hipHostMalloc(host_ptr, bytes, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) return fail(XMHW_ERR_NOMEM, "hipHostMalloc: out of memory");
+    if (e != hipSuccess) return hip_fail(e, "hipHostMalloc");
+    return XMHW_OK;
+}
+int xmhw_host_free(void* host_ptr) {
+    if (host_ptr) HIP_TRY(hipHostFree(host_ptr));
+    return XMHW_OK;
+}
+int xmhw_memcpy2d_h2d_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+                            void* stream) {
+    if (width == 0 || height == 0) return XMHW_OK;
+    if (!dst || !src || dpitch < width || spitch < width) return fail(XMHW_ERR_INVALID, "bad pointer/pitch");
+    HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    return XMHW_OK;
+}
+int xmhw_memcpy_d2h_async(void* dst, const void* src, size_t bytes, void* stream) {
+    if (bytes == 0) return XMHW_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    return XMHW_OK;
+}
+int xmhw_decode(const void* raw_dev, int raw_itemsize, int big_endian, int64_t rows, int64_t cols, int64_t ld_raw,
+                void* out_dev, int out_itemsize, int64_t ld_out, int has_scale, double scale_factor, double add_offset,
+                int has_fill, double fill_value, void* stream) {
+    if (rows < 0 || cols < 0 || ld_raw < cols || ld_out < cols) return fail(XMHW_ERR_INVALID, "bad rows/cols/ld");
+    if (rows == 0 || cols == 0) return XMHW_OK;
+    if (!raw_dev || !out_dev) return fail(XMHW_ERR_INVALID, "NULL device buffer");
+    hipError_t e = xmhw::launch_decode(raw_dev, raw_itemsize, big_endian, rows, cols, ld_raw, out_dev, out_itemsize, ld_out,
+                                       scale_factor, add_offset, has_scale, has_fill, fill_value,
+                                       static_cast<hipStream_t>(stream));
+    if (e == hipErrorInvalidValue)
+        return fail(XMHW_ERR_UNSUPPORTED, "decode: stored/decoded type pair not supported (int16->f32/f64, f32->f32, f64->f64)");
+    if (e != hipSuccess) return hip_fail(e, "decode launch");
+    return XMHW_OK;
+}
 int xmhw_memset(void* dst, int value, size_t bytes, void* stream) {
     if (bytes == 0) return XMHW_OK;
     HIP_TRY(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)));

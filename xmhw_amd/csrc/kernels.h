@@ -113,6 +113,12 @@ hipError_t launch_event_intermediate(const T* ts, int64_t Tn, int64_t C, int64_t
                                      const int32_t* events, int64_t ldo, double* out, int64_t ldv, uint8_t* dur,
                                      hipStream_t stream);
 
+// file bytes -> samples (kernels_ingest.hip): raw_type = item size of the stored type (2 int16, 4 float32,
+// 8 float64), swap = the file is big-endian, optional scale/offset (CF packing) and fill value -> NaN
+hipError_t launch_decode(const void* in, int raw_type, int swap, int64_t rows, int64_t cols, int64_t ld_in, void* out,
+                         int out_itemsize, int64_t ld_out, double scale, double offset, int has_scale, int has_fill,
+                         double fill, hipStream_t stream);
+
 template <typename T>
 hipError_t launch_synth(T* ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
                         double nan_frac, hipStream_t stream);

@@ -69,17 +69,20 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     m.def("memcpy2d_h2d", [](uintptr_t dst, py::buffer src, int64_t col0, int64_t ncols, uintptr_t stream) {
         // columns [col0, col0 + ncols) of a C-contiguous 2-D host array -> dense (rows, ncols) device array
         py::buffer_info bi = src.request();
-        if (bi.ndim != 2 || bi.strides[1] != bi.itemsize || bi.strides[0] != bi.itemsize * bi.shape[1])
-            throw InvalidError("memcpy2d_h2d needs a C-contiguous 2-D array");
+        // rows must be contiguous; the row pitch is free (record variables of a netCDF classic file are
+        // interleaved with the other record variables: rows are one record apart)
+        if (bi.ndim != 2 || bi.strides[1] != bi.itemsize || bi.strides[0] < bi.itemsize * bi.shape[1])
+            throw InvalidError("memcpy2d_h2d needs a 2-D array with contiguous rows");
         if (col0 < 0 || ncols < 0 || col0 + ncols > bi.shape[1]) throw InvalidError("column range outside the array");
         const size_t isz = static_cast<size_t>(bi.itemsize);
+        const size_t spitch = static_cast<size_t>(bi.strides[0]);
         py::gil_scoped_release r;
         check(xmhw_memcpy2d_h2d(vp(dst), isz * static_cast<size_t>(ncols), static_cast<const char*>(bi.ptr) + isz * col0,
-                                isz * static_cast<size_t>(bi.shape[1]), isz * static_cast<size_t>(ncols),
-                                static_cast<size_t>(bi.shape[0]), vp(stream)));
+                                spitch, isz * static_cast<size_t>(ncols), static_cast<size_t>(bi.shape[0]), vp(stream)));
     }, py::arg("dst"), py::arg("src"), py::arg("col0"), py::arg("ncols"), py::arg("stream") = 0);
     m.def("memcpy_d2h", [](py::buffer dst, uintptr_t src, uintptr_t stream) {
         py::buffer_info bi = dst.request(true);
+        py::gil_scoped_release r;        // a large copy must not stall the thread that feeds the next slab
         check(xmhw_memcpy_d2h(bi.ptr, vp(src), static_cast<size_t>(bi.size) * bi.itemsize, vp(stream)));
     }, py::arg("dst"), py::arg("src"), py::arg("stream") = 0);
     m.def("memcpy_d2h_bytes", [](py::buffer dst, uintptr_t src, size_t nbytes, uintptr_t stream) {
@@ -391,6 +394,28 @@ PYBIND11_MODULE(_xmhw_hip, m) {
                                 isz * static_cast<size_t>(ncols), isz * static_cast<size_t>(ncols),
                                 static_cast<size_t>(bi.shape[0]), vp(stream)));
     }, py::arg("dst"), py::arg("col0"), py::arg("ncols"), py::arg("src"), py::arg("stream") = 0);
+
+    m.def("decode", [](uintptr_t raw, int raw_itemsize, int big_endian, int64_t rows, int64_t cols, int64_t ld_raw,
+                       uintptr_t out, int out_itemsize, int64_t ld_out, bool has_scale, double scale, double offset,
+                       bool has_fill, double fill, uintptr_t stream) {
+        check(xmhw_decode(vp(raw), raw_itemsize, big_endian, rows, cols, ld_raw, vp(out), out_itemsize, ld_out, has_scale,
+                          scale, offset, has_fill, fill, vp(stream)));
+    }, py::arg("raw"), py::arg("raw_itemsize"), py::arg("big_endian"), py::arg("rows"), py::arg("cols"), py::arg("ld_raw"),
+       py::arg("out"), py::arg("out_itemsize"), py::arg("ld_out"), py::arg("has_scale"), py::arg("scale"),
+       py::arg("offset"), py::arg("has_fill"), py::arg("fill"), py::arg("stream") = 0);
+    m.def("host_alloc", [](size_t n) { void* p = nullptr; check(xmhw_host_alloc(&p, n)); return reinterpret_cast<uintptr_t>(p); });
+    m.def("host_free", [](uintptr_t p) { check(xmhw_host_free(vp(p))); });
+    m.def("host_view", [](uintptr_t p, size_t nbytes) {
+        // a numpy uint8 view of page-locked memory obtained from host_alloc (the caller keeps it alive)
+        return py::array_t<uint8_t>({nbytes}, {1}, static_cast<uint8_t*>(vp(p)), py::none());
+    });
+    m.def("memcpy2d_h2d_async", [](uintptr_t dst, size_t dpitch, uintptr_t src, size_t spitch, size_t width, size_t height,
+                                   uintptr_t stream) {
+        check(xmhw_memcpy2d_h2d_async(vp(dst), dpitch, vp(src), spitch, width, height, vp(stream)));
+    });
+    m.def("memcpy_d2h_async", [](uintptr_t dst, uintptr_t src, size_t bytes, uintptr_t stream) {
+        check(xmhw_memcpy_d2h_async(vp(dst), vp(src), bytes, vp(stream)));
+    });
 
     m.def("synth_sst", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
                           double nan_frac, uintptr_t stream) {

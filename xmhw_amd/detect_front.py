@@ -241,8 +241,12 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
     survivor among all survivors, total number of survivors) - the climatology columns are taken at
     that offset - and the result covers the block only (keep has c1 - c0 entries, no error for an
     all-land block)."""
-    from .device import _grid_batch, compact_columns
-    stacked = np.ascontiguousarray(native_float(stacked))
+    from .device import _grid_batch, compact_columns, decode_on_host, device_itemsize, is_packed
+    if is_packed(stacked):
+        if intermediate:
+            stacked = decode_on_host(stacked)       # the per-step path compacts on the host anyway
+    else:
+        stacked = np.ascontiguousarray(native_float(stacked))
     T, N = stacked.shape
 
     def host_compact(a):
@@ -274,9 +278,10 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
     if seas.ndim != 2 or thresh.ndim != 2 or seas.shape[0] != thresh.shape[0]:
         raise XmhwException("seas and thresh must be (D, cells) arrays")
     D = thresh.shape[0]
-    _, _, _, rows = _check_inputs(np.zeros((T, 1), dtype=stacked.dtype), seas[:, :1], thresh[:, :1], doy, doys)
+    sample_dtype = stacked.decoded_dtype if is_packed(stacked) else stacked.dtype
+    _, _, _, rows = _check_inputs(np.zeros((T, 1), dtype=sample_dtype), seas[:, :1], thresh[:, :1], doy, doys)
     h = hip()
-    isz = stacked.dtype.itemsize
+    isz = device_itemsize(stacked)
     neg = int(bool(coldSpells))
     clim_bufs = []
     keeps, tables, counts_all = [], [], []

@@ -8,10 +8,48 @@ from .exception import XmhwException
 KERNELS = {"auto": 0, "ring": 1, "generic": 2}
 
 
+class PackedArray(np.ndarray):
+    """A view of file bytes (netCDF classic: big-endian float32/float64, or CF-packed int16) that is
+    decoded ON THE DEVICE: the array carries its decoding recipe through transposes / reshapes /
+    slices (xmhw_amd.ingest builds it).  ``decode`` = dict(scale, offset, fill, out) with
+    ``out`` the decoded dtype (float32 / float64); scale / fill may be None."""
+
+    def __new__(cls, array, decode):
+        obj = np.asarray(array).view(cls)
+        obj.decode = dict(decode)
+        return obj
+
+    def __array_finalize__(self, obj):
+        if obj is not None:
+            self.decode = getattr(obj, "decode", None)
+
+    @property
+    def decoded_dtype(self):
+        return np.dtype(self.decode["out"])
+
+
+def is_packed(a):
+    return isinstance(a, PackedArray) and a.decode is not None
+
+
+def decode_on_host(a):
+    """numpy restatement of the device decoding (tests, tiny inputs): xarray's CF decoding"""
+    d = a.decode
+    raw = np.asarray(a)
+    out = raw.astype(np.dtype(d["out"]))
+    if d.get("scale") is not None:
+        out = out * np.dtype(d["out"]).type(d["scale"]) + np.dtype(d["out"]).type(d.get("offset") or 0.0)
+    if d.get("fill") is not None:
+        out[raw == raw.dtype.type(d["fill"])] = np.nan
+    return out
+
+
 def native_float(a):
     """The array as native-endian float32 or float64 (what the kernels read): float32 / float64 of
     either byte order keep their width (netCDF-3 and some GRIB decoders hand over big-endian
     arrays), every other dtype becomes float64."""
+    if is_packed(a):
+        return a
     a = np.asarray(a)
     if a.dtype.kind == "f" and a.dtype.itemsize in (4, 8):
         return a if a.dtype.isnative else a.astype(a.dtype.newbyteorder("="))
@@ -232,22 +270,56 @@ def calc_clim_device(ts, doy, pctile, windowHalfWidth, smoothPercentile, smoothP
         plan.destroy()
 
 
-def compact_columns(stacked, lo, hi, anynans):
-    """land_check()'s dropna + compaction (xmhw/identify.py:520-525) for columns [lo, hi) of a
-    C-contiguous host (T, N) array, on the device: pitched upload, land_mask kernel, gather of the
-    surviving columns.  Returns (DeviceBuffer holding the dense (T, n_keep) array or None if
-    n_keep == 0, keep mask of the slab)."""
+def upload_columns(stacked, lo, hi):
+    """Columns [lo, hi) of a C-contiguous host (T, N) array as a dense device (T, n) array of the
+    DECODED dtype: a pitched upload of the raw bytes, then -- for file views (PackedArray: big-endian
+    and / or CF-packed samples) -- the decode kernel.  Returns (DeviceBuffer, itemsize)."""
     h = hip()
     T = stacked.shape[0]
     n = hi - lo
-    isz = stacked.dtype.itemsize
-    d_raw = DeviceBuffer(isz * T * n)
+    raw_isz = stacked.dtype.itemsize
+    d_raw = DeviceBuffer(raw_isz * T * n)
+    try:
+        if lo == 0 and hi == stacked.shape[1] and stacked.flags.c_contiguous:
+            h.memcpy_h2d(d_raw.ptr, np.asarray(stacked))
+        else:
+            h.memcpy2d_h2d(d_raw.ptr, np.asarray(stacked), lo, n)
+        if not is_packed(stacked):
+            out, d_raw = d_raw, None
+            return out, raw_isz
+        d = stacked.decode
+        out_isz = np.dtype(d["out"]).itemsize
+        big = stacked.dtype.byteorder == ">" or (stacked.dtype.byteorder == "=" and not np.little_endian)
+        kind = stacked.dtype.kind
+        if not ((kind == "i" and raw_isz == 2) or (kind == "f" and raw_isz in (4, 8))):
+            raise XmhwException(f"stored type {stacked.dtype} is not supported by the device decoder")
+        plain = (kind == "f" and not big and d.get("scale") is None and d.get("fill") is None and out_isz == raw_isz)
+        if plain:
+            out, d_raw = d_raw, None
+            return out, raw_isz
+        d_out = DeviceBuffer(out_isz * T * n)
+        try:
+            h.decode(d_raw.ptr, raw_isz, int(big), T, n, n, d_out.ptr, out_isz, n, d.get("scale") is not None,
+                     float(d.get("scale") or 1.0), float(d.get("offset") or 0.0), d.get("fill") is not None,
+                     float(d.get("fill") or 0.0))
+            h.stream_sync(0)
+            out, d_out = d_out, None
+            return out, out_isz
+        finally:
+            if d_out is not None:
+                d_out.free()
+    finally:
+        if d_raw is not None:
+            d_raw.free()
+
+
+def mask_compact(d_raw, isz, T, n, anynans):
+    """land_check()'s dropna + compaction (xmhw/identify.py:520-525) of a dense device (T, n) array:
+    land_mask kernel, gather of the surviving columns.  Consumes d_raw.  Returns (DeviceBuffer holding
+    the dense (T, n_keep) array or None if n_keep == 0, keep mask)."""
+    h = hip()
     d_mask = d_idx = d_out = None
     try:
-        if lo == 0 and hi == stacked.shape[1]:
-            h.memcpy_h2d(d_raw.ptr, stacked)
-        else:
-            h.memcpy2d_h2d(d_raw.ptr, stacked, lo, n)
         d_mask = DeviceBuffer(n)
         h.land_mask(d_raw.ptr, isz, T, n, n, int(bool(anynans)), d_mask.ptr)
         h.stream_sync(0)
@@ -270,6 +342,68 @@ def compact_columns(stacked, lo, hi, anynans):
                 b.free()
 
 
+def compact_columns(stacked, lo, hi, anynans):
+    """upload_columns() + mask_compact(): (DeviceBuffer or None, keep mask of the slab)."""
+    d_raw, isz = upload_columns(stacked, lo, hi)
+    return mask_compact(d_raw, isz, stacked.shape[0], hi - lo, anynans)
+
+
+def device_itemsize(stacked):
+    """item size of the samples the kernels will see for this host array"""
+    return stacked.decoded_dtype.itemsize if is_packed(stacked) else stacked.dtype.itemsize
+
+
+class SlabPrefetcher:
+    """Iterates over column slabs of a host array with the NEXT slab's upload (and decode) running in
+    a background thread while the caller computes on the current one: pageable pitched copies are
+    synchronous for the calling thread (about 54 GB/s on this platform), so overlap takes a second
+    thread, not a second stream; the bindings release the GIL during copies."""
+
+    def __init__(self, stacked, slabs):
+        import threading
+        self._stacked, self._slabs = stacked, list(slabs)
+        self._threading = threading
+        self._next = None
+        self._start(0)
+
+    def _start(self, i):
+        if i >= len(self._slabs):
+            self._next = None
+            return
+        box = {}
+        dev = hip().get_device()
+
+        def work():
+            try:
+                hip().set_device(dev)                      # the device is a per-thread setting
+                box["out"] = upload_columns(self._stacked, *self._slabs[i])
+            except BaseException as e:                     # noqa: BLE001 -- re-raised in the consumer
+                box["err"] = e
+
+        t = self._threading.Thread(target=work, daemon=True)
+        t.start()
+        self._next = (i, t, box)
+
+    def __iter__(self):
+        while self._next is not None:
+            i, t, box = self._next
+            t.join()
+            if "err" in box:
+                self._next = None
+                raise box["err"]
+            self._start(i + 1)
+            yield self._slabs[i], box["out"]
+
+    def close(self):
+        """free an upload that was prepared but never consumed"""
+        if self._next is not None:
+            _, t, box = self._next
+            t.join()
+            if "out" in box:
+                box["out"][0].free()
+            self._next = None
+
+
 def device_budget_bytes(fraction=0.6):
     """Working-set budget of the grid entry points: a fraction of the current device's HBM (a
     single slab - one contiguous upload - whenever the whole grid fits: 173 GB on an MI355X)."""
@@ -280,13 +414,19 @@ def device_budget_bytes(fraction=0.6):
         return 64 << 30
 
 
-def _grid_batch(stacked, max_batch_bytes, per_cell_extra=0):
-    """cells per slab so that raw + compacted copies (+ per-cell extras) stay below the budget"""
+def _grid_batch(stacked, max_batch_bytes, per_cell_extra=0, pipeline=True):
+    """cells per slab so that raw + decoded + compacted copies (+ per-cell extras) stay below the
+    budget; large inputs are cut into at least 8 slabs so that uploads overlap compute"""
     if max_batch_bytes is None:
         max_batch_bytes = device_budget_bytes()
     T, N = stacked.shape
-    per_cell = 2 * T * stacked.dtype.itemsize + per_cell_extra
-    return int(max(1, min(N, max_batch_bytes // max(per_cell, 1))))
+    per_cell = T * (stacked.dtype.itemsize + 2 * device_itemsize(stacked)) + per_cell_extra
+    if pipeline:
+        per_cell += T * stacked.dtype.itemsize            # the next slab's upload is resident too
+    cb = int(max(1, min(N, max_batch_bytes // max(per_cell, 1))))
+    if pipeline and T * N * stacked.dtype.itemsize >= (4 << 30):
+        cb = min(cb, -(-N // 8))
+    return cb
 
 
 def _grid_block_on_device(plan, stacked, c0, c1, anynans, pctile, coldSpells, feb29_fix, smooth, width):
@@ -353,17 +493,21 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
     ``device_block=True`` (sharded runs) leaves the result on the device: the third return value is
     a DeviceBuffer holding ONE dense (2D, c1 - c0) float64 block -- the D thresh rows, then the D seas
     rows, on the grid with NaN at the dropped cells -- ready for xmhw_gather_blocks; the fourth is None."""
-    if not (isinstance(stacked, np.ndarray) and stacked.dtype.kind == "f" and stacked.dtype.itemsize in (4, 8)
-            and stacked.dtype.isnative and stacked.flags.c_contiguous):
+    if is_packed(stacked):
+        if stacked.ndim != 2 or stacked.strides[1] != stacked.dtype.itemsize:
+            raise XmhwException("a file view must have contiguous rows (time, cells)")
+    elif not (isinstance(stacked, np.ndarray) and stacked.dtype.kind == "f" and stacked.dtype.itemsize in (4, 8)
+              and stacked.dtype.isnative and stacked.flags.c_contiguous):
         stacked = np.ascontiguousarray(native_float(stacked))       # (a memmap of floats passes through untouched)
     T, N = stacked.shape
     h = hip()
     plan = Plan(doy, windowHalfWidth, kernel=kernel, nchunks=nchunks, narrowing=narrowing)
     D = plan.D
-    isz = stacked.dtype.itemsize
+    isz = device_itemsize(stacked)
     feb29_fix = tstep is False
     finish = feb29_fix or smoothPercentile
     keeps, ths, ses = [], [], []
+    pre = None
     try:
         cb = _grid_batch(stacked, max_batch_bytes, per_cell_extra=4 * D * 8)
         c0, c1 = (0, N) if columns is None else (int(columns[0]), int(columns[1]))
@@ -373,11 +517,23 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
                                     f"({cb} columns do): use more ranks")
             return _grid_block_on_device(plan, stacked, c0, c1, anynans, pctile, coldSpells, feb29_fix,
                                          smoothPercentile, smoothPercentileWidth)
-        for lo in range(c0, c1, cb):
-            hi = min(c1, lo + cb)
-            d_ts, keep = compact_columns(stacked, lo, hi, anynans)
+        slabs = [(lo, min(c1, lo + cb)) for lo in range(c0, c1, cb)]
+        many = len(slabs) > 1
+        th = se = None
+        if many and scatter:
+            # results go straight to their columns of the full-width host arrays (pitched device-to-host copy)
+            th = np.empty((D, c1 - c0))
+            se = np.empty((D, c1 - c0))
+        # slab k+1 is uploaded (and decoded) by a second thread while slab k computes
+        pre = SlabPrefetcher(stacked, slabs)
+        for (lo, hi), (d_up, up_isz) in pre:
+            d_ts, keep = mask_compact(d_up, up_isz, T, hi - lo, anynans)
             keeps.append(keep)
+            w = hi - lo
             if d_ts is None:
+                if th is not None:
+                    th[:, lo - c0:hi - c0] = np.nan
+                    se[:, lo - c0:hi - c0] = np.nan
                 continue
             n = int(keep.sum())
             bufs = [d_ts]
@@ -392,7 +548,6 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
                     clim_finish(plan, raw_th, raw_se, n, feb29_fix, smoothPercentile, smoothPercentileWidth,
                                 out_th, out_se)
                 h.stream_sync(0)
-                w = hi - lo
                 if scatter and n != w:
                     d_idx = DeviceBuffer.from_array(np.nonzero(keep)[0].astype(np.int64)); bufs.append(d_idx)
                     full_th, full_se = DeviceBuffer(8 * D * w), DeviceBuffer(8 * D * w)
@@ -401,14 +556,20 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
                     h.scatter_cells(out_se.ptr, D, n, d_idx.ptr, n, full_se.ptr, w)
                     h.stream_sync(0)
                     out_th, out_se, n = full_th, full_se, w
-                ths.append(((lo, hi), out_th.to_array((D, n), np.float64)))
-                ses.append(((lo, hi), out_se.to_array((D, n), np.float64)))
+                if th is not None:
+                    h.memcpy2d_d2h(th, lo - c0, w, out_th.ptr)
+                    h.memcpy2d_d2h(se, lo - c0, w, out_se.ptr)
+                else:
+                    ths.append(((lo, hi), out_th.to_array((D, n), np.float64)))
+                    ses.append(((lo, hi), out_se.to_array((D, n), np.float64)))
             finally:
                 for b in bufs:
                     b.free()
         keep = np.concatenate(keeps) if keeps else np.zeros(0, dtype=bool)
         if not keep.any() and columns is None:
             raise XmhwException("All points of grid are either land or NaN")     # identify.py:527-528
+        if th is not None:
+            return keep, plan.doys.copy(), th, se
         if not scatter:
             if not ths:
                 return keep, plan.doys.copy(), np.zeros((D, 0)), np.zeros((D, 0))
@@ -423,4 +584,6 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
             se[:, a - c0:b - c0] = y
         return keep, plan.doys.copy(), th, se
     finally:
+        if pre is not None:
+            pre.close()
         plan.destroy()

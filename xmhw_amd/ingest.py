@@ -1,0 +1,142 @@
+"""File -> device ingest for threshold() / detect().
+
+The reference leaves reading to xarray (``xr.open_dataset(...)['sst']``, docs/gettingstarted.rst:
+30-33) and masks land by ``dropna`` on the stacked array (xmhw/identify.py:520-528).  Here a netCDF
+classic file is memory-mapped (xmhw_amd/netcdf3.py), the variable's RAW bytes -- big-endian, possibly
+CF-packed int16 -- are handed to the grid entry points as a ``PackedArray``, and everything after
+that happens on the device, slab by slab with the next slab's upload overlapping the current slab's
+kernels (device.SlabPrefetcher): byte swap + ``raw * scale_factor + add_offset`` + ``_FillValue`` ->
+NaN (xmhw_decode), land mask, compaction, climatology, placement back on the grid.  An int16-packed
+archive therefore crosses PCIe at 2 bytes per sample instead of 4 (or 8 once xarray has decoded it).
+
+    temp = open_series("sst.day.mean.nc", "sst")      # GridSeries over the mapped file
+    clim = xmhw_amd.threshold(temp)
+    mhw  = xmhw_amd.detect(temp, climatology_series(clim, "thresh"), climatology_series(clim, "seas"))
+"""
+import re
+
+import numpy as np
+
+from . import netcdf3
+from .api import GridSeries
+from .device import PackedArray
+from .exception import XmhwException
+
+_UNITS = {"days": 86400.0, "day": 86400.0, "d": 86400.0, "hours": 3600.0, "hour": 3600.0, "hrs": 3600.0, "h": 3600.0,
+          "minutes": 60.0, "minute": 60.0, "min": 60.0, "seconds": 1.0, "second": 1.0, "secs": 1.0, "s": 1.0}
+_STANDARD = ("", "standard", "gregorian", "proleptic_gregorian")
+
+
+class CFTime:
+    """A date on a non-standard CF calendar (noleap / 365_day, all_leap / 366_day, 360_day): just what
+    calendar.add_doy() reads from cftime objects -- year, month, dayofyr, calendar."""
+    __slots__ = ("year", "month", "day", "dayofyr", "calendar")
+
+    def __init__(self, year, month, day, dayofyr, calendar):
+        self.year, self.month, self.day, self.dayofyr, self.calendar = year, month, day, dayofyr, calendar
+
+    def __repr__(self):
+        return f"CFTime({self.year:04d}-{self.month:02d}-{self.day:02d}, {self.calendar})"
+
+
+def _month_table(calendar):
+    if calendar in ("360_day",):
+        return [30] * 12
+    feb = 29 if calendar in ("all_leap", "366_day") else 28
+    return [31, feb, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31]
+
+
+def decode_time(values, units, calendar=""):
+    """CF time coordinate -> datetime64[s] (standard calendars) or an object array of CFTime."""
+    m = re.match(r"\s*(\w+)\s+since\s+(\d{1,4})-(\d{1,2})-(\d{1,2})(?:[ T](\d{1,2}):(\d{1,2})(?::(\d{1,2}(?:\.\d*)?))?)?", units or "")
+    if not m or m.group(1).lower() not in _UNITS:
+        raise XmhwException(f"cannot decode time units {units!r}")
+    step = _UNITS[m.group(1).lower()]
+    y0, mo0, d0 = int(m.group(2)), int(m.group(3)), int(m.group(4))
+    sec0 = int(m.group(5) or 0) * 3600 + int(m.group(6) or 0) * 60 + float(m.group(7) or 0)
+    secs = np.asarray(values, dtype=np.float64) * step + sec0
+    calendar = (calendar or "").lower()
+    if calendar in _STANDARD:
+        origin = np.datetime64(f"{y0:04d}-{mo0:02d}-{d0:02d}", "s")
+        return origin + np.round(secs).astype("timedelta64[s]")
+    months = _month_table(calendar)
+    ylen = sum(months)
+    day0 = sum(months[:mo0 - 1]) + (d0 - 1)
+    days = np.floor(secs / 86400.0).astype(np.int64) + day0
+    out = np.empty(days.shape, dtype=object)
+    cum = np.cumsum([0] + months)
+    for i, dd in enumerate(days):
+        yr, doy = y0 + dd // ylen, dd % ylen
+        mon = int(np.searchsorted(cum, doy, side="right"))
+        out[i] = CFTime(int(yr), mon, int(doy - cum[mon - 1]) + 1, int(doy) + 1, calendar)
+    return out
+
+
+def open_series(path, varname=None, tdim=None):
+    """A (time, y, x) variable of a netCDF classic file as a GridSeries whose values are a zero-copy
+    PackedArray over the mapped file: nothing is read or decoded on the host."""
+    f = netcdf3.File(path)
+    cands = [v for v in f.variables.values() if len(v.dims) >= 2 and v.name not in f.dimensions]
+    if varname is None:
+        if len(cands) != 1:
+            raise XmhwException(f"{path}: name the variable, candidates {[v.name for v in cands]}")
+        var = cands[0]
+    else:
+        if varname not in f.variables:
+            raise XmhwException(f"{path}: no variable {varname!r}")
+        var = f.variables[varname]
+    tdim = tdim or var.dims[0]
+    if var.dims[0] != tdim:
+        raise XmhwException(f"{path}: {var.name} must have {tdim!r} as its first (slowest) dimension, has {var.dims}")
+    inner = var.data[0] if var.shape[0] else var.data
+    if var.shape[0] and not np.asarray(inner).flags.c_contiguous:
+        raise XmhwException(f"{path}: {var.name}: the non-time dimensions must be contiguous in the file")
+    at = var.attrs
+    kind, isz = var.dtype.kind, var.dtype.itemsize
+    scale, offset, fill = at.get("scale_factor"), at.get("add_offset"), at.get("_FillValue", at.get("missing_value"))
+    if kind == "i" and isz == 2:
+        # xarray's CF decoding: float32 for float32 attributes, float64 otherwise
+        f64 = any(isinstance(x, (float, np.float64)) and not isinstance(x, np.float32) for x in (scale, offset) if x is not None)
+        out = np.float64 if f64 else np.float32
+        if scale is None and offset is not None:
+            scale = 1.0
+    elif kind == "f" and isz in (4, 8):
+        out = np.float32 if isz == 4 else np.float64
+        if scale is not None or offset is not None:
+            scale = 1.0 if scale is None else scale
+    else:
+        raise XmhwException(f"{path}: {var.name} is stored as {var.dtype}; the device decoder takes int16, float32, float64")
+    decode = dict(scale=None if scale is None else float(scale), offset=None if offset is None else float(offset),
+                  fill=None if fill is None else float(fill), out=np.dtype(out).name)
+    coords, coord_attrs = {}, {}
+    for d in var.dims:
+        if d in f.variables and f.variables[d].dims == (d,):
+            cv = f.variables[d]
+            coords[d] = np.asarray(cv.data).astype(cv.dtype.newbyteorder("="))
+            coord_attrs[d] = {k: v for k, v in cv.attrs.items()}
+        else:
+            coords[d] = np.arange(var.shape[var.dims.index(d)])
+            coord_attrs[d] = {}
+    tat = coord_attrs.get(tdim, {})
+    enc = {}
+    if "units" in tat and " since " in str(tat["units"]):
+        cal = str(tat.get("calendar", ""))
+        coords[tdim] = decode_time(coords[tdim], tat["units"], cal)
+        if cal:
+            enc["calendar"] = cal
+    attrs = {k: v for k, v in at.items() if k not in ("scale_factor", "add_offset", "_FillValue", "missing_value")}
+    gs = GridSeries.__new__(GridSeries)
+    gs.values = PackedArray(var.data, decode)
+    gs.dims = tuple(var.dims)
+    gs.coords = coords
+    gs.attrs = attrs
+    gs.coord_attrs = coord_attrs
+    gs.time_encoding = enc
+    gs._file = f                     # keeps the mapping alive
+    return gs
+
+
+def threshold_file(path, varname=None, **kwargs):
+    """threshold() straight from a netCDF classic file (see the module docstring)."""
+    from .api import threshold
+    return threshold(open_series(path, varname, kwargs.get("tdim")), **kwargs)
