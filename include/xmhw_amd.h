@@ -75,7 +75,9 @@ int xmhw_host_alloc(void **host_ptr, size_t bytes);        /* page-locked host m
 int xmhw_host_free(void *host_ptr);
 int xmhw_memcpy2d_h2d_async(void *dev_dst, size_t dpitch, const void *host_src, size_t spitch,
                             size_t width_bytes, size_t height, void *stream);
+int xmhw_memcpy_h2d_async(void *dev_dst, const void *host_src, size_t bytes, void *stream);
 int xmhw_memcpy_d2h_async(void *host_dst, const void *dev_src, size_t bytes, void *stream);
+int xmhw_event_sync(void *event);                           /* block the host until the event has happened */
 int xmhw_decode(const void *raw_dev, int raw_itemsize, int big_endian, int64_t rows, int64_t cols,
                 int64_t ld_raw, void *out_dev, int out_itemsize, int64_t ld_out, int has_scale,
                 double scale_factor, double add_offset, int has_fill, double fill_value, void *stream);
@@ -315,6 +317,28 @@ int xmhw_synth_sst_f32(float *ts_dev, int64_t T, int64_t C, int64_t ld, int64_t 
                        uint64_t seed, double nan_frac, void *stream);
 int xmhw_synth_sst_f64(double *ts_dev, int64_t T, int64_t C, int64_t ld, int64_t cell0,
                        uint64_t seed, double nan_frac, void *stream);
+
+/* ---- block_average() (xmhw/stats.py:27-428) ------------------------------ *
+ * The reference runs groupby(pd.cut(years, bins, right=False)).agg(...) per cell (call_groupby
+ * :285-319).  Device buffers throughout; bin_of_t[T] (int32, device) = year-bin index of every time
+ * step, -1 outside the bins.  Results: out[stat][bin][cell] float64, leading dimension ldo >= C.
+ * xmhw_block_events: the 15 statistics of agg_mhw (:344-362: ecount, duration, intensity_max,
+ * intensity_max_max, intensity_mean, intensity_cumulative, total_icum, intensity_mean_relThresh,
+ * intensity_cumulative_relThresh, severity_mean, severity_cumulative, intensity_mean_abs,
+ * intensity_cumulative_abs, rate_onset, rate_decline) from the compact event table of detect()
+ * (n_events x 31, events of cell c at rows offsets[c]..offsets[c+1]); an event belongs to the bin
+ * of the time step in column mtime_column (3 = time_start, 5 = time_peak).
+ * xmhw_block_time_*: ts_mean, ts_max, ts_min per block (agg_ts :421-425) and, when `cats` (T, ldcat)
+ * is given, the moderate / strong / severe / extreme day counts (agg_cats :391-400): 7 planes.  */
+int xmhw_block_events(const double *table_dev, const int64_t *offsets_dev, int64_t C,
+                      const int32_t *bin_of_t_dev, int64_t T, int32_t nbins, int32_t mtime_column,
+                      double *out_dev, int64_t ldo, void *stream);
+int xmhw_block_time_f32(const float *ts_dev, int64_t T, int64_t C, int64_t ld, const double *cats_dev,
+                        int64_t ldcat, const int32_t *bin_of_t_dev, int32_t nbins, double *out_dev,
+                        int64_t ldo, void *stream);
+int xmhw_block_time_f64(const double *ts_dev, int64_t T, int64_t C, int64_t ld, const double *cats_dev,
+                        int64_t ldcat, const int32_t *bin_of_t_dev, int32_t nbins, double *out_dev,
+                        int64_t ldo, void *stream);
 
 /* ---- the sharded path: cells split across the GPUs of a node, ONE gather at the end ------- *
  * Replaces the reference's collect, dask.compute(climls) + xr.concat(dim='cell')

@@ -44,30 +44,26 @@ def main():
         "lat": (("lat",), np.linspace(-89.875, 89.875, args.lat).astype(np.float32), {}),
         "lon": (("lon",), np.linspace(0.125, 359.875, args.lon).astype(np.float32), {}),
         "sst": (("time", "lat", "lon"), np.zeros((1, args.lat, args.lon), dtype=dt), vat)})
-    f = netcdf3.File(path)
-    begin = f.variables["sst"].data.__array_interface__["data"][0] - np.frombuffer(f._mm, dtype=np.uint8).__array_interface__["data"][0]
-    f.close()
+    # sst is the last variable the writer laid out and only one of its T steps was written
+    begin = os.path.getsize(path) - ((isz * N + 3) & ~3)
     with open(path, "r+b") as fh:
         fh.truncate(begin + isz * T * N)
     mm = np.memmap(path, dtype=dt, mode="r+", offset=begin, shape=(T, N))
-    rows = max(1, (2 << 30) // (4 * N))
-    buf = DeviceBuffer(4 * rows * N)
-    land = np.zeros(N, dtype=bool)
-    land[:: 6] = True                              # a sixth of the cells is land
-    for r0 in range(0, T, rows):
-        r1 = min(T, r0 + rows)
-        # the generator is a function of (cell, t): generate rows r0..r1 of all cells
-        h.synth_sst_rows(buf.ptr, r0, r1 - r0, N, 20260102) if hasattr(h, "synth_sst_rows") else None
-        a = buf.to_array((r1 - r0, N), np.float32) if hasattr(h, "synth_sst_rows") else \
-            (15 + 5 * np.sin(2 * np.pi * (np.arange(r0, r1)[:, None] - (np.arange(N) % 365)[None, :]) / 365.25)
-             + np.random.default_rng(r0).normal(size=(r1 - r0, N)).astype(np.float32)).astype(np.float32)
+    cb = max(1, (2 << 30) // (4 * T))                 # column blocks of ~2 GB: the generator is a function of (cell, t)
+    buf = DeviceBuffer(4 * T * cb)
+    for c0 in range(0, N, cb):
+        c1 = min(N, c0 + cb)
+        h.synth_sst(buf.ptr, 4, T, c1 - c0, c1 - c0, c0, 20260102, 0.0, 0)
+        h.stream_sync(0)
+        a = buf.to_array((T, c1 - c0), np.float32)
+        land = (np.arange(c0, c1) % 6) == 0            # a sixth of the cells is land
         if args.kind == "f32":
             a[:, land] = np.nan
-            mm[r0:r1] = a
+            mm[:, c0:c1] = a
         else:
             q = np.round((a - 15.0) / 0.01).astype(np.int16)
             q[:, land] = -32768
-            mm[r0:r1] = q
+            mm[:, c0:c1] = q
     mm.flush()
     del mm
     buf.free()

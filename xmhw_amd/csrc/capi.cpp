@@ -506,6 +506,18 @@ int clim_host(const T* ts, const int32_t* doy, int64_t Tn, int64_t C, int32_t D,
 
 }  // namespace
 
+template <typename T>
+static int block_time(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* cats, int64_t ldcat,
+                      const int32_t* bin_of_t, int32_t nbins, double* out, int64_t ldo, void* stream) {
+    if (C < 0 || Tn <= 0 || nbins <= 0 || ldo < C || ld < C || (cats && ldcat < C)) return fail(XMHW_ERR_INVALID, "bad C/T/nbins/ld");
+    if (C == 0) return XMHW_OK;
+    if (!ts || !bin_of_t || !out) return fail(XMHW_ERR_INVALID, "NULL buffer");
+    hipError_t e = xmhw::launch_block_time<T>(ts, Tn, C, ld, cats, ldcat, bin_of_t, nbins, out, ldo,
+                                              static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "block_time launch");
+    return XMHW_OK;
+}
+
 extern "C" {
 
 int xmhw_version(void) { return 1000 * 0 + 1; }
@@ -592,6 +604,15 @@ int xmhw_memcpy2d_h2d_async(void* dst, size_t dpitch, const void* src, size_t sp
     if (width == 0 || height == 0) return XMHW_OK;
     if (!dst || !src || dpitch < width || spitch < width) return fail(XMHW_ERR_INVALID, "bad pointer/pitch");
     HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    return XMHW_OK;
+}
+int xmhw_memcpy_h2d_async(void* dst, const void* src, size_t bytes, void* stream) {
+    if (bytes == 0) return XMHW_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    return XMHW_OK;
+}
+int xmhw_event_sync(void* event) {
+    HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(event)));
     return XMHW_OK;
 }
 int xmhw_memcpy_d2h_async(void* dst, const void* src, size_t bytes, void* stream) {
@@ -936,6 +957,26 @@ int xmhw_event_stats_f64(const double* ts, int64_t T, int64_t C, int64_t ld, con
                          const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,
                          const int32_t* events, int64_t ldo, const int64_t* offsets, double* table, void* stream) {
     return event_stats<double>(ts, T, C, ld, seas, thresh, ldc, row_of_t, negate, events, ldo, offsets, table, stream);
+}
+
+int xmhw_block_events(const double* table, const int64_t* offsets, int64_t C, const int32_t* bin_of_t, int64_t T,
+                      int32_t nbins, int32_t mtime_column, double* out, int64_t ldo, void* stream) {
+    if (C < 0 || T <= 0 || nbins <= 0 || ldo < C) return fail(XMHW_ERR_INVALID, "bad C/T/nbins/ldo");
+    if (mtime_column < 0 || mtime_column >= xmhw::kEventColumns) return fail(XMHW_ERR_INVALID, "bad mtime column");
+    if (C == 0) return XMHW_OK;
+    if (!table || !offsets || !bin_of_t || !out) return fail(XMHW_ERR_INVALID, "NULL buffer");
+    hipError_t e = xmhw::launch_block_events(table, offsets, C, bin_of_t, T, nbins, mtime_column, out, ldo,
+                                             static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "block_events launch");
+    return XMHW_OK;
+}
+int xmhw_block_time_f32(const float* ts, int64_t T, int64_t C, int64_t ld, const double* cats, int64_t ldcat,
+                        const int32_t* bin_of_t, int32_t nbins, double* out, int64_t ldo, void* stream) {
+    return block_time<float>(ts, T, C, ld, cats, ldcat, bin_of_t, nbins, out, ldo, stream);
+}
+int xmhw_block_time_f64(const double* ts, int64_t T, int64_t C, int64_t ld, const double* cats, int64_t ldcat,
+                        const int32_t* bin_of_t, int32_t nbins, double* out, int64_t ldo, void* stream) {
+    return block_time<double>(ts, T, C, ld, cats, ldcat, bin_of_t, nbins, out, ldo, stream);
 }
 
 int xmhw_synth_sst_f32(float* ts, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,

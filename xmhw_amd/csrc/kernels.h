@@ -113,6 +113,14 @@ hipError_t launch_event_intermediate(const T* ts, int64_t Tn, int64_t C, int64_t
                                      const int32_t* events, int64_t ldo, double* out, int64_t ldv, uint8_t* dur,
                                      hipStream_t stream);
 
+// block_average() (kernels_stats.hip): segmented reductions keyed by (cell, year bin); out[stat][bin][cell]
+constexpr int kBlockEventStats = 15;
+hipError_t launch_block_events(const double* table, const int64_t* offsets, int64_t C, const int32_t* bin_of_t, int64_t Tn,
+                               int32_t nbins, int32_t mtime_col, double* out, int64_t ldo, hipStream_t stream);
+template <typename T>
+hipError_t launch_block_time(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* cats, int64_t ldcat,
+                             const int32_t* bin_of_t, int32_t nbins, double* out, int64_t ldo, hipStream_t stream);
+
 // file bytes -> samples (kernels_ingest.hip): raw_type = item size of the stored type (2 int16, 4 float32,
 // 8 float64), swap = the file is big-endian, optional scale/offset (CF packing) and fill value -> NaN
 hipError_t launch_decode(const void* in, int raw_type, int swap, int64_t rows, int64_t cols, int64_t ld_in, void* out,

@@ -413,9 +413,32 @@ PYBIND11_MODULE(_xmhw_hip, m) {
                                    uintptr_t stream) {
         check(xmhw_memcpy2d_h2d_async(vp(dst), dpitch, vp(src), spitch, width, height, vp(stream)));
     });
+    m.def("memcpy_h2d_async", [](uintptr_t dst, uintptr_t src, size_t bytes, uintptr_t stream) {
+        check(xmhw_memcpy_h2d_async(vp(dst), vp(src), bytes, vp(stream)));
+    });
+    m.def("event_sync", [](uintptr_t e) { py::gil_scoped_release r; check(xmhw_event_sync(vp(e))); });
     m.def("memcpy_d2h_async", [](uintptr_t dst, uintptr_t src, size_t bytes, uintptr_t stream) {
         check(xmhw_memcpy_d2h_async(vp(dst), vp(src), bytes, vp(stream)));
     });
+
+    m.def("block_events", [](uintptr_t table, uintptr_t offsets, int64_t C, uintptr_t bin_of_t, int64_t T, int nbins,
+                             int mtime_col, uintptr_t out, int64_t ldo, uintptr_t stream) {
+        check(xmhw_block_events(static_cast<const double*>(vp(table)), static_cast<const int64_t*>(vp(offsets)), C,
+                                static_cast<const int32_t*>(vp(bin_of_t)), T, nbins, mtime_col, static_cast<double*>(vp(out)),
+                                ldo, vp(stream)));
+    }, py::arg("table"), py::arg("offsets"), py::arg("C"), py::arg("bin_of_t"), py::arg("T"), py::arg("nbins"),
+       py::arg("mtime_col"), py::arg("out"), py::arg("ldo"), py::arg("stream") = 0);
+    m.def("block_time", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, uintptr_t cats, int64_t ldcat,
+                           uintptr_t bin_of_t, int nbins, uintptr_t out, int64_t ldo, uintptr_t stream) {
+        if (itemsize == 4)
+            check(xmhw_block_time_f32(static_cast<const float*>(vp(ts)), T, C, ld, static_cast<const double*>(vp(cats)), ldcat,
+                                      static_cast<const int32_t*>(vp(bin_of_t)), nbins, static_cast<double*>(vp(out)), ldo, vp(stream)));
+        else if (itemsize == 8)
+            check(xmhw_block_time_f64(static_cast<const double*>(vp(ts)), T, C, ld, static_cast<const double*>(vp(cats)), ldcat,
+                                      static_cast<const int32_t*>(vp(bin_of_t)), nbins, static_cast<double*>(vp(out)), ldo, vp(stream)));
+        else throw InvalidError("itemsize must be 4 or 8");
+    }, py::arg("ts"), py::arg("itemsize"), py::arg("T"), py::arg("C"), py::arg("ld"), py::arg("cats"), py::arg("ldcat"),
+       py::arg("bin_of_t"), py::arg("nbins"), py::arg("out"), py::arg("ldo"), py::arg("stream") = 0);
 
     m.def("synth_sst", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
                           double nan_frac, uintptr_t stream) {
