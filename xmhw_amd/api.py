@@ -230,8 +230,8 @@ def _threshold(temp, compute, tdim="time", climatologyPeriod=[None, None], pctil
             other = tuple(i for i in range(len(sdims)) if i != ax)
             alive = keepg.any(axis=other) if other else keepg
             if not alive.all():
-                thg = np.compress(alive, thg, axis=ax + 1)
-                seg = np.compress(alive, seg, axis=ax + 1)
+                thg = landmask.compress_axis(thg, alive, ax + 1)
+                seg = landmask.compress_axis(seg, alive, ax + 1)
             ocoords[d] = np.asarray(coords[d])[alive]
     q = pctile / 100.0
     out_coord_attrs = {"doy": doy_attrs}

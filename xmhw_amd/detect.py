@@ -97,8 +97,9 @@ def _alive_axes(keep, sshape):
 
 
 def _compress_grid(a, alive, first_axis):
+    from .landmask import compress_axis
     for ax, m in enumerate(alive):
-        a = np.compress(m, a, axis=first_axis + ax)
+        a = compress_axis(a, m, first_axis + ax)
     return a
 
 

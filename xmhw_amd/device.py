@@ -279,7 +279,15 @@ def calc_clim_device(ts, doy, pctile, windowHalfWidth, smoothPercentile, smoothP
 _STAGE = {}
 _USE_STAGING = _os.environ.get("XMHW_AMD_STAGING", "1") != "0"
 _STAGE_BYTES = 1 << 30
-_STAGE_THREADS = 16
+_STAGE_THREADS = int(_os.environ.get("XMHW_AMD_STAGE_THREADS", "32"))
+_TRACE = _os.environ.get("XMHW_AMD_TRACE", "0") != "0"
+
+
+def _trace(label, t0):
+    if _TRACE:
+        import sys
+        import time
+        print(f"[xmhw_amd] {label}: {time.perf_counter() - t0:.3f} s", file=sys.stderr, flush=True)
 _STAGE_MIN = 256 << 20
 
 
@@ -337,10 +345,12 @@ def upload_columns(stacked, lo, hi):
     """Columns [lo, hi) of a C-contiguous host (T, N) array as a dense device (T, n) array of the
     DECODED dtype: a pitched upload of the raw bytes, then -- for file views (PackedArray: big-endian
     and / or CF-packed samples) -- the decode kernel.  Returns (DeviceBuffer, itemsize)."""
+    import time as _time
     h = hip()
     T = stacked.shape[0]
     n = hi - lo
     raw_isz = stacked.dtype.itemsize
+    _t0 = _time.perf_counter()
     d_raw = DeviceBuffer(raw_isz * T * n)
     try:
         if raw_isz * T * n >= _STAGE_MIN and _USE_STAGING:
@@ -349,6 +359,7 @@ def upload_columns(stacked, lo, hi):
             h.memcpy_h2d(d_raw.ptr, np.asarray(stacked))
         else:
             h.memcpy2d_h2d(d_raw.ptr, np.asarray(stacked), lo, n)
+        _trace(f"upload columns [{lo},{hi}) {raw_isz * T * n / 1e9:.2f} GB", _t0)
         if not is_packed(stacked):
             out, d_raw = d_raw, None
             return out, raw_isz
@@ -591,8 +602,14 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
             se = np.empty((D, c1 - c0))
         # slab k+1 is uploaded (and decoded) by a second thread while slab k computes
         pre = SlabPrefetcher(stacked, slabs)
+        import time as _time
+        _tl = _time.perf_counter()
         for (lo, hi), (d_up, up_isz) in pre:
+            _trace(f"wait for slab [{lo},{hi})", _tl)
+            _tl = _time.perf_counter()
             d_ts, keep = mask_compact(d_up, up_isz, T, hi - lo, anynans)
+            _trace("mask + compact", _tl)
+            _tl = _time.perf_counter()
             keeps.append(keep)
             w = hi - lo
             if d_ts is None:
@@ -621,9 +638,13 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
                     h.scatter_cells(out_se.ptr, D, n, d_idx.ptr, n, full_se.ptr, w)
                     h.stream_sync(0)
                     out_th, out_se, n = full_th, full_se, w
+                _trace("kernels + scatter", _tl)
+                _tl = _time.perf_counter()
                 if th is not None:
                     h.memcpy2d_d2h(th, lo - c0, w, out_th.ptr)
                     h.memcpy2d_d2h(se, lo - c0, w, out_se.ptr)
+                    _trace("results to host (pitched)", _tl)
+                    _tl = _time.perf_counter()
                 else:
                     ths.append(((lo, hi), out_th.to_array((D, n), np.float64)))
                     ses.append(((lo, hi), out_se.to_array((D, n), np.float64)))

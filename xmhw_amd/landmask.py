@@ -35,3 +35,18 @@ def land_check(values, dims, tdim="time", anynans=False):
     stacked, order, sshape = stack_cells(values, dims, tdim)
     keep = keep_mask(stacked, anynans)
     return np.ascontiguousarray(stacked[:, keep]), keep, order, sshape
+
+
+def compress_axis(a, mask, axis):
+    """np.compress(mask, a, axis) without the copy when the surviving lines form one contiguous run
+    (a polar land band, a regional tile's margin): a slice view then.  On a global grid the copy of
+    both climatologies cost as much as the kernels."""
+    mask = np.asarray(mask, dtype=bool)
+    if mask.all():
+        return a
+    idx = np.nonzero(mask)[0]
+    if idx.size and idx[-1] - idx[0] + 1 == idx.size:
+        sl = [slice(None)] * a.ndim
+        sl[axis] = slice(int(idx[0]), int(idx[-1]) + 1)
+        return a[tuple(sl)]
+    return np.compress(mask, a, axis=axis)
