@@ -19,7 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="0.25deg")
     ap.add_argument("--cells", type=int, default=0)
-    ap.add_argument("--variants", type=int, nargs="*", default=[-1, 0, 1])
+    ap.add_argument("--variants", type=int, nargs="*", default=[-1, 0, 1, 2, 3, 4])
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--chunks", type=int, default=0)
     args = ap.parse_args()

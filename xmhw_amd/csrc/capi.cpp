@@ -697,7 +697,7 @@ int xmhw_plan_create(const int32_t* doy_host, int64_t T, int32_t window_half_wid
 }
 int xmhw_plan_set_ring2(xmhw_plan* plan, int32_t variant) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
-    if (variant < -1 || variant > 1) return fail(XMHW_ERR_INVALID, "ring2 variant must be -1 (off), 0 or 1");
+    if (variant < -1 || variant > 6) return fail(XMHW_ERR_INVALID, "ring2 variant must be -1 (off) or 0..6");
     plan->ring2_variant = variant;
     return XMHW_OK;
 }

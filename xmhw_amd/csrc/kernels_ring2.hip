@@ -75,6 +75,9 @@ __device__ __forceinline__ uint32_t maxu(uint32_t a, uint32_t b) { return a > b 
 __device__ __forceinline__ uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t acc) {
     return __builtin_amdgcn_sad_u8(a, b, acc);
 }
+__device__ __forceinline__ uint32_t sad_u16(uint32_t a, uint32_t b, uint32_t acc) {
+    return __builtin_amdgcn_sad_u16(a, b, acc);
+}
 __device__ __forceinline__ uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) {
     return __builtin_amdgcn_perm(hi, lo, sel);
 }
@@ -207,17 +210,13 @@ struct Top2 {
     }
 };
 
-// extraction width: 5 keys after 32-bit count passes (each pass is ~120 instructions, so the window of
-// acceptable ranks is wide); 3 keys when the bracket is closed by 8-bit probes (a probe is ~50
-// instructions: aiming at a 2-rank window costs less than two extra insertions per key)
-constexpr int kJ2_count = 5, kJ2_probe = 3;
 constexpr int kBudget2 = 6;
 
 }  // namespace
 
 // sflags[step]: bit 0 = SIMPLE (every real track pushes a valid sample and is counted; padded
 // tracks push invalid).  ntracks = real tracks (tracks >= ntracks are padding).
-template <int W, int YPS, bool PROBE8, bool STATS>
+template <int W, int YPS, int PB, int JX, bool STATS>
 __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, int32_t step_min, const DevChunk* __restrict__ chunks, double q,
@@ -227,10 +226,16 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     constexpr int R = 2 * W + 1;
     constexpr int SUBS = 8;
     constexpr int NTP = SUBS * YPS;
-    constexpr int J = PROBE8 ? kJ2_probe : kJ2_count;
+    // PB: width of the code ring the bracket is closed on (0: none, 32-bit count passes only; 8; 16);
+    // JX: extraction width (the window of acceptable ranks is JX - 1 wide)
+    static_assert(PB == 0 || PB == 8 || PB == 16, "code ring of 8 or 16 bits");
+    constexpr bool PROBE8 = PB != 0;             // (name kept: "closes the bracket on a code ring")
+    constexpr int J = JX;
+    constexpr int CPW = PB == 16 ? 2 : 4;        // codes per 32-bit word
+    constexpr uint32_t LMAX = PB == 16 ? 65534u : 254u;   // levels 1..LMAX are exact thresholds; LMAX + 1 = padding
     constexpr uint32_t SLACK = J - 2;
     constexpr int NK = YPS * R;                 // keys per lane
-    constexpr int NW = (NK + 3) / 4;            // code words per lane
+    constexpr int NW = PB == 16 ? (NK + 1) / 2 : (NK + 3) / 4;            // code words per lane
     constexpr uint32_t ALLC = (1u << YPS) - 1u;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -404,15 +409,16 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                 uint32_t cin[YPS];
 #pragma unroll
                 for (int y = 0; y < YPS; ++y)
-                    cin[y] = minu(__builtin_elementwise_sub_sat(kin[y], cbase) >> cshift, 254u);
+                    cin[y] = minu(__builtin_elementwise_sub_sat(kin[y], cbase) >> cshift, LMAX);
 #define XMHW_R2_CODE(K)                                                                          \
     case K:                                                                                      \
         if constexpr (K < R) {                                                                   \
             _Pragma("unroll") for (int y = 0; y < YPS; ++y) {                                    \
                 const int pos = y * R + (K < R ? K : 0);                                         \
-                const uint32_t sel = pos % 4 == 0 ? 0x07060500u : pos % 4 == 1 ? 0x07060004u    \
-                                     : pos % 4 == 2 ? 0x07000504u : 0x00060504u;                 \
-                codes[pos / 4] = perm_b32(codes[pos / 4], cin[y], sel);                          \
+                const uint32_t sel = PB == 16 ? (pos % 2 == 0 ? 0x07060100u : 0x01000504u)       \
+                                   : pos % 4 == 0 ? 0x07060500u : pos % 4 == 1 ? 0x07060004u    \
+                                   : pos % 4 == 2 ? 0x07000504u : 0x00060504u;                   \
+                codes[pos / CPW] = perm_b32(codes[pos / CPW], cin[y], sel);                      \
             }                                                                                    \
         }                                                                                        \
         break;
@@ -515,60 +521,74 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                     // (re)build the code ring when there is none, or when the previous row's level came
                     // close to an edge of the 254-level window
                     const bool want = have_c != 0 && n != 0;
-                    const bool rebase = want && (have_code == 0 || Lc < 20u || Lc > 234u);
+                    // 8 bits: 254 levels of about one rank, rebuilt when the target nears an edge (every few
+                    // rows: it drifts ~13 ranks a day); 16 bits: 65534 levels of about a quarter rank cover the
+                    // whole year of a cell, rebuilt only when the local key density has changed a lot
+                    const float lpr_now = kpr * __builtin_ldexpf(1.0f, -static_cast<int>(cshift));
+                    const bool edge = PB == 16 ? (Lc < 4096u || Lc > 61000u || lpr_now < 1.5f || lpr_now > 24.0f)
+                                               : (Lc < 20u || Lc > 234u);
+                    const bool rebase = want && (have_code == 0 || edge);
                     if (__any(rebase)) {
-                        // window: 254 levels of 2^shift keys, about one rank per level; the carried
-                        // pivot goes to level 72 when the target has been rising, 182 when falling
-                        const float lw = fmaxf(kpr, 1.0f);
+                        const float lw = fmaxf(PB == 16 ? kpr * 0.25f : kpr, 1.0f);
                         uint32_t sh = 31u - static_cast<uint32_t>(__builtin_clz(static_cast<uint32_t>(fminf(lw, 8.0e6f))));
-                        const uint32_t at = drift >= 0.0f ? 72u : 182u;
+                        sh = minu(sh, PB == 16 ? 15u : 23u);
+                        const uint32_t at = PB == 16 ? 32768u : (drift >= 0.0f ? 72u : 182u);
                         const uint32_t span = at << sh;
                         uint32_t nb = pc > span ? pc - span : 0u;
-                        nb = minu(nb, 0xFFFFFFFFu - (256u << sh));
+                        nb = minu(nb, 0xFFFFFFFFu - ((LMAX + 2u) << sh));
                         if (rebase) {
                             cbase = nb;
                             cshift = sh;
                             have_code = 1;
-                            Lc = minu(static_cast<uint32_t>((pc - nb) >> sh) + 1u, 254u);
+                            Lc = minu(static_cast<uint32_t>((pc - nb) >> sh) + 1u, LMAX);
+                            drift = 0.0f;
                         }
                         // every lane of the wave converts (cells that keep their window recompute the same codes)
 #pragma unroll
                         for (int wd = 0; wd < NW; ++wd) {
                             uint32_t word = 0;
 #pragma unroll
-                            for (int b = 0; b < 4; ++b) {
-                                const int pos = wd * 4 + b;
-                                uint32_t c = 255u;
+                            for (int b = 0; b < CPW; ++b) {
+                                const int pos = wd * CPW + b;
+                                uint32_t c = LMAX + 1u;
                                 if (pos < NK)
-                                    c = minu(__builtin_elementwise_sub_sat(ring[pos / R][pos % R], cbase) >> cshift, 254u);
-                                word |= c << (8 * b);
+                                    c = minu(__builtin_elementwise_sub_sat(ring[pos / R][pos % R], cbase) >> cshift, LMAX);
+                                word |= c << (PB * b);
                             }
                             codes[wd] = word;
                         }
                         if constexpr (STATS) ++st_rebase;
                     }
                     if (__any(have_code != 0 && n != 0)) {
-                        // cum(L) = #{code < L} = #{key < cbase + (L << cshift)}, exact for 1 <= L <= 254
+                        // cum(L) = #{code < L} = #{key < cbase + (L << cshift)}, exact for 1 <= L <= LMAX:
+                        // sum |c - L| - sum |c - (L-1)| = 2 #{c < L} - N over the N code slots of the cell
                         auto cum8 = [&](uint32_t L) -> uint32_t {
-                            const uint32_t b1 = L * 0x01010101u, b0 = b1 - 0x01010101u;
-                            uint32_t a1 = 0, a0 = 0;
+                            const uint32_t one = PB == 16 ? 0x00010001u : 0x01010101u;
+                            const uint32_t b1 = L * one, b0 = b1 - one;
+                            uint32_t a1 = 0, a0 = 0, c1 = 0, c0 = 0;       // two chains each: the SADs of a chain are dependent
 #pragma unroll
                             for (int wd = 0; wd < NW; ++wd) {
-                                a1 = sad_u8(codes[wd], b1, a1);
-                                a0 = sad_u8(codes[wd], b0, a0);
+                                if (wd & 1) {
+                                    c1 = PB == 16 ? sad_u16(codes[wd], b1, c1) : sad_u8(codes[wd], b1, c1);
+                                    c0 = PB == 16 ? sad_u16(codes[wd], b0, c0) : sad_u8(codes[wd], b0, c0);
+                                } else {
+                                    a1 = PB == 16 ? sad_u16(codes[wd], b1, a1) : sad_u8(codes[wd], b1, a1);
+                                    a0 = PB == 16 ? sad_u16(codes[wd], b0, a0) : sad_u8(codes[wd], b0, a0);
+                                }
                             }
-                            const uint32_t d = cell_sum(a1 - a0);
-                            return (d + static_cast<uint32_t>(8 * 4 * NW)) >> 1;
+                            const uint32_t d = cell_sum((a1 + c1) - (a0 + c0));
+                            return (d + static_cast<uint32_t>(8 * CPW * NW)) >> 1;
                         };
                         const bool active = have_code != 0 && n != 0;
                         // levels per rank near the target
-                        const float lpr = fminf(fmaxf(kpr * __builtin_ldexpf(1.0f, -static_cast<int>(cshift)), 0.25f), 16.0f);
-                        uint32_t Ll = 0, Cl = 0, Lh = 255u, Ch = nn;     // cum(Ll) <= lo < cum(Lh); ends virtual
+                        const float lpr = fminf(fmaxf(kpr * __builtin_ldexpf(1.0f, -static_cast<int>(cshift)), 0.25f), 64.0f);
+                        const float LMAXF = static_cast<float>(LMAX);
+                        uint32_t Ll = 0, Cl = 0, Lh = LMAX + 1u, Ch = nn;     // cum(Ll) <= lo < cum(Lh); ends virtual
                         const float start = static_cast<float>(Lc) + drift;
-                        uint32_t L = static_cast<uint32_t>(fminf(fmaxf(start, 1.0f), 254.0f));
+                        uint32_t L = static_cast<uint32_t>(fminf(fmaxf(start, 1.0f), LMAXF));
                         bool done = !active;
                         const float aim = static_cast<float>(lo) - 0.5f * static_cast<float>(SLACK);
-                        for (int it = 0; it < 14; ++it) {
+                        for (int it = 0; it < (PB == 16 ? 24 : 14); ++it) {
                             const uint32_t cu = cum8(done ? 1u : L);
                             if constexpr (STATS) ++st_probe8;
                             if (!done) {
@@ -577,13 +597,13 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                                 else if (Lh - Ll <= 1u) done = true;                     // a level holds > J-1 keys, or off the window
                                 else {
                                     // secant in level space from the end just probed; one-sided: carried slope
-                                    const bool both = Ll >= 1u && Lh <= 254u;
+                                    const bool both = Ll >= 1u && Lh <= LMAX;
                                     const float slope = both ? static_cast<float>(Lh - Ll) *
                                                                    __builtin_amdgcn_rcpf(static_cast<float>(Ch - Cl))
                                                              : lpr;
-                                    const bool from_l = Ll >= 1u && (cu <= lo || Lh > 254u);
+                                    const bool from_l = Ll >= 1u && (cu <= lo || Lh > LMAX);
                                     const float ranks = from_l ? aim - static_cast<float>(Cl) : static_cast<float>(Ch) - aim;
-                                    const float stf = fminf(fmaxf(ranks * slope, 1.0f), 255.0f);
+                                    const float stf = fminf(fmaxf(ranks * slope, 1.0f), LMAXF);
                                     uint32_t st = static_cast<uint32_t>(stf);
                                     if (it >= 5) st = maxu((Lh - Ll) >> 1, 1u);
                                     uint32_t Ln = from_l ? Ll + st : (Lh > st ? Lh - st : 0u);
@@ -598,15 +618,20 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                             if (Ll >= 1u) {
                                 pl = cbase + (Ll << cshift) - 1u; Fl = Cl; lreal = 1;
                             }
-                            if (Lh <= 254u) {
+                            if (Lh <= LMAX) {
                                 ph = cbase + (Lh << cshift) - 1u; Fh = Ch; hreal = 1;
                             }
                             if (Ll >= 1u && lo - Cl <= SLACK) {
                                 const float moved = static_cast<float>(Ll) - static_cast<float>(Lc);
-                                drift = 0.5f * drift + 0.5f * fminf(fmaxf(moved, -64.0f), 64.0f);
+                                const float cap = PB == 16 ? 1024.0f : 64.0f;
+                                drift = 0.5f * drift + 0.5f * fminf(fmaxf(moved, -cap), cap);
+                                Lc = Ll;
+                            } else if (Ll >= 1u && Lh <= LMAX) {
+                                // an overfull level (ties, a dense spot): the window itself is fine, the 32-bit
+                                // passes below finish this row
                                 Lc = Ll;
                             } else {
-                                have_code = 0;     // next row rebuilds the window around the new answer
+                                have_code = 0;     // off the window: next row rebuilds it around the new answer
                                 drift = 0.0f;
                             }
                         }
@@ -805,9 +830,13 @@ namespace {
 typedef void (*Ring2Kernel)(const float*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*, int32_t,
                             const DevChunk*, double, int, int32_t, double*, double*, int64_t, unsigned long long*);
 struct Ring2Entry { int w, yps, variant; Ring2Kernel fn, fn_stats; };
-// variant: bit 0 = PROBE8; the _stats twin carries the debug pass counters
-#define XMHW_R2V(W, Y, V) {W, Y, V, clim_ring2_f32<W, Y, ((V) & 1) != 0, false>, clim_ring2_f32<W, Y, ((V) & 1) != 0, true>}
-#define XMHW_R2(W, Y) XMHW_R2V(W, Y, 0), XMHW_R2V(W, Y, 1)
+// variant -> (code-ring bits, extraction width); the _stats twin carries the debug pass counters
+//   0: 32-bit count passes, J = 5        1: 8-bit probes, J = 5      2: 16-bit probes, J = 5
+//   3: 16-bit probes, J = 4              4: 16-bit probes, J = 3
+//   5: 32-bit count passes, J = 4        6: 32-bit count passes, J = 6
+#define XMHW_R2V(W, Y, V, PB, JX) {W, Y, V, clim_ring2_f32<W, Y, PB, JX, false>, clim_ring2_f32<W, Y, PB, JX, true>}
+#define XMHW_R2(W, Y) XMHW_R2V(W, Y, 0, 0, 5), XMHW_R2V(W, Y, 1, 8, 5), XMHW_R2V(W, Y, 2, 16, 5), XMHW_R2V(W, Y, 3, 16, 4), \
+                      XMHW_R2V(W, Y, 4, 16, 3), XMHW_R2V(W, Y, 5, 0, 4), XMHW_R2V(W, Y, 6, 0, 6)
 const Ring2Entry kRing2[] = {
     XMHW_R2(5, 3), XMHW_R2(5, 4), XMHW_R2(5, 5),
 };
