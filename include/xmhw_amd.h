@@ -318,6 +318,17 @@ int xmhw_synth_sst_f32(float *ts_dev, int64_t T, int64_t C, int64_t ld, int64_t 
 int xmhw_synth_sst_f64(double *ts_dev, int64_t T, int64_t C, int64_t ld, int64_t cell0,
                        uint64_t seed, double nan_frac, void *stream);
 
+/* The detect-side entries above take host row tables (row_of_t).  Their device copies (and the tiled
+ * exceedance kernel's chunk tables, and per-stream scratch such as the float32 threshold copy) are
+ * CACHED between calls, keyed by content: after the first call with a given table the entries are
+ * asynchronous on `stream` -- no allocation, no synchronisation.  xmhw_release_cached_tables() frees
+ * the caches (synchronises the device).
+ * xmhw_offsets_from_counts: exclusive prefix sum of the per-cell event counts (the count pass of
+ * xmhw_events_from_bits) into the int64 offsets (n + 1 entries, the last one = number of events)
+ * the fill pass takes -- on the device, asynchronous.                                           */
+int xmhw_release_cached_tables(void);
+int xmhw_offsets_from_counts(const int32_t *counts_dev, int64_t n, int64_t *offsets_dev, void *stream);
+
 /* ---- block_average() (xmhw/stats.py:27-428) ------------------------------ *
  * The reference runs groupby(pd.cut(years, bins, right=False)).agg(...) per cell (call_groupby
  * :285-319).  Device buffers throughout; bin_of_t[T] (int32, device) = year-bin index of every time

@@ -86,3 +86,45 @@ def test_errors(front):
         front.mhw_filter_cells(x, th[:, :1], np.ones(10, int), np.array([1, 2, 3]))   # cells differ
     with pytest.raises(XmhwException):
         front.mhw_filter_cells(x, th, np.ones(10, int), np.array([1, 2, 3]), minDuration=0)
+
+
+def test_offsets_from_counts_device_prefix_sum():
+    """the device prefix sum between the two events_from_bits passes, across block boundaries"""
+    from xmhw_amd.device import DeviceBuffer, hip
+    h = hip()
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 1023, 1024, 1025, 5000, 1024 * 1024 + 7, 3_000_001):
+        counts = rng.integers(0, 40, size=n).astype(np.int32)
+        d_c = DeviceBuffer.from_array(counts if n else np.zeros(1, np.int32))
+        d_o = DeviceBuffer(8 * (n + 1))
+        h.offsets_from_counts(d_c.ptr, n, d_o.ptr)
+        h.stream_sync(0)
+        got = d_o.to_array((n + 1,), np.int64)
+        want = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(counts, out=want[1:])
+        np.testing.assert_array_equal(got, want)
+        d_c.free(); d_o.free()
+
+
+def test_detect_entries_reuse_cached_tables_and_survive_a_release():
+    """repeated calls with the same row table (cached on the device), a different one, and a cache
+    release in between give the same tables as the first call"""
+    import xmhw_amd
+    from xmhw_amd import GridSeries, climatology_series
+    from xmhw_amd._lib import hip
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "oisst_2003_2004.npz"))
+    time = np.datetime64("2003-01-01") + g["time"].astype("timedelta64[D]")
+    temp = GridSeries(g["sst"], ("time", "lat", "lon"), {"time": time, "lat": g["lat"], "lon": g["lon"]},
+                      time_encoding={"calendar": "proleptic_gregorian"})
+    clim = xmhw_amd.threshold(temp)
+    th, se = climatology_series(clim, "thresh"), climatology_series(clim, "seas")
+    first = xmhw_amd.detect(temp, th, se)
+    again = xmhw_amd.detect(temp, th, se)
+    np.testing.assert_array_equal(first.table, again.table)
+    short = GridSeries(g["sst"][:400], ("time", "lat", "lon"), {"time": time[:400], "lat": g["lat"], "lon": g["lon"]},
+                       time_encoding={"calendar": "proleptic_gregorian"})
+    xmhw_amd.detect(short, th, se)                       # another row table enters the cache
+    hip().release_cached_tables()
+    third = xmhw_amd.detect(temp, th, se)
+    np.testing.assert_array_equal(first.table, third.table)
+    np.testing.assert_array_equal(first.offsets, third.offsets)

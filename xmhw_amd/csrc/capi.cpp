@@ -6,7 +6,10 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -261,17 +264,98 @@ int clim_oneshot(const T* ts, const int32_t* doy, int64_t Tn, int64_t C, int32_t
     return XMHW_OK;
 }
 
-// row_of_t on the device for the duration of one call
-struct DeviceRows {
-    int32_t* ptr = nullptr;
-    hipError_t err = hipSuccess;
-    DeviceRows(const int32_t* host, int64_t Tn, hipStream_t st) {
-        err = hipMalloc(&ptr, sizeof(int32_t) * static_cast<size_t>(Tn));
-        if (err == hipSuccess)
-            err = hipMemcpyAsync(ptr, host, sizeof(int32_t) * static_cast<size_t>(Tn), hipMemcpyHostToDevice, st);
-    }
-    ~DeviceRows() { if (ptr) (void)hipFree(ptr); }
+// ---- per-call tables kept on the device between calls ------------------------------------------
+// Every detect-side entry needs row_of_t (and the tiled exceedance kernel its chunk tables) on the
+// device.  Round 1 allocated, uploaded, synchronised and freed them on every call, which made the
+// "asynchronous" stream argument a fiction.  Now a small cache keyed by the table's content keeps them
+// (uploaded once, with a blocking copy, at the first call that sees them), and scratch buffers are
+// kept per stream and grow on demand: steady-state calls neither allocate nor synchronise.
+struct ChunkTables {
+    int32_t *tile_begin = nullptr, *t0 = nullptr, *i0 = nullptr, *n = nullptr;
+    int32_t ntiles = 0;
+    int64_t nchunks = 0;
 };
+struct RowsEntry {
+    std::vector<int32_t> host;
+    int device = 0;
+    int32_t* d_rows = nullptr;
+    std::map<std::pair<int64_t, int>, ChunkTables> chunks;      // (D, tile) -> tables
+    uint64_t stamp = 0;
+    ~RowsEntry() {
+        if (d_rows) (void)hipFree(d_rows);
+        for (auto& kv : chunks)
+            for (int32_t* p : {kv.second.tile_begin, kv.second.t0, kv.second.i0, kv.second.n})
+                if (p) (void)hipFree(p);
+    }
+};
+std::mutex g_cache_mu;
+std::vector<std::unique_ptr<RowsEntry>> g_rows_cache;
+uint64_t g_stamp = 0;
+constexpr size_t kRowsCacheSlots = 8;
+
+// returns nullptr and sets *err on failure
+RowsEntry* cached_rows(const int32_t* row_of_t, int64_t Tn, hipError_t* err) {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    int dev = 0;
+    *err = hipGetDevice(&dev);
+    if (*err != hipSuccess) return nullptr;
+    for (auto& e : g_rows_cache)
+        if (e->device == dev && static_cast<int64_t>(e->host.size()) == Tn &&
+            std::memcmp(e->host.data(), row_of_t, sizeof(int32_t) * static_cast<size_t>(Tn)) == 0) {
+            e->stamp = ++g_stamp;
+            return e.get();
+        }
+    auto e = std::make_unique<RowsEntry>();
+    e->host.assign(row_of_t, row_of_t + Tn);
+    e->device = dev;
+    *err = hipMalloc(&e->d_rows, sizeof(int32_t) * static_cast<size_t>(Tn));
+    if (*err != hipSuccess) { e->d_rows = nullptr; return nullptr; }
+    *err = hipMemcpy(e->d_rows, row_of_t, sizeof(int32_t) * static_cast<size_t>(Tn), hipMemcpyHostToDevice);
+    if (*err != hipSuccess) return nullptr;
+    if (g_rows_cache.size() >= kRowsCacheSlots) {
+        size_t oldest = 0;
+        for (size_t i = 1; i < g_rows_cache.size(); ++i)
+            if (g_rows_cache[i]->stamp < g_rows_cache[oldest]->stamp) oldest = i;
+        (void)hipDeviceSynchronize();          // nothing in flight may still read the evicted tables
+        g_rows_cache.erase(g_rows_cache.begin() + static_cast<long>(oldest));
+    }
+    e->stamp = ++g_stamp;
+    g_rows_cache.push_back(std::move(e));
+    return g_rows_cache.back().get();
+}
+
+// scratch memory per (device, stream): grows on demand (the only synchronising moment), never shrinks
+struct Scratch { void* ptr = nullptr; size_t cap = 0; };
+std::map<std::pair<int, void*>, Scratch> g_scratch;
+hipError_t scratch_get(hipStream_t st, size_t bytes, void** out) {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    Scratch& sc = g_scratch[{dev, static_cast<void*>(st)}];
+    if (sc.cap < bytes) {
+        if (sc.ptr) {
+            e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return e;
+            (void)hipFree(sc.ptr);
+            sc.ptr = nullptr;
+            sc.cap = 0;
+        }
+        e = hipMalloc(&sc.ptr, bytes);
+        if (e != hipSuccess) { sc.ptr = nullptr; return e; }
+        sc.cap = bytes;
+    }
+    *out = sc.ptr;
+    return hipSuccess;
+}
+void release_cached_tables() {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    (void)hipDeviceSynchronize();
+    g_rows_cache.clear();
+    for (auto& kv : g_scratch)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    g_scratch.clear();
+}
 
 template <typename T>
 int detect_events(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* thresh, int64_t ldt,
@@ -284,15 +368,12 @@ int detect_events(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* 
     if (!ts || !thresh || !row_of_t || !events || !start || !end)
         return fail(XMHW_ERR_INVALID, "NULL buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    DeviceRows rows(row_of_t, Tn, st);
-    hipError_t e = rows.err;
-    if (e == hipSuccess)
-        e = xmhw::launch_detect<T>(ts, Tn, C, ld, thresh, ldt, rows.ptr, min_duration, join_gaps, max_gap, negate,
-                                   events, start, end, bthresh, ldo, nevents, st);
-    // the row table must outlive the kernel: synchronise before releasing it
-    hipError_t e2 = hipStreamSynchronize(st);
+    hipError_t e = hipSuccess;
+    RowsEntry* rows = cached_rows(row_of_t, Tn, &e);
+    if (!rows) return hip_fail(e, "row table upload");
+    e = xmhw::launch_detect<T>(ts, Tn, C, ld, thresh, ldt, rows->d_rows, min_duration, join_gaps, max_gap, negate,
+                               events, start, end, bthresh, ldo, nevents, st);
     if (e != hipSuccess) return hip_fail(e, "detect_events launch");
-    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
     return XMHW_OK;
 }
 
@@ -305,18 +386,15 @@ int event_stats(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* se
     if (!ts || !seas || !thresh || !row_of_t || !events || !offsets)
         return fail(XMHW_ERR_INVALID, "NULL buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    DeviceRows rows(row_of_t, Tn, st);
-    hipError_t e = rows.err;
-    if (e == hipSuccess)
-        e = xmhw::launch_event_stats<T>(ts, Tn, C, ld, seas, thresh, ldc, rows.ptr, negate, events, ldo, offsets,
-                                        table, st);
-    hipError_t e2 = hipStreamSynchronize(st);
+    hipError_t e = hipSuccess;
+    RowsEntry* rows = cached_rows(row_of_t, Tn, &e);
+    if (!rows) return hip_fail(e, "row table upload");
+    e = xmhw::launch_event_stats<T>(ts, Tn, C, ld, seas, thresh, ldc, rows->d_rows, negate, events, ldo, offsets, table, st);
     if (e != hipSuccess) return hip_fail(e, "event_stats launch");
-    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
     return XMHW_OK;
 }
 
-static int g_exceed_kernel = 0;   // 0 auto, 1 per-step kernel, 2 tiled kernel (xmhw_set_exceed_kernel)
+static std::atomic<int> g_exceed_kernel{0};   // 0 auto, 1 per-step kernel, 2 tiled kernel (xmhw_set_exceed_kernel)
 
 // Chunks for exceed_bits_tiled: maximal segments of consecutive steps with consecutive rows inside one
 // tile of `tile` rows, grouped by tile (time order kept inside a tile).
@@ -350,18 +428,6 @@ struct ExceedChunks {
     }
 };
 
-struct DeviceI32 {
-    int32_t* ptr = nullptr;
-    hipError_t err = hipSuccess;
-    DeviceI32(const std::vector<int32_t>& v, hipStream_t st) {
-        const size_t bytes = sizeof(int32_t) * (v.empty() ? 1 : v.size());
-        err = hipMalloc(&ptr, bytes);
-        if (err == hipSuccess && !v.empty())
-            err = hipMemcpyAsync(ptr, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice, st);
-    }
-    ~DeviceI32() { if (ptr) (void)hipFree(ptr); }
-};
-
 template <typename T>
 int exceed_bits(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* thresh, int64_t ldt, int64_t D,
                 const int32_t* row_of_t, int32_t negate, uint64_t* bits, int64_t ldb, void* stream) {
@@ -373,65 +439,76 @@ int exceed_bits(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* th
         if (row_of_t[t] < 0 || row_of_t[t] >= D) return fail(XMHW_ERR_INVALID, "row_of_t outside [0, D)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     constexpr int kTile = sizeof(T) == 4 ? 64 : 32;
-    const ExceedChunks ch(row_of_t, Tn, D, kTile);
+    hipError_t e = hipSuccess;
+    RowsEntry* rows = cached_rows(row_of_t, Tn, &e);
+    if (!rows) return hip_fail(e, "row table upload");
+    // chunk tables of the tiled kernel: built and uploaded once per (row table, D, tile)
+    ChunkTables* ct = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        auto key = std::make_pair(D, kTile);
+        auto it = rows->chunks.find(key);
+        if (it == rows->chunks.end()) {
+            const ExceedChunks ch(row_of_t, Tn, D, kTile);
+            ChunkTables t;
+            t.ntiles = ch.ntiles;
+            t.nchunks = static_cast<int64_t>(ch.t0.size());
+            auto put = [&](int32_t** dst, const std::vector<int32_t>& v) -> hipError_t {
+                const size_t bytes = sizeof(int32_t) * (v.empty() ? 1 : v.size());
+                hipError_t err = hipMalloc(dst, bytes);
+                if (err == hipSuccess && !v.empty()) err = hipMemcpy(*dst, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice);
+                return err;
+            };
+            for (auto pr : {std::make_pair(&t.tile_begin, &ch.tile_begin), std::make_pair(&t.t0, &ch.t0),
+                            std::make_pair(&t.i0, &ch.i0), std::make_pair(&t.n, &ch.n)})
+                if (e == hipSuccess) e = put(pr.first, *pr.second);
+            if (e != hipSuccess) return hip_fail(e, "chunk table upload");
+            it = rows->chunks.emplace(key, t).first;
+        }
+        ct = &it->second;
+    }
     // The tiled kernel pays one pass over its unrolled tile per chunk: worth it when chunks are long
     // (calendar-like labels); an arbitrary label sequence falls back to the per-step kernel.
     // One thread walks all tiles of a cell, so small grids (too few workgroups to fill 256 CUs) keep the
     // per-step kernel, which also splits the time axis over blocks.
-    const bool tiled = g_exceed_kernel == 2 ||
-                       (g_exceed_kernel == 0 && static_cast<int64_t>(ch.t0.size()) * kTile <= 4 * Tn && C >= 131072);
+    const int mode = g_exceed_kernel.load();
+    const bool tiled = mode == 2 || (mode == 0 && ct->nchunks * kTile <= 4 * Tn && C >= 131072);
     const int64_t W = (Tn + 63) / 64;
-    hipError_t e = hipSuccess;
     float* thf = nullptr;
     if constexpr (sizeof(T) == 4) {
         // float32 series: compare against the float32 floor of the thresholds (same results, see
-        // kernels_events.hip), 4 instead of 8 bytes per threshold
-        // only the addressed (D, C) region is converted: `thresh` may point into a wider array
-        // (column block k0 of a (D, ldt) climatology), where D * ldt elements would overrun it
-        HIP_TRY(hipMalloc(&thf, sizeof(float) * static_cast<size_t>(D) * static_cast<size_t>(C)));
+        // kernels_events.hip), 4 instead of 8 bytes per threshold.  Only the addressed (D, C) region is
+        // converted: `thresh` may point into a wider array (column block k0 of a (D, ldt) climatology),
+        // where D * ldt elements would overrun it.  The copy lives in this stream's scratch buffer.
+        void* sp = nullptr;
+        e = scratch_get(st, sizeof(float) * static_cast<size_t>(D) * static_cast<size_t>(C), &sp);
+        if (e != hipSuccess) return hip_fail(e, "scratch allocation");
+        thf = static_cast<float*>(sp);
         e = xmhw::launch_floor_to_f32(thresh, D, C, ldt, thf, C, st);
+        if (e != hipSuccess) return hip_fail(e, "floor_to_f32 launch");
     }
     const int64_t ldtf = sizeof(T) == 4 ? C : ldt;   // leading dimension of the thresholds the kernels read
-    if (e == hipSuccess && tiled) {
-        DeviceI32 d_tb(ch.tile_begin, st), d_t0(ch.t0, st), d_i0(ch.i0, st), d_n(ch.n, st);
-        for (const DeviceI32* d : {&d_tb, &d_t0, &d_i0, &d_n})
-            if (d->err != hipSuccess) e = d->err;
-        if (e == hipSuccess)
-            e = ldb == C ? hipMemsetAsync(bits, 0, sizeof(uint64_t) * static_cast<size_t>(W) * static_cast<size_t>(C), st)
-                         : hipMemset2DAsync(bits, sizeof(uint64_t) * static_cast<size_t>(ldb), 0,
-                                            sizeof(uint64_t) * static_cast<size_t>(C), static_cast<size_t>(W), st);
+    if (tiled) {
+        e = ldb == C ? hipMemsetAsync(bits, 0, sizeof(uint64_t) * static_cast<size_t>(W) * static_cast<size_t>(C), st)
+                     : hipMemset2DAsync(bits, sizeof(uint64_t) * static_cast<size_t>(ldb), 0,
+                                        sizeof(uint64_t) * static_cast<size_t>(C), static_cast<size_t>(W), st);
         if (e == hipSuccess) {
             if constexpr (sizeof(T) == 4)
-                e = xmhw::launch_exceed_bits_tiled<float, float, 64>(ts, C, ld, thf, ldtf, D, d_tb.ptr, ch.ntiles,
-                                                                     d_t0.ptr, d_i0.ptr, d_n.ptr, negate, bits, ldb, st);
+                e = xmhw::launch_exceed_bits_tiled<float, float, 64>(ts, C, ld, thf, ldtf, D, ct->tile_begin, ct->ntiles,
+                                                                     ct->t0, ct->i0, ct->n, negate, bits, ldb, st);
             else
-                e = xmhw::launch_exceed_bits_tiled<double, double, 32>(ts, C, ld, thresh, ldt, D, d_tb.ptr, ch.ntiles,
-                                                                       d_t0.ptr, d_i0.ptr, d_n.ptr, negate, bits, ldb,
-                                                                       st);
+                e = xmhw::launch_exceed_bits_tiled<double, double, 32>(ts, C, ld, thresh, ldt, D, ct->tile_begin, ct->ntiles,
+                                                                       ct->t0, ct->i0, ct->n, negate, bits, ldb, st);
         }
-        hipError_t e2 = hipStreamSynchronize(st);
-        if (thf) (void)hipFree(thf);
         if (e != hipSuccess) return hip_fail(e, "exceed_bits_tiled launch");
-        if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
         return XMHW_OK;
     }
-    if (e == hipSuccess) {
-        DeviceRows rows(row_of_t, Tn, st);
-        e = rows.err;
-        if (e == hipSuccess) {
-            if constexpr (sizeof(T) == 4)
-                e = xmhw::launch_exceed_bits<float, float>(ts, Tn, C, ld, thf, ldtf, rows.ptr, negate, bits, ldb, st);
-            else
-                e = xmhw::launch_exceed_bits<double, double>(ts, Tn, C, ld, thresh, ldt, rows.ptr, negate, bits, ldb, st);
-        }
-        hipError_t e2 = hipStreamSynchronize(st);
-        if (thf) (void)hipFree(thf);
-        if (e != hipSuccess) return hip_fail(e, "exceed_bits launch");
-        if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
-        return XMHW_OK;
-    }
-    if (thf) (void)hipFree(thf);
-    return hip_fail(e, "exceed_bits setup");
+    if constexpr (sizeof(T) == 4)
+        e = xmhw::launch_exceed_bits<float, float>(ts, Tn, C, ld, thf, ldtf, rows->d_rows, negate, bits, ldb, st);
+    else
+        e = xmhw::launch_exceed_bits<double, double>(ts, Tn, C, ld, thresh, ldt, rows->d_rows, negate, bits, ldb, st);
+    if (e != hipSuccess) return hip_fail(e, "exceed_bits launch");
+    return XMHW_OK;
 }
 
 template <typename T>
@@ -442,13 +519,11 @@ int event_stats_sparse(const T* ts, int64_t Tn, int64_t C, int64_t ld, const dou
     if (n_events == 0) return XMHW_OK;
     if (!ts || !seas || !thresh || !row_of_t || !table) return fail(XMHW_ERR_INVALID, "NULL buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    DeviceRows rows(row_of_t, Tn, st);
-    if (rows.err != hipSuccess) return hip_fail(rows.err, "row_of_t upload");
-    hipError_t e = xmhw::launch_event_stats_sparse<T>(ts, Tn, ld, seas, thresh, ldc, rows.ptr, negate, n_events,
-                                                      table, st);
-    hipError_t e2 = hipStreamSynchronize(st);
+    hipError_t e = hipSuccess;
+    RowsEntry* rows = cached_rows(row_of_t, Tn, &e);
+    if (!rows) return hip_fail(e, "row table upload");
+    e = xmhw::launch_event_stats_sparse<T>(ts, Tn, ld, seas, thresh, ldc, rows->d_rows, negate, n_events, table, st);
     if (e != hipSuccess) return hip_fail(e, "event_stats_sparse launch");
-    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
     return XMHW_OK;
 }
 
@@ -461,14 +536,12 @@ int event_intermediate(const T* ts, int64_t Tn, int64_t C, int64_t ld, const dou
     if (C == 0) return XMHW_OK;
     if (!ts || !seas || !thresh || !row_of_t || !events || !out || !dur) return fail(XMHW_ERR_INVALID, "NULL buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    DeviceRows rows(row_of_t, Tn, st);
-    hipError_t e = rows.err;
-    if (e == hipSuccess)
-        e = xmhw::launch_event_intermediate<T>(ts, Tn, C, ld, seas, thresh, ldc, rows.ptr, negate, events, ldo, out,
-                                               ldv, dur, st);
-    hipError_t e2 = hipStreamSynchronize(st);
+    hipError_t e = hipSuccess;
+    RowsEntry* rows = cached_rows(row_of_t, Tn, &e);
+    if (!rows) return hip_fail(e, "row table upload");
+    e = xmhw::launch_event_intermediate<T>(ts, Tn, C, ld, seas, thresh, ldc, rows->d_rows, negate, events, ldo, out, ldv, dur,
+                                           st);
     if (e != hipSuccess) return hip_fail(e, "event_intermediate launch");
-    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
     return XMHW_OK;
 }
 
@@ -901,6 +974,22 @@ int xmhw_event_stats_f32(const float* ts, int64_t T, int64_t C, int64_t ld, cons
                          const double* thresh, int64_t ldc, const int32_t* row_of_t, int32_t negate,
                          const int32_t* events, int64_t ldo, const int64_t* offsets, double* table, void* stream) {
     return event_stats<float>(ts, T, C, ld, seas, thresh, ldc, row_of_t, negate, events, ldo, offsets, table, stream);
+}
+int xmhw_release_cached_tables(void) {
+    release_cached_tables();
+    return XMHW_OK;
+}
+int xmhw_offsets_from_counts(const int32_t* counts_dev, int64_t n, int64_t* offsets_dev, void* stream) {
+    if (n < 0) return fail(XMHW_ERR_INVALID, "n must be >= 0");
+    if (!offsets_dev || (n > 0 && !counts_dev)) return fail(XMHW_ERR_INVALID, "NULL buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    void* sp = nullptr;
+    const int64_t nblocks = (n + 1023) / 1024;
+    hipError_t e = scratch_get(st, sizeof(int64_t) * static_cast<size_t>(nblocks + 1), &sp);
+    if (e != hipSuccess) return hip_fail(e, "scratch allocation");
+    e = xmhw::launch_offsets_from_counts(counts_dev, n, offsets_dev, static_cast<int64_t*>(sp), st);
+    if (e != hipSuccess) return hip_fail(e, "offsets_from_counts launch");
+    return XMHW_OK;
 }
 int xmhw_set_exceed_kernel(int32_t mode) {
     if (mode < 0 || mode > 2) return fail(XMHW_ERR_INVALID, "mode must be 0 (auto), 1 (per-step) or 2 (tiled)");

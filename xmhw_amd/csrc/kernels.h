@@ -106,6 +106,11 @@ hipError_t launch_event_stats_sparse(const T* ts, int64_t Tn, int64_t ld, const 
                                      int64_t ldc, const int32_t* row_of_t, int32_t negate, int64_t n_events,
                                      double* table, hipStream_t stream);
 
+// exclusive prefix sum of per-cell event counts into int64 table offsets [n+1]; block_sums: scratch of
+// (n + 1023) / 1024 + 1 int64
+hipError_t launch_offsets_from_counts(const int32_t* counts, int64_t n, int64_t* offsets, int64_t* block_sums,
+                                      hipStream_t stream);
+
 // per-step columns of mhw_df(): out [8][T][ldv] f64, dur [4][T][ldv] u8
 template <typename T>
 hipError_t launch_event_intermediate(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* seas,

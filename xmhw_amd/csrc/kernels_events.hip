@@ -367,4 +367,83 @@ template hipError_t launch_event_stats_sparse<double>(const double*, int64_t, in
                                                       int64_t, const int32_t*, int32_t, int64_t, double*,
                                                       hipStream_t);
 
+// ---------------------------------------------------------------------------
+// offsets_from_counts: exclusive prefix sum of the per-cell event counts (int32) into int64 table
+// offsets, on the device -- the count pass and the fill pass of events_from_bits no longer meet on
+// the host.  Three small launches: sums of 1024-element blocks, a scan of the block sums by one
+// workgroup, the scan inside every block.
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int kScanBlock = 1024;
+
+__device__ __forceinline__ int64_t wave_incl_scan(int64_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+// inclusive scan over the 1024 threads of a workgroup; returns the thread's inclusive value, *total = block sum
+__device__ __forceinline__ int64_t block_incl_scan(int64_t v, int64_t* total) {
+    __shared__ int64_t wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t inc = wave_incl_scan(v, lane);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        int64_t w = lane < 16 ? wsum[lane] : 0;
+        w = wave_incl_scan(w, lane);
+        if (lane < 16) wsum[lane] = w;
+    }
+    __syncthreads();
+    const int64_t base = wave ? wsum[wave - 1] : 0;
+    *total = wsum[15];
+    __syncthreads();
+    return inc + base;
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_block_sums(const int32_t* __restrict__ counts, int64_t n,
+                                                             int64_t* __restrict__ sums) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kScanBlock + threadIdx.x;
+    int64_t total;
+    block_incl_scan(i < n ? counts[i] : 0, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kScanBlock) void scan_of_sums(int64_t* __restrict__ sums, int64_t nblocks) {
+    // one workgroup: exclusive scan in place, sums[nblocks] = grand total
+    int64_t carry = 0;
+    for (int64_t b0 = 0; b0 < nblocks; b0 += kScanBlock) {
+        const int64_t i = b0 + threadIdx.x;
+        const int64_t v = i < nblocks ? sums[i] : 0;
+        int64_t total;
+        const int64_t inc = block_incl_scan(v, &total);
+        if (i < nblocks) sums[i] = carry + inc - v;
+        carry += total;
+    }
+    if (threadIdx.x == 0) sums[nblocks] = carry;
+}
+__global__ __launch_bounds__(kScanBlock) void scan_apply(const int32_t* __restrict__ counts, int64_t n,
+                                                        const int64_t* __restrict__ sums, int64_t nblocks,
+                                                        int64_t* __restrict__ offsets) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kScanBlock + threadIdx.x;
+    const int64_t v = i < n ? counts[i] : 0;
+    int64_t total;
+    const int64_t inc = block_incl_scan(v, &total);
+    if (i < n) offsets[i] = sums[blockIdx.x] + inc - v;
+    if (i == 0) offsets[n] = sums[nblocks];
+}
+}  // namespace
+
+hipError_t launch_offsets_from_counts(const int32_t* counts, int64_t n, int64_t* offsets, int64_t* block_sums,
+                                      hipStream_t stream) {
+    const int64_t nblocks = (n + kScanBlock - 1) / kScanBlock;
+    if (n == 0) return hipMemsetAsync(offsets, 0, sizeof(int64_t), stream);
+    hipLaunchKernelGGL(scan_block_sums, dim3(static_cast<unsigned>(nblocks)), dim3(kScanBlock), 0, stream, counts, n, block_sums);
+    hipLaunchKernelGGL(scan_of_sums, dim3(1), dim3(kScanBlock), 0, stream, block_sums, nblocks);
+    hipLaunchKernelGGL(scan_apply, dim3(static_cast<unsigned>(nblocks)), dim3(kScanBlock), 0, stream, counts, n, block_sums,
+                       nblocks, offsets);
+    return hipGetLastError();
+}
+
 }  // namespace xmhw

@@ -440,6 +440,11 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     }, py::arg("ts"), py::arg("itemsize"), py::arg("T"), py::arg("C"), py::arg("ld"), py::arg("cats"), py::arg("ldcat"),
        py::arg("bin_of_t"), py::arg("nbins"), py::arg("out"), py::arg("ldo"), py::arg("stream") = 0);
 
+    m.def("release_cached_tables", []() { check(xmhw_release_cached_tables()); });
+    m.def("offsets_from_counts", [](uintptr_t counts, int64_t n, uintptr_t offsets, uintptr_t stream) {
+        check(xmhw_offsets_from_counts(static_cast<const int32_t*>(vp(counts)), n, static_cast<int64_t*>(vp(offsets)), vp(stream)));
+    }, py::arg("counts"), py::arg("n"), py::arg("offsets"), py::arg("stream") = 0);
+
     m.def("synth_sst", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
                           double nan_frac, uintptr_t stream) {
         if (itemsize == 4)

@@ -93,7 +93,7 @@ def _check_inputs(ts, seas, thresh, doy, doys):
 def _table_only_device(h, d_ts, isz, se_ptr, th_ptr, ldc, D, rows, T, n, neg, minDuration, joinGaps, maxGap):
     """Event table of n cells whose dense (T, n) series and climatologies (device pointers to the
     first of the n columns, leading dimension ldc) are already on the device, without per-step
-    outputs: exceedance bits -> run walk (count, host prefix sum, fill) -> one thread per event
+    outputs: exceedance bits -> run walk (count, device prefix sum, fill) -> one thread per event
     (csrc/kernels_events.hip)."""
     bufs = []
     try:
@@ -105,14 +105,16 @@ def _table_only_device(h, d_ts, isz, se_ptr, th_ptr, ldc, D, rows, T, n, neg, mi
             h.events_from_bits(d_bits.ptr, T, n, n, int(minDuration), int(bool(joinGaps)), int(maxGap), 0, d_n.ptr, 0)
         except h.InvalidArgument as e:
             raise XmhwException(str(e)) from e
-        h.stream_sync(0)
+        # table offsets = exclusive prefix sum of the counts, on the device; the host only learns the
+        # total (8 bytes) to size the table, and takes the counts along for its own bookkeeping
+        d_off = DeviceBuffer(8 * (n + 1)); bufs.append(d_off)
+        h.offsets_from_counts(d_n.ptr, n, d_off.ptr)
+        total = np.empty(1, dtype=np.int64)
+        h.memcpy_d2h(total, d_off.ptr + 8 * n)          # synchronises the stream
+        ntot = int(total[0])
         counts = d_n.to_array((n,), np.int32)
-        offs = np.zeros(n + 1, dtype=np.int64)
-        np.cumsum(counts, out=offs[1:])
-        ntot = int(offs[-1])
         if ntot == 0:
             return np.zeros((0, h.EVENT_COLUMNS)), counts
-        d_off = DeviceBuffer.from_array(offs); bufs.append(d_off)
         d_tab = DeviceBuffer(8 * ntot * h.EVENT_COLUMNS); bufs.append(d_tab)
         h.events_from_bits(d_bits.ptr, T, n, n, int(minDuration), int(bool(joinGaps)), int(maxGap), d_off.ptr, 0,
                            d_tab.ptr)
