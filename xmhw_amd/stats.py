@@ -131,8 +131,20 @@ def block_average(mhw, dstime=None, period=None, blockLength=1, mtime="time_star
             ts = tsg.reshape(tsg.shape[0], 1)
             cats = None if catg is None else catg.reshape(catg.shape[0], 1)
         else:
-            ts = tsg.reshape(tsg.shape[0], -1)[:, mhw.cell_index]
-            cats = None if catg is None else catg.reshape(catg.shape[0], -1)[:, mhw.cell_index]
+            # the series either covers the full grid the events were detected on, or (InterDataset, a
+            # ClimDataset-shaped input) the grid without its all-land lines
+            alive = _alive_axes(mhw.keep, mhw.sshape)
+            cshape = tuple(int(m.sum()) for m in alive)
+            if tuple(tsg.shape[1:]) == tuple(mhw.sshape):
+                flat = mhw.cell_index
+            elif tuple(tsg.shape[1:]) == cshape:
+                sub = np.unravel_index(mhw.cell_index, mhw.sshape)
+                ranks = [np.cumsum(m) - 1 for m in alive]
+                flat = np.ravel_multi_index(tuple(r[i] for r, i in zip(ranks, sub)), cshape)
+            else:
+                raise XmhwException(f"dstime has grid {tuple(tsg.shape[1:])}, the events were detected on {tuple(mhw.sshape)}")
+            ts = tsg.reshape(tsg.shape[0], -1)[:, flat]
+            cats = None if catg is None else catg.reshape(catg.shape[0], -1)[:, flat]
         period = [int(years[0]), int(years[-1])]                                 # stats.py:106-109
     if removeMissing and not sw_temp:                                             # stats.py:112-116
         raise XmhwException("To remove missing values you need to pass "
