@@ -60,6 +60,7 @@ struct xmhw_plan {
     int32_t nchunks = 0;
     uint32_t* d_table = nullptr;
     int32_t yps2 = 0;         // second-generation float32 ring kernel (kernels_ring2.hip), 0: not available
+    int32_t subs2 = 0;        // ... and its lanes per cell (8, or 4 for variant 7)
     int32_t ring2_variant = 0;    // -1: off (round-1 kernel); 0: lean steps; 1: + 8-bit SAD probes (slower, kept as a measured variant)
     uint32_t* d_table2 = nullptr;
     uint32_t* d_sflags = nullptr;
@@ -108,7 +109,10 @@ int32_t auto_chunks(const xmhw_plan* p, int64_t C) {
 int upload(xmhw_plan* p, int64_t C) {
     std::lock_guard<std::mutex> lock(p->mu);
     const int32_t nchunks = auto_chunks(p, C);
-    if (p->uploaded && nchunks == p->nchunks) return XMHW_OK;
+    if (p->uploaded && nchunks == p->nchunks &&
+        p->subs2 == xmhw::ring2_subs(p->ring2_variant) &&
+        p->yps2 == (p->ring2_variant >= 0 ? xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, p->ring2_variant) : 0))
+        return XMHW_OK;
     const xmhw::Plan& h = p->host;
     if (!p->uploaded) {
         // every table is allocated at most once: a failed upload can be retried without leaking
@@ -124,13 +128,24 @@ int upload(xmhw_plan* p, int64_t C) {
         HIP_TRY(put(&p->d_centres, h.centres));
         p->yps = xmhw::ring_pick(h.w, h.ntracks, 4, &p->subs);
         if (p->yps) HIP_TRY(put(&p->d_table, h.ring_table(p->subs, p->yps)));
-        p->yps2 = xmhw::ring2_pick_yps(h.w, h.ntracks);
-        if (p->yps2) {
-            HIP_TRY(put(&p->d_table2, h.ring_table(8, p->yps2)));
-            HIP_TRY(put(&p->d_sflags, h.step_flags()));
-        }
+        HIP_TRY(put(&p->d_sflags, h.step_flags()));
         p->yps64 = xmhw::ring64_pick_yps(h.w, h.ntracks);
         if (p->yps64) HIP_TRY(put(&p->d_table64, h.ring_table(16, p->yps64)));
+    }
+    // the second-generation ring kernel's table depends on the variant's lanes per cell
+    {
+        const int32_t subs2 = xmhw::ring2_subs(p->ring2_variant);
+        const int32_t yps2 = p->ring2_variant >= 0 ? xmhw::ring2_pick_yps(h.w, h.ntracks, p->ring2_variant) : 0;
+        if (yps2 != p->yps2 || subs2 != p->subs2) {
+            if (p->d_table2) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p->d_table2)); p->d_table2 = nullptr; }
+            p->yps2 = yps2;
+            p->subs2 = subs2;
+            if (yps2) {
+                const std::vector<uint32_t> t2 = h.ring_table(subs2, yps2);
+                HIP_TRY(hipMalloc(&p->d_table2, sizeof(uint32_t) * t2.size()));
+                HIP_TRY(hipMemcpy(p->d_table2, t2.data(), sizeof(uint32_t) * t2.size(), hipMemcpyHostToDevice));
+            }
+        }
     }
     if (p->yps || p->yps64 || p->yps2) {
         std::vector<xmhw::Chunk> ch = h.make_chunks(nchunks);
@@ -770,14 +785,14 @@ int xmhw_plan_create(const int32_t* doy_host, int64_t T, int32_t window_half_wid
 }
 int xmhw_plan_set_ring2(xmhw_plan* plan, int32_t variant) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
-    if (variant < -1 || variant > 6) return fail(XMHW_ERR_INVALID, "ring2 variant must be -1 (off) or 0..6");
+    if (variant < -1 || variant > 7) return fail(XMHW_ERR_INVALID, "ring2 variant must be -1 (off) or 0..7");
     plan->ring2_variant = variant;
     return XMHW_OK;
 }
 int xmhw_plan_ring2_in_use(const xmhw_plan* plan, int32_t* variant) {
     if (!plan || !variant) return fail(XMHW_ERR_INVALID, "NULL argument");
     const bool ring = resolve_kernel(plan, 4) == XMHW_KERNEL_RING;
-    *variant = (ring && plan->ring2_variant >= 0 && xmhw::ring2_pick_yps(plan->host.w, plan->host.ntracks) > 0)
+    *variant = (ring && plan->ring2_variant >= 0 && xmhw::ring2_pick_yps(plan->host.w, plan->host.ntracks, plan->ring2_variant) > 0)
                    ? plan->ring2_variant : -1;
     return XMHW_OK;
 }

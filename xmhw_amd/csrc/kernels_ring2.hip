@@ -46,10 +46,13 @@ __device__ __forceinline__ uint32_t dpp2(uint32_t v) {
 }
 constexpr int kR8 = 0x128, kR4 = 0x124, kR2 = 0x122;
 
+// lanes of a cell sit in one 16-lane DPP row: 8 subs at stride 2 (8 cells per wave) or 4 subs at
+// stride 4 (16 cells per wave); the all-reduce is 3 or 2 row rotations
+template <int SUBS>
 __device__ __forceinline__ uint32_t cell_sum(uint32_t v) {
     v += dpp2<kR8>(v);
     v += dpp2<kR4>(v);
-    v += dpp2<kR2>(v);
+    if constexpr (SUBS == 8) v += dpp2<kR2>(v);
     return v;
 }
 template <int CTRL>
@@ -59,10 +62,11 @@ __device__ __forceinline__ double dpp2_f64(double v) {
     const uint32_t hi = dpp2<CTRL>(static_cast<uint32_t>(b >> 32));
     return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
 }
+template <int SUBS>
 __device__ __forceinline__ double cell_sum(double v) {
     v += dpp2_f64<kR8>(v);
     v += dpp2_f64<kR4>(v);
-    v += dpp2_f64<kR2>(v);
+    if constexpr (SUBS == 8) v += dpp2_f64<kR2>(v);
     return v;
 }
 __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
@@ -186,10 +190,11 @@ struct Top2 {
             }
         }
     }
+    template <int SUBS>
     __device__ __forceinline__ void merge_cell() {
         merge<kR8>();
         merge<kR4>();
-        merge<kR2>();
+        if constexpr (SUBS == 8) merge<kR2>();
     }
     __device__ __forceinline__ uint32_t at(uint32_t j) const {
         // a chain of selects; the empty asm keeps the compiler from turning it into a dynamically
@@ -216,7 +221,7 @@ constexpr int kBudget2 = 6;
 
 // sflags[step]: bit 0 = SIMPLE (every real track pushes a valid sample and is counted; padded
 // tracks push invalid).  ntracks = real tracks (tracks >= ntracks are padding).
-template <int W, int YPS, int PB, int JX, bool STATS>
+template <int W, int YPS, int PB, int JX, int SUBS, bool STATS>
 __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, int32_t step_min, const DevChunk* __restrict__ chunks, double q,
@@ -224,8 +229,9 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     unsigned long long* __restrict__ stats) {
     static_assert(W == 5, "count_le11 is written for an 11-sample window");
     constexpr int R = 2 * W + 1;
-    constexpr int SUBS = 8;
+    static_assert(SUBS == 8 || SUBS == 4, "8 lanes per cell (8 cells per wave) or 4 (16 cells per wave)");
     constexpr int NTP = SUBS * YPS;
+    constexpr int CPWAVE = 64 / SUBS;            // cells per wave
     // PB: width of the code ring the bracket is closed on (0: none, 32-bit count passes only; 8; 16);
     // JX: extraction width (the window of acceptable ranks is JX - 1 wide)
     static_assert(PB == 0 || PB == 8 || PB == 16, "code ring of 8 or 16 bits");
@@ -239,12 +245,13 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     constexpr uint32_t ALLC = (1u << YPS) - 1u;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int sub = (lane >> 1) & 7;
-    const int cw = (lane & 1) | ((lane >> 4) << 1);
-    const int64_t cell = (static_cast<int64_t>(blockIdx.x) * kWaves2 + wave) * 8 + cw;
+    // lane = (c / k) * 16 + sub * k + (c % k) with k = 16 / SUBS cells per DPP row
+    const int sub = SUBS == 8 ? (lane >> 1) & 7 : (lane >> 2) & 3;
+    const int cw = SUBS == 8 ? (lane & 1) | ((lane >> 4) << 1) : (lane & 3) | ((lane >> 4) << 2);
+    const int64_t cell = (static_cast<int64_t>(blockIdx.x) * kWaves2 + wave) * CPWAVE + cw;
     const bool cell_ok = cell < C;
     const DevChunk ch = chunks[blockIdx.y];
-    const uint32_t* tab = table + sub;           // y-major: entry of slot y at tab[step * NTP + y * 8]
+    const uint32_t* tab = table + sub;           // y-major: entry of slot y at tab[step * NTP + y * SUBS]
     const float* col = ts + (cell_ok ? cell : C - 1);
     const uint32_t negmask = negate ? 0xFFFFFFFFu : 0u;
     const uint32_t tmax = static_cast<uint32_t>(Tn - 1);
@@ -261,30 +268,38 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     double lsum = 0.0;        // sum of the valid samples in this lane's rings (all tracks)
     uint32_t nval = 0;        // number of valid keys in this lane's rings (all tracks)
 
-    auto load_entries = [&](int32_t s, uint32_t (&e)[YPS]) {
-        const uint32_t* p = tab + static_cast<int64_t>(s - step_min) * NTP;
+    // Sample addressing.  The step table (plan.h) names the time step every track pushes at every step;
+    // on the steps the host flags CONSEC every real track simply pushes the sample after the one it
+    // pushed at the previous step, so the per-track pointers advance by one row and the table is not
+    // read at all (all but ~30 of the 376 steps of a daily axis).  Otherwise the step's entries are read
+    // on the spot (a dependent load, exposed, but rare).  Loads are unconditional: hold / invalid codes
+    // wrap to a huge index and are clamped to the last row (a wasted but harmless read); what the
+    // sample means is decided when it is consumed.  A padded slot keeps its clamped address (stride 0).
+    uint32_t tix[YPS];        // time index of the sample most recently requested for each track
+    const uint32_t last_step = padded_last ? 0u : 1u;
+    auto entries_of = [&](int32_t step, uint32_t (&e)[YPS]) {
+        const uint32_t* p = tab + static_cast<int64_t>(step - step_min) * NTP;
 #pragma unroll
         for (int y = 0; y < YPS; ++y) e[y] = p[y * SUBS];
     };
-    // unconditional loads: hold / invalid codes wrap to a huge index and are clamped to the last
-    // row (a wasted but harmless read); what the sample means is decided when it is consumed
-    auto load_samples = [&](const uint32_t (&e)[YPS], float (&x)[YPS]) {
+    auto point_at = [&](int32_t step) {
+        uint32_t e[YPS];
+        entries_of(step, e);
 #pragma unroll
-        for (int y = 0; y < YPS; ++y) {
-            const uint32_t t = minu((e[y] >> 1) - 2u, tmax);
-            x[y] = col[static_cast<int64_t>(t) * ld];
-        }
+        for (int y = 0; y < YPS; ++y) tix[y] = minu((e[y] >> 1) - 2u, tmax);
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) tix[y] += (y == YPS - 1) ? last_step : 1u;
+    };
+    auto request = [&](float (&x)[YPS]) {
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) x[y] = col[static_cast<int64_t>(tix[y]) * ld];
     };
 
-    uint32_t e_cur[YPS], e_nxt[YPS];
     float x_cur[YPS];
-    load_entries(ch.warm_start, e_cur);
-    load_samples(e_cur, x_cur);
-    if (ch.warm_start + 1 < ch.end) load_entries(ch.warm_start + 1, e_nxt);
-    else {
-#pragma unroll
-        for (int y = 0; y < YPS; ++y) e_nxt[y] = make_entry(kCodeInvalid, false);
-    }
+    point_at(ch.warm_start);
+    request(x_cur);
 
     int m = (ch.warm_start - step_min) % R;
     // carried across rows, uniform over the 8 lanes of a cell (kept as integers, not as lane masks)
@@ -309,14 +324,16 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     while (s < ch.end) {
     bool rotate = false;
     for (; s < ch.end && !rotate; ++s) {
-        // ---- prefetch: samples of step s+1, table entries of step s+2 ------------
+        // ---- prefetch: the samples of step s+1 (consumed one row later) ------------------
         float x_nxt[YPS];
-        uint32_t e_nn[YPS];
-        load_samples(e_nxt, x_nxt);
-        if (s + 2 < ch.end) load_entries(s + 2, e_nn);
-        else {
+        if (s + 1 < ch.end) {
+            const uint32_t sfn = __builtin_amdgcn_readfirstlane(sflags[s + 1 - step_min]);
+            if (sfn & 2u) advance();
+            else point_at(s + 1);
+            request(x_nxt);
+        } else {
 #pragma unroll
-            for (int y = 0; y < YPS; ++y) e_nn[y] = make_entry(kCodeInvalid, false);
+            for (int y = 0; y < YPS; ++y) x_nxt[y] = 0.0f;
         }
         const uint32_t sf = __builtin_amdgcn_readfirstlane(sflags[s - step_min]);
 
@@ -336,7 +353,20 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
 #pragma unroll
             for (int y = 0; y < YPS; ++y) kin[y] = key_of_bits(__float_as_uint(x_cur[y]), negmask);
             kin[YPS - 1] |= padmask;
+        } else if (sf & 1u) {
+            // a simple step by the table, but a NaN was loaded or invalid keys sit in the rings: every
+            // real track pushes and is pooled, only the samples need looking at
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) {
+                const float xv = x_cur[y];
+                const bool ok = cell_ok && xv == xv;
+                kin[y] = ok ? key_of_bits(__float_as_uint(xv), negmask) : kInv;
+            }
+            kin[YPS - 1] |= padmask;
         } else {
+            // calendar edges, Feb 29, chunk warm-up: decode the step's table entries
+            uint32_t e_cur[YPS];
+            entries_of(s, e_cur);
             cmask = 0;
 #pragma unroll
             for (int y = 0; y < YPS; ++y) {
@@ -440,8 +470,8 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
             uint32_t n;
             double total;
             if (wallc) {
-                n = cell_sum(nval);
-                total = cell_sum(lsum);
+                n = cell_sum<SUBS>(nval);
+                total = cell_sum<SUBS>(lsum);
             } else {
                 // Feb-29 style rows: only the counted tracks are pooled; count and sum them afresh
                 uint32_t nl = 0;
@@ -460,8 +490,8 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                     nl += cnt ? cy : 0u;
                     tl += cnt ? ty : 0.0;
                 }
-                n = cell_sum(nl);
-                total = cell_sum(tl);
+                n = cell_sum<SUBS>(nl);
+                total = cell_sum<SUBS>(tl);
             }
             if (__any(!(fabs(total) <= 1.7976931348623157e308))) {
                 // an infinite sample went through the running sum (inf - inf = NaN once it leaves):
@@ -476,9 +506,9 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                     tl += ((cmask >> y) & 1u) ? ty : 0.0;
                 }
                 lsum = t;
-                total = cell_sum(tl);
+                total = cell_sum<SUBS>(tl);
             }
-            if constexpr (!PROBE8) Fc += cell_sum(dF);
+            if constexpr (!PROBE8) Fc += cell_sum<SUBS>(dF);
 
             const uint32_t nn = n ? n : 1u;
             const double vi = static_cast<double>(nn - 1) * q;
@@ -504,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                         c += ((cmask >> y) & 1u) ? cy : 0u;
                     }
                 }
-                return cell_sum(c);
+                return cell_sum<SUBS>(c);
             };
 
             uint32_t pl = 0, Fl = 0, ph = 0xFFFFFFFFu, Fh = nn;
@@ -576,8 +606,8 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                                     a0 = PB == 16 ? sad_u16(codes[wd], b0, a0) : sad_u8(codes[wd], b0, a0);
                                 }
                             }
-                            const uint32_t d = cell_sum((a1 + c1) - (a0 + c0));
-                            return (d + static_cast<uint32_t>(8 * CPW * NW)) >> 1;
+                            const uint32_t d = cell_sum<SUBS>((a1 + c1) - (a0 + c0));
+                            return (d + static_cast<uint32_t>(SUBS * CPW * NW)) >> 1;
                         };
                         const bool active = have_code != 0 && n != 0;
                         // levels per rank near the target
@@ -722,7 +752,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                             top.insert(((cmask >> y) & 1u) ? d : 0xFFFFFFFFu);
                         }
                 }
-                top.merge_cell();
+                top.template merge_cell<SUBS>();
                 if constexpr (STATS) ++st_extract;
                 if (!resolved) {
                     if (window) {
@@ -793,11 +823,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
 
         if ((s & 63) == 63) __syncthreads();
 #pragma unroll
-        for (int y = 0; y < YPS; ++y) {
-            e_cur[y] = e_nxt[y];
-            e_nxt[y] = e_nn[y];
-            x_cur[y] = x_nxt[y];
-        }
+        for (int y = 0; y < YPS; ++y) x_cur[y] = x_nxt[y];
     }
     if (rotate) {
         // a held track did not advance: rotate its window one slot so that its oldest sample sits
@@ -829,32 +855,40 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
 namespace {
 typedef void (*Ring2Kernel)(const float*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*, int32_t,
                             const DevChunk*, double, int, int32_t, double*, double*, int64_t, unsigned long long*);
-struct Ring2Entry { int w, yps, variant; Ring2Kernel fn, fn_stats; };
-// variant -> (code-ring bits, extraction width); the _stats twin carries the debug pass counters
+struct Ring2Entry { int w, yps, subs, variant; Ring2Kernel fn, fn_stats; };
+// variant -> (code-ring bits, extraction width, lanes per cell); the _stats twin carries the debug pass counters
 //   0: 32-bit count passes, J = 5        1: 8-bit probes, J = 5      2: 16-bit probes, J = 5
 //   3: 16-bit probes, J = 4              4: 16-bit probes, J = 3
 //   5: 32-bit count passes, J = 4        6: 32-bit count passes, J = 6
-#define XMHW_R2V(W, Y, V, PB, JX) {W, Y, V, clim_ring2_f32<W, Y, PB, JX, false>, clim_ring2_f32<W, Y, PB, JX, true>}
-#define XMHW_R2(W, Y) XMHW_R2V(W, Y, 0, 0, 5), XMHW_R2V(W, Y, 1, 8, 5), XMHW_R2V(W, Y, 2, 16, 5), XMHW_R2V(W, Y, 3, 16, 4), \
-                      XMHW_R2V(W, Y, 4, 16, 3), XMHW_R2V(W, Y, 5, 0, 4), XMHW_R2V(W, Y, 6, 0, 6)
+//   7: as 0 with 4 lanes per cell (16 cells per wave, twice the tracks per lane)
+#define XMHW_R2V(W, Y, S, V, PB, JX) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, S, false>, clim_ring2_f32<W, Y, PB, JX, S, true>}
+#define XMHW_R2(W, Y) XMHW_R2V(W, Y, 8, 0, 0, 5), XMHW_R2V(W, Y, 8, 1, 8, 5), XMHW_R2V(W, Y, 8, 2, 16, 5), \
+                      XMHW_R2V(W, Y, 8, 3, 16, 4), XMHW_R2V(W, Y, 8, 4, 16, 3), XMHW_R2V(W, Y, 8, 5, 0, 4), \
+                      XMHW_R2V(W, Y, 8, 6, 0, 6)
 const Ring2Entry kRing2[] = {
     XMHW_R2(5, 3), XMHW_R2(5, 4), XMHW_R2(5, 5),
+    XMHW_R2V(5, 5, 4, 7, 0, 5), XMHW_R2V(5, 8, 4, 7, 0, 5), XMHW_R2V(5, 10, 4, 7, 0, 5),
 };
 #undef XMHW_R2
 #undef XMHW_R2V
-const Ring2Entry* find_ring2(int32_t w, int32_t yps, int32_t variant) {
+const Ring2Entry* find_ring2(int32_t w, int32_t yps, int32_t subs, int32_t variant) {
     for (const auto& e : kRing2)
-        if (e.w == w && e.yps == yps && e.variant == variant) return &e;
+        if (e.w == w && e.yps == yps && e.subs == subs && e.variant == variant) return &e;
     return nullptr;
 }
 }  // namespace
 
-int32_t ring2_pick_yps(int32_t w, int32_t ntracks) {
+int32_t ring2_subs(int32_t variant) { return variant == 7 ? 4 : 8; }
+
+int32_t ring2_pick_yps(int32_t w, int32_t ntracks, int32_t variant) {
+    const int32_t subs = ring2_subs(variant);
     int32_t best = 0;
     for (const auto& e : kRing2)
-        if (e.w == w && e.variant == 0 && e.yps * 8 >= ntracks && (best == 0 || e.yps < best)) best = e.yps;
+        if (e.w == w && e.variant == (variant < 0 ? 0 : variant) && e.subs == subs && e.yps * subs >= ntracks &&
+            (best == 0 || e.yps < best))
+            best = e.yps;
     // padding may only sit in the last slot of a lane
-    if (best && (best - 1) * 8 >= ntracks) return 0;
+    if (best && (best - 1) * subs >= ntracks) return 0;
     return best;
 }
 
@@ -863,13 +897,14 @@ hipError_t launch_ring2_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
                             int32_t w, int32_t yps, int32_t ntracks, int32_t variant, double q, int negate,
                             double* thresh, double* seas, int64_t ldo, hipStream_t stream,
                             unsigned long long* stats) {
-    const Ring2Entry* e = find_ring2(w, yps, variant);
+    const int32_t subs = ring2_subs(variant);
+    const Ring2Entry* e = find_ring2(w, yps, subs, variant);
     if (!e) return hipErrorInvalidValue;
     if (C <= 0 || nchunks <= 0) return hipSuccess;
-    const int64_t cells_per_block = 8 * kWaves2;
+    const int64_t cells_per_block = (64 / subs) * kWaves2;
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
-    hipLaunchKernelGGL(stats ? e->fn_stats : e->fn, grid, dim3(64 * kWaves2), 0, stream, ts, C, ld, Tn, table, sflags, step_min, chunks, q,
-                       negate, ntracks, thresh, seas, ldo, stats);
+    hipLaunchKernelGGL(stats ? e->fn_stats : e->fn, grid, dim3(64 * kWaves2), 0, stream, ts, C, ld, Tn, table, sflags, step_min,
+                       chunks, q, negate, ntracks, thresh, seas, ldo, stats);
     return hipGetLastError();
 }
 

@@ -51,12 +51,16 @@ std::vector<uint32_t> Plan::step_flags() const {
     const std::vector<uint32_t> tab = ring_table(1, ntracks);      // [step][track]
     std::vector<uint32_t> f(static_cast<size_t>(nsteps), 0u);
     for (int32_t i = 0; i < nsteps; ++i) {
-        bool simple = true;
+        bool simple = true, consec = i > 0;
         for (int32_t k = 0; k < ntracks; ++k) {
             const uint32_t e = tab[static_cast<size_t>(i) * ntracks + k];
             simple = simple && (e & 1u) && (e >> 1) >= 2u;
+            if (i > 0) {
+                const uint32_t p = tab[static_cast<size_t>(i - 1) * ntracks + k];
+                consec = consec && (e >> 1) >= 2u && (p >> 1) >= 2u && (e >> 1) == (p >> 1) + 1u;
+            }
         }
-        f[i] = simple ? 1u : 0u;
+        f[i] = (simple ? 1u : 0u) | (consec ? 2u : 0u);
     }
     return f;
 }

@@ -59,7 +59,8 @@ struct Plan {
     // (the table is [step][track]; kernels_ring2.hip reads it y-major instead: track k -> sub k % subs,
     // slot k / subs, so that padding only ever sits in the last slot of a lane)
     std::vector<uint32_t> ring_table(int32_t subs, int32_t yps) const;
-    // per step: bit 0 = SIMPLE (every real track pushes a valid sample and is part of the pool)
+    // per step: bit 0 = SIMPLE (every real track pushes a valid sample and is part of the pool);
+    // bit 1 = CONSEC (every real track pushes the sample following the one it pushed at the previous step)
     std::vector<uint32_t> step_flags() const;
     std::vector<Chunk> make_chunks(int32_t nchunks) const;
 };
