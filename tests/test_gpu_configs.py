@@ -12,7 +12,8 @@ T / D / window / percentile / NaN fraction / tstep axis / smoothing width (singl
 
 configs[0] (single point, 30-yr daily) goes through the public point path.
 
-Kernels this file is the evidence for (kernel trace: profiles/r2_configs_kernel_trace_stats.csv):
+Kernels this file is the evidence for (kernel trace of the device half, tools/trace_configs.py:
+profiles/r2_configs_kernel_stats.csv):
 the untiled ``clim_finish`` (D = 1460 > 511, config 5), the 25-32-track ring (30 years, configs 1-2)
 and the 20-track ring (config 5).
 """

@@ -73,7 +73,7 @@ def _compare(dev, x, doy, q=0.9, negate=False, nchunks=1, expect_fast=None):
         if expect_fast is not None:
             frac = st[4] / max(1, st[0])
             assert (frac > 0.4) == expect_fast, (v, st)
-        if v >= 1:
+        if v in (1, 2, 3, 4):         # the variants that carry a code ring
             assert st[5] > 0 or np.isnan(x).any() or expect_fast is False, (v, st)
     return t0, s0
 

@@ -61,7 +61,7 @@ struct xmhw_plan {
     uint32_t* d_table = nullptr;
     int32_t yps2 = 0;         // second-generation float32 ring kernel (kernels_ring2.hip), 0: not available
     int32_t subs2 = 0;        // ... and its lanes per cell (8, or 4 for variant 7)
-    int32_t ring2_variant = 0;    // -1: off (round-1 kernel); 0: lean steps; 1: + 8-bit SAD probes (slower, kept as a measured variant)
+    int32_t ring2_variant = -2;   // -2: auto (0 or 7, whichever pads fewer tracks); -1: off (round-1 kernel); 0..7: see kernels_ring2.hip
     uint32_t* d_table2 = nullptr;
     uint32_t* d_sflags = nullptr;
     int32_t yps64 = 0;        // float64 ring kernel tracks-per-lane (16 lanes per cell)
@@ -106,12 +106,22 @@ int32_t auto_chunks(const xmhw_plan* p, int64_t C) {
     return static_cast<int32_t>(std::max<int64_t>(want, 1));
 }
 
+// the ring2 variant float32 input runs on: the requested one, or (auto) 8 lanes per cell unless the
+// 4-lane layout pads fewer tracks (20 tracks: 4 x 5 exactly against 8 x 3 = 24) and does not spill
+int32_t ring2_resolved(const xmhw_plan* p) {
+    if (p->ring2_variant != -2) return p->ring2_variant;
+    const int32_t y8 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 0);
+    const int32_t y4 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 7);
+    if (y4 && y4 <= 8 && (!y8 || y4 * 4 < y8 * 8)) return 7;
+    return 0;
+}
+
 int upload(xmhw_plan* p, int64_t C) {
     std::lock_guard<std::mutex> lock(p->mu);
     const int32_t nchunks = auto_chunks(p, C);
     if (p->uploaded && nchunks == p->nchunks &&
-        p->subs2 == xmhw::ring2_subs(p->ring2_variant) &&
-        p->yps2 == (p->ring2_variant >= 0 ? xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, p->ring2_variant) : 0))
+        p->subs2 == xmhw::ring2_subs(ring2_resolved(p)) &&
+        p->yps2 == (ring2_resolved(p) >= 0 ? xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, ring2_resolved(p)) : 0))
         return XMHW_OK;
     const xmhw::Plan& h = p->host;
     if (!p->uploaded) {
@@ -134,8 +144,9 @@ int upload(xmhw_plan* p, int64_t C) {
     }
     // the second-generation ring kernel's table depends on the variant's lanes per cell
     {
-        const int32_t subs2 = xmhw::ring2_subs(p->ring2_variant);
-        const int32_t yps2 = p->ring2_variant >= 0 ? xmhw::ring2_pick_yps(h.w, h.ntracks, p->ring2_variant) : 0;
+        const int32_t v2 = ring2_resolved(p);
+        const int32_t subs2 = xmhw::ring2_subs(v2);
+        const int32_t yps2 = v2 >= 0 ? xmhw::ring2_pick_yps(h.w, h.ntracks, v2) : 0;
         if (yps2 != p->yps2 || subs2 != p->subs2) {
             if (p->d_table2) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p->d_table2)); p->d_table2 = nullptr; }
             p->yps2 = yps2;
@@ -181,10 +192,10 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
     hipError_t e;
     if (kernel == XMHW_KERNEL_RING) {
         if constexpr (sizeof(T) == 4) {
-            if (plan->yps2 && plan->ring2_variant >= 0)
+            if (plan->yps2 && ring2_resolved(plan) >= 0)
                 e = xmhw::launch_ring2_f32(reinterpret_cast<const float*>(ts), C, ld, h.T, plan->d_table2, plan->d_sflags,
                                            h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps2, h.ntracks,
-                                           plan->ring2_variant, q, negate, thresh, seas, ldo, st, plan->d_stats);
+                                           ring2_resolved(plan), q, negate, thresh, seas, ldo, st, plan->d_stats);
             else
             e = xmhw::launch_ring_f32(reinterpret_cast<const float*>(ts), C, ld, plan->d_table,
                                       h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps, plan->subs, q,
@@ -785,15 +796,15 @@ int xmhw_plan_create(const int32_t* doy_host, int64_t T, int32_t window_half_wid
 }
 int xmhw_plan_set_ring2(xmhw_plan* plan, int32_t variant) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
-    if (variant < -1 || variant > 7) return fail(XMHW_ERR_INVALID, "ring2 variant must be -1 (off) or 0..7");
+    if (variant < -2 || variant > 7) return fail(XMHW_ERR_INVALID, "ring2 variant must be -2 (auto), -1 (off) or 0..7");
     plan->ring2_variant = variant;
     return XMHW_OK;
 }
 int xmhw_plan_ring2_in_use(const xmhw_plan* plan, int32_t* variant) {
     if (!plan || !variant) return fail(XMHW_ERR_INVALID, "NULL argument");
     const bool ring = resolve_kernel(plan, 4) == XMHW_KERNEL_RING;
-    *variant = (ring && plan->ring2_variant >= 0 && xmhw::ring2_pick_yps(plan->host.w, plan->host.ntracks, plan->ring2_variant) > 0)
-                   ? plan->ring2_variant : -1;
+    const int32_t v2 = ring2_resolved(plan);
+    *variant = (ring && v2 >= 0 && xmhw::ring2_pick_yps(plan->host.w, plan->host.ntracks, v2) > 0) ? v2 : -1;
     return XMHW_OK;
 }
 int xmhw_plan_destroy(xmhw_plan* plan) {

@@ -160,9 +160,14 @@ struct TopJ {
         if constexpr (SUBS == 32) merge_dpp<0>();
     }
     __device__ __forceinline__ uint32_t at(uint32_t j) const {  // m[j], j uniform per cell
+        // the empty asm keeps the select chain a select chain (the compiler otherwise builds a dynamically
+        // indexed array in LDS: 5,120 B per block and a dependent LDS round trip per row)
         uint32_t r = m[0];
 #pragma unroll
-        for (int i = 1; i < J; ++i) r = (j == static_cast<uint32_t>(i)) ? m[i] : r;
+        for (int i = 1; i < J; ++i) {
+            r = (j == static_cast<uint32_t>(i)) ? m[i] : r;
+            asm volatile("" : "+v"(r));
+        }
         return r;
     }
     __device__ __forceinline__ uint32_t count_below(uint32_t d) const {  // #{m[i] < d}

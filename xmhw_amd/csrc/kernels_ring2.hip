@@ -115,7 +115,8 @@ __device__ __forceinline__ uint32_t bits_of_key(uint32_t k) {
 // before a VALU instruction may read it; the compiler pads every pair with s_nop (167 issue slots
 // for 55 keys), here three SGPR pairs rotate so that compare i is consumed four slots later
 // (22 slots per 11 keys, no s_nop).
-__device__ __forceinline__ uint32_t count_le11(const uint32_t (&r)[11], uint32_t p, uint32_t& c, uint32_t d) {
+template <class RingT>
+__device__ __forceinline__ uint32_t count_le11(const RingT& r, uint32_t p, uint32_t& c, uint32_t d) {
     // two accumulators (c, d) so that consecutive v_addc do not depend on each other
     unsigned long long s0, s1, s2, sd;
     asm("v_cmp_le_u32_e64 %[s0], %[k0], %[p]\n\t"
@@ -252,6 +253,8 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     const bool cell_ok = cell < C;
     const DevChunk ch = chunks[blockIdx.y];
     const uint32_t* tab = table + sub;           // y-major: entry of slot y at tab[step * NTP + y * SUBS]
+    // lanes beyond the last cell work on a copy of the last cell (and store nothing): a partly filled
+    // wave then takes the same fast steps as a full one
     const float* col = ts + (cell_ok ? cell : C - 1);
     const uint32_t negmask = negate ? 0xFFFFFFFFu : 0u;
     const uint32_t tmax = static_cast<uint32_t>(Tn - 1);
@@ -260,11 +263,12 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     const uint32_t padmask = padded_last ? 0xFFFFFFFFu : 0u;
     const uint32_t full_valid = static_cast<uint32_t>((padded_last ? YPS - 1 : YPS) * R);
 
-    uint32_t ring[YPS][R];
+    // one 11-register tuple per track: slot m (wave-uniform) is read and written through the VGPR index
+    // register (s_set_gpr_idx_on + v_mov), every other access names its register statically
+    typedef uint32_t RingT __attribute__((ext_vector_type(R)));
+    RingT ring[YPS];
 #pragma unroll
-    for (int y = 0; y < YPS; ++y)
-#pragma unroll
-        for (int k = 0; k < R; ++k) ring[y][k] = kInv;
+    for (int y = 0; y < YPS; ++y) ring[y] = kInv;
     double lsum = 0.0;        // sum of the valid samples in this lane's rings (all tracks)
     uint32_t nval = 0;        // number of valid keys in this lane's rings (all tracks)
 
@@ -321,13 +325,18 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     // every row.  Between two segments it costs nothing.
     uint32_t hmask = 0;        // bit y: track y held at the last step of the segment
     int32_t s = ch.warm_start;
+    // step flags are read two steps ahead (a scalar load consumed on the spot costs its full latency
+    // on every row)
+    uint32_t sf_cur = __builtin_amdgcn_readfirstlane(sflags[s - step_min]);
+    uint32_t sf_nxt = s + 1 < ch.end ? __builtin_amdgcn_readfirstlane(sflags[s + 1 - step_min]) : 0u;
     while (s < ch.end) {
     bool rotate = false;
     for (; s < ch.end && !rotate; ++s) {
         // ---- prefetch: the samples of step s+1 (consumed one row later) ------------------
         float x_nxt[YPS];
+        const uint32_t sf_nn = s + 2 < ch.end ? __builtin_amdgcn_readfirstlane(sflags[s + 2 - step_min]) : 0u;
         if (s + 1 < ch.end) {
-            const uint32_t sfn = __builtin_amdgcn_readfirstlane(sflags[s + 1 - step_min]);
+            const uint32_t sfn = sf_nxt;
             if (sfn & 2u) advance();
             else point_at(s + 1);
             request(x_nxt);
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
 #pragma unroll
             for (int y = 0; y < YPS; ++y) x_nxt[y] = 0.0f;
         }
-        const uint32_t sf = __builtin_amdgcn_readfirstlane(sflags[s - step_min]);
+        const uint32_t sf = sf_cur;
 
         // ---- what this step pushes ------------------------------------------------------
         uint32_t kin[YPS], kout[YPS];
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
 #pragma unroll
             for (int y = 0; y < YPS; ++y) {
                 const float xv = x_cur[y];
-                const bool ok = cell_ok && xv == xv;
+                const bool ok = xv == xv;
                 kin[y] = ok ? key_of_bits(__float_as_uint(xv), negmask) : kInv;
             }
             kin[YPS - 1] |= padmask;
@@ -374,30 +383,20 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                 cmask |= (e_cur[y] & 1u) << y;
                 hmask |= (code == kCodeHold ? 1u : 0u) << y;
                 const float xv = x_cur[y];
-                const bool ok = code >= 2u && cell_ok && xv == xv;
+                const bool ok = code >= 2u && xv == xv;
                 kin[y] = ok ? key_of_bits(__float_as_uint(xv), negmask) : kInv;
             }
             wave_hold = __any(hmask != 0);
         }
         // ---- the one place where the rings are written (slot m of every track) ------------
-#define XMHW_R2_PUSH(K)                                                              \
-    case K:                                                                          \
-        if constexpr (K < R) {                                                       \
-            _Pragma("unroll") for (int y = 0; y < YPS; ++y) kout[y] = opaque(ring[y][K < R ? K : 0]); \
-            if (wave_hold) {                                                         \
-                _Pragma("unroll") for (int y = 0; y < YPS; ++y)                      \
-                    kin[y] = ((hmask >> y) & 1u) ? kout[y] : kin[y];                 \
-            }                                                                        \
-            _Pragma("unroll") for (int y = 0; y < YPS; ++y) ring_set(ring[y][K < R ? K : 0], kin[y]); \
-        }                                                                            \
-        break;
-        switch (m) {
-            XMHW_R2_PUSH(0) XMHW_R2_PUSH(1) XMHW_R2_PUSH(2) XMHW_R2_PUSH(3) XMHW_R2_PUSH(4)
-            XMHW_R2_PUSH(5) XMHW_R2_PUSH(6) XMHW_R2_PUSH(7) XMHW_R2_PUSH(8) XMHW_R2_PUSH(9)
-            XMHW_R2_PUSH(10)
-            default: break;
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) kout[y] = ring[y][m];
+        if (wave_hold) {
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) kin[y] = ((hmask >> y) & 1u) ? kout[y] : kin[y];
         }
-#undef XMHW_R2_PUSH
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) ring[y][m] = kin[y];
         uint32_t dF = 0;
         if (fast) {
             // running sum: + new samples - evicted samples (padded slot: both are masked to +0.0)
@@ -824,6 +823,8 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
         if ((s & 63) == 63) __syncthreads();
 #pragma unroll
         for (int y = 0; y < YPS; ++y) x_cur[y] = x_nxt[y];
+        sf_cur = sf_nxt;
+        sf_nxt = sf_nn;
     }
     if (rotate) {
         // a held track did not advance: rotate its window one slot so that its oldest sample sits
@@ -834,8 +835,14 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
             const uint32_t last = opaque(ring[y][R - 1]);
             asm volatile("s_nop 1");     // hy may come straight from a v_cmp: two wait states before a VALU read
 #pragma unroll
-            for (int k = R - 1; k >= 1; --k) ring_sel(ring[y][k], ring[y][k - 1], hy);
-            ring_sel(ring[y][0], last, hy);
+            for (int k = R - 1; k >= 1; --k) {
+                uint32_t e = ring[y][k];
+                ring_sel(e, ring[y][k - 1], hy);
+                ring[y][k] = e;
+            }
+            uint32_t e0 = ring[y][0];
+            ring_sel(e0, last, hy);
+            ring[y][0] = e0;
         }
         have_code = 0;         // byte positions moved: rebuild the code ring
     }

@@ -98,9 +98,15 @@ struct TopJ {
         merge_dpp<dpp_ror(1)>();
     }
     __device__ __forceinline__ double at(uint32_t j) const {
+        // a chain of selects; the empty asm keeps the compiler from turning it into a dynamically indexed
+        // array (which it places in LDS: a store of all J entries and a dependent read on every row --
+        // the 12 KB of LDS per block this kernel used to report)
         double r = m[0];
 #pragma unroll
-        for (int i = 1; i < J; ++i) r = (j == static_cast<uint32_t>(i)) ? m[i] : r;
+        for (int i = 1; i < J; ++i) {
+            r = (j == static_cast<uint32_t>(i)) ? m[i] : r;
+            asm volatile("" : "+v"(r));
+        }
         return r;
     }
     __device__ __forceinline__ uint32_t count_below(double d) const {
