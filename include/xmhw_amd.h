@@ -81,6 +81,14 @@ int xmhw_event_sync(void *event);                           /* block the host un
 int xmhw_decode(const void *raw_dev, int raw_itemsize, int big_endian, int64_t rows, int64_t cols,
                 int64_t ld_raw, void *out_dev, int out_itemsize, int64_t ld_out, int has_scale,
                 double scale_factor, double add_offset, int has_fill, double fill_value, void *stream);
+/* maxPadLength: `ts.interpolate_na(dim=tdim, max_gap=maxPadLength)` (xmhw/xmhw.py:159-160, :409-410;
+ * xarray's linear interpolate_na with use_coordinate=True) on the device copy of a compacted series
+ * (T, C), leading dimension ld, IN PLACE.  x_dev[T] = the numeric time coordinate (float64; for
+ * datetime axes xarray uses nanoseconds since the first step).  A run of NaN strictly between valid
+ * samples at steps a < b is filled iff x[b] - x[a] <= max_gap, with numpy.interp's float64 arithmetic
+ * rounded to the sample type; leading / trailing runs and all-NaN cells are left alone.           */
+int xmhw_pad_gaps(void *ts_dev, int itemsize, int64_t T, int64_t C, int64_t ld, const double *x_dev,
+                  double max_gap, void *stream);
 int xmhw_stream_create(void **stream);
 int xmhw_stream_destroy(void *stream);
 int xmhw_stream_sync(void *stream);     /* NULL = default stream                  */

@@ -131,3 +131,50 @@ def test_tstep_axis_end_to_end():
     mhw = detect(g, th, se, tstep=True)
     ref = _detect(g, th, se, oracle_detect_cells, tstep=True)
     _compare(mhw, ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("cold", [False, True])
+def test_threshold_detect_equals_the_two_calls(oisst, dtype, cold, monkeypatch):
+    """threshold_detect() (series uploaded once, kept in HBM between the two stages) returns what
+    threshold() followed by detect() returns; the second stage must not upload the series again."""
+    import xmhw_amd.device as dev
+    import xmhw_amd.detect_front as front
+    from xmhw_amd import climatology_series, detect, threshold, threshold_detect
+    g = _grid(oisst, dtype)
+    clim0 = threshold(g, coldSpells=cold)
+    mhw0 = detect(g, climatology_series(clim0, "thresh"), climatology_series(clim0, "seas"), coldSpells=cold)
+
+    uploads = []
+    real = dev.compact_columns
+
+    def counting(stacked, lo, hi, anynans):
+        uploads.append(stacked.shape)
+        return real(stacked, lo, hi, anynans)
+
+    monkeypatch.setattr(dev, "compact_columns", counting)
+    clim1, mhw1 = threshold_detect(g, coldSpells=cold)
+    T = g.values.shape[0]
+    assert not [s for s in uploads if s[0] == T], uploads       # only the (D, N) climatologies were uploaded
+    npt.assert_array_equal(clim1["thresh"], clim0["thresh"])
+    npt.assert_array_equal(clim1["seas"], clim0["seas"])
+    npt.assert_array_equal(mhw1.offsets, mhw0.offsets)
+    npt.assert_array_equal(mhw1.table, mhw0.table)
+    assert mhw1.n_events > 0
+    clim2, mhw2, inter2 = threshold_detect(g, coldSpells=cold, intermediate=True)
+    npt.assert_array_equal(mhw2.table, mhw0.table)
+    assert "ts" in inter2.data_vars or len(inter2.data_vars) > 0
+
+
+def test_threshold_detect_with_a_climatology_period_falls_back(oisst):
+    """a climatology period cuts the series for threshold(): nothing is reused, results equal the two calls"""
+    from xmhw_amd import climatology_series, detect, threshold, threshold_detect
+    g = _grid(oisst)
+    period = [2004, 2004]          # the leap year of the 2003-2004 fixture: every doy has a row
+    clim0 = threshold(g, climatologyPeriod=period)
+    mhw0 = detect(g, climatology_series(clim0, "thresh"), climatology_series(clim0, "seas"))
+    clim1, mhw1 = threshold_detect(g, climatologyPeriod=period)
+    npt.assert_array_equal(clim1["thresh"], clim0["thresh"])
+    npt.assert_array_equal(mhw1.table, mhw0.table)
+    with pytest.raises(Exception, match="Maximum gap"):
+        threshold_detect(g, maxGap=5, minDuration=5)

@@ -45,7 +45,7 @@ def test_exceptions_like_the_reference(oisst):
                        {"time": oisst["time64"], "lat": np.arange(0), "lon": oisst["lon"]})
     with pytest.raises(XmhwException):                       # identify.py:514-516
         _threshold(empty, oracle_compute)
-    with pytest.raises(XmhwException):
+    with pytest.raises(TypeError):                           # xarray's interpolate_na: a bare number on a datetime axis
         _threshold(g, oracle_compute, maxPadLength=3)
 
 

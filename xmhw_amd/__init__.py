@@ -10,13 +10,13 @@ from .exception import XmhwException
 from .api import threshold, threshold_array, GridSeries, ClimDataset
 from .calendar import add_doy, get_calendar
 from .landmask import land_check
-from .detect import detect, EventDataset, InterDataset, climatology_series
+from .detect import detect, threshold_detect, EventDataset, InterDataset, climatology_series
 from .device import release_device_cache
 from .stats import block_average, BlockDataset
 from .ingest import open_series, threshold_file
 
 __all__ = ["threshold", "threshold_array", "GridSeries", "ClimDataset", "XmhwException",
-           "add_doy", "get_calendar", "land_check", "detect", "EventDataset", "InterDataset",
+           "add_doy", "get_calendar", "land_check", "detect", "threshold_detect", "EventDataset", "InterDataset",
            "climatology_series", "release_device_cache", "block_average", "BlockDataset", "open_series",
            "threshold_file"]
 __version__ = "0.1.0"

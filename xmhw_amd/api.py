@@ -18,6 +18,7 @@ from . import calendar as cal
 from . import landmask
 from .device import calc_clim_device, calc_clim_grid_device
 from .exception import XmhwException
+from .padding import make_pad
 
 GITHUB = "https://github.com/coecms/xmhw"
 
@@ -123,7 +124,8 @@ def threshold(
     ``xmhw.xmhw.threshold`` (xmhw/xmhw.py:38-99).  Differences, all documented
     in DESIGN.md: results are float64 whatever the input dtype; ``skipna`` only
     changes the provenance text (it never changes the reference's numbers
-    either, quirk Q1); ``maxPadLength`` is not supported (quirk Q10).
+    either, quirk Q1); ``maxPadLength`` follows xarray's interpolate_na(max_gap=...) rules: a timedelta
+    on a datetime axis, a number on a numeric one (xmhw_amd/padding.py).
     The device stage is always the HIP path (no CPU fallback).
     """
     return _threshold(temp, calc_clim_device, tdim, climatologyPeriod, pctile, windowHalfWidth,
@@ -147,8 +149,6 @@ def _threshold(temp, compute, tdim="time", climatologyPeriod=[None, None], pctil
     if tdim not in dims:                                      # xmhw.py:105-109
         raise XmhwException(f"{tdim} dimension not present, default"
                             + "is 'time' or pass as tdim='time_dimension_name'")
-    if maxPadLength:
-        raise XmhwException("maxPadLength (interpolate_na) is not supported by xmhw_amd")
     if is_xr:
         values = temp.values
         coords, coord_attrs = _from_xarray(temp)
@@ -186,13 +186,20 @@ def _threshold(temp, compute, tdim="time", climatologyPeriod=[None, None], pctil
     if cal.get_calendar(calname) == 360.0:                    # xmhw.py:142-144
         tstep = True
     doy = cal.add_doy(time, keep_tstep=tstep)                 # xmhw.py:145
-
-    if on_device:
-        keep, doys, th, se = grid_compute(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile,
-                                          smoothPercentileWidth, tstep, coldSpells)
-    else:
-        doys, th, se = compute(ts, doy, pctile, windowHalfWidth, smoothPercentile,
-                               smoothPercentileWidth, tstep, coldSpells)
+    # ts.interpolate_na(dim=tdim, max_gap=maxPadLength) after land_check (xmhw.py:157-160): on the device
+    # copy of the compacted series, handed to the device stage as a recipe (None: no interpolation)
+    pad = make_pad(maxPadLength, time)
+    extra = {} if pad is None else {"pad": pad}
+    try:
+        if on_device:
+            keep, doys, th, se = grid_compute(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile,
+                                              smoothPercentileWidth, tstep, coldSpells, **extra)
+        else:
+            doys, th, se = compute(ts, doy, pctile, windowHalfWidth, smoothPercentile,
+                                   smoothPercentileWidth, tstep, coldSpells, **extra)
+    finally:
+        if pad is not None:
+            pad.free()
 
     D = doys.shape[0]
     yrs = cal.years_of(time)

@@ -733,6 +733,17 @@ int xmhw_decode(const void* raw_dev, int raw_itemsize, int big_endian, int64_t r
     if (e != hipSuccess) return hip_fail(e, "decode launch");
     return XMHW_OK;
 }
+int xmhw_pad_gaps(void* ts_dev, int itemsize, int64_t T, int64_t C, int64_t ld, const double* x_dev, double max_gap,
+                  void* stream) {
+    if (T < 0 || C < 0 || ld < C) return fail(XMHW_ERR_INVALID, "bad T/C/ld");
+    if (itemsize != 4 && itemsize != 8) return fail(XMHW_ERR_INVALID, "itemsize must be 4 or 8");
+    if (!(max_gap == max_gap)) return fail(XMHW_ERR_INVALID, "max_gap is NaN");
+    if (T == 0 || C == 0) return XMHW_OK;
+    if (!ts_dev || !x_dev) return fail(XMHW_ERR_INVALID, "NULL device buffer");
+    hipError_t e = xmhw::launch_pad_gaps(ts_dev, itemsize, T, C, ld, x_dev, max_gap, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "pad_gaps launch");
+    return XMHW_OK;
+}
 int xmhw_memset(void* dst, int value, size_t bytes, void* stream) {
     if (bytes == 0) return XMHW_OK;
     HIP_TRY(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)));

@@ -133,6 +133,10 @@ hipError_t launch_decode(const void* in, int raw_type, int swap, int64_t rows, i
                          int out_itemsize, int64_t ld_out, double scale, double offset, int has_scale, int has_fill,
                          double fill, hipStream_t stream);
 
+// ts.interpolate_na(dim=tdim, max_gap=...) on the device copy of the series, in place (kernels_ingest.hip)
+hipError_t launch_pad_gaps(void* ts, int itemsize, int64_t Tn, int64_t C, int64_t ld, const double* x, double max_gap,
+                           hipStream_t stream);
+
 template <typename T>
 hipError_t launch_synth(T* ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
                         double nan_frac, hipStream_t stream);

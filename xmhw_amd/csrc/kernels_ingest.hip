@@ -66,6 +66,58 @@ hipError_t launch(const void* in, int swap, int64_t rows, int64_t cols, int64_t 
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------
+// pad_gaps: ts.interpolate_na(dim=tdim, max_gap=maxPadLength) of the reference (xmhw/xmhw.py:159-160,
+// :409-410), i.e. xarray's linear interpolate_na with use_coordinate=True on the device copy of the
+// compacted series, in place.  One thread per cell walks its column (lanes along the cell axis, rows
+// loaded kAhead at a time).  A run of NaN strictly between two valid samples at steps a < b is filled
+// iff x[b] - x[a] <= max_gap (x = the numeric time coordinate), with numpy.interp's arithmetic in
+// double -- slope = (y[b] - y[a]) / (x[b] - x[a]); slope * (x[u] - x[a]) + y[a]; the two NaN fallbacks
+// of numpy's compiled_base.c -- rounded to the sample type on store.  Leading and trailing runs and
+// all-NaN cells stay as they are.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pad_gaps(T* __restrict__ ts, int64_t Tn, int64_t C, int64_t ld,
+                                                const double* __restrict__ x, double max_gap) {
+    constexpr int kAhead = 8;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    T* col = ts + c;
+    int64_t a = -1;
+    double ya = 0.0;
+    for (int64_t t0 = 0; t0 < Tn; t0 += kAhead) {
+        T v[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int64_t t = t0 + u < Tn ? t0 + u : Tn - 1;
+            v[u] = col[t * ld];
+        }
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int64_t t = t0 + u;
+            if (t >= Tn || !(v[u] == v[u])) continue;
+            const double yb = static_cast<double>(v[u]);
+            if (a >= 0 && t - a > 1) {
+                const double xa = x[a], xb = x[t];
+                if (xb - xa <= max_gap) {
+                    const double slope = (yb - ya) / (xb - xa);
+                    for (int64_t k = a + 1; k < t; ++k) {
+                        double r = slope * (x[k] - xa) + ya;
+                        if (r != r) {
+                            r = slope * (x[k] - xb) + yb;
+                            if (r != r && ya == yb) r = ya;
+                        }
+                        col[k * ld] = static_cast<T>(r);
+                    }
+                }
+            }
+            a = t;
+            ya = yb;
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_decode(const void* in, int raw_type, int swap, int64_t rows, int64_t cols, int64_t ld_in, void* out,
@@ -81,6 +133,19 @@ hipError_t launch_decode(const void* in, int raw_type, int swap, int64_t rows, i
     if (raw_type == 8 && out_itemsize == 8)
         return launch<double, double>(in, swap, rows, cols, ld_in, out, ld_out, scale, offset, has_scale, has_fill, fill, stream);
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_pad_gaps(void* ts, int itemsize, int64_t Tn, int64_t C, int64_t ld, const double* x, double max_gap,
+                           hipStream_t stream) {
+    if (Tn <= 0 || C <= 0) return hipSuccess;
+    dim3 grid(static_cast<unsigned>((C + 255) / 256));
+    if (itemsize == 4)
+        hipLaunchKernelGGL(pad_gaps<float>, grid, dim3(256), 0, stream, static_cast<float*>(ts), Tn, C, ld, x, max_gap);
+    else if (itemsize == 8)
+        hipLaunchKernelGGL(pad_gaps<double>, grid, dim3(256), 0, stream, static_cast<double*>(ts), Tn, C, ld, x, max_gap);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 
 }  // namespace xmhw

@@ -403,6 +403,11 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     }, py::arg("raw"), py::arg("raw_itemsize"), py::arg("big_endian"), py::arg("rows"), py::arg("cols"), py::arg("ld_raw"),
        py::arg("out"), py::arg("out_itemsize"), py::arg("ld_out"), py::arg("has_scale"), py::arg("scale"),
        py::arg("offset"), py::arg("has_fill"), py::arg("fill"), py::arg("stream") = 0);
+    m.def("pad_gaps", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, uintptr_t x, double max_gap,
+                         uintptr_t stream) {
+        check(xmhw_pad_gaps(vp(ts), itemsize, T, C, ld, static_cast<const double*>(vp(x)), max_gap, vp(stream)));
+    }, py::arg("ts"), py::arg("itemsize"), py::arg("T"), py::arg("C"), py::arg("ld"), py::arg("x"), py::arg("max_gap"),
+       py::arg("stream") = 0);
     m.def("host_alloc", [](size_t n) { void* p = nullptr; check(xmhw_host_alloc(&p, n)); return reinterpret_cast<uintptr_t>(p); });
     m.def("host_free", [](uintptr_t p) { check(xmhw_host_free(vp(p))); });
     m.def("host_view", [](uintptr_t p, size_t nbytes) {

@@ -21,6 +21,7 @@ from . import landmask
 from .api import GITHUB, GridSeries, _from_xarray, _is_xarray
 from .detect_front import EVENT_COLUMNS, INTERMEDIATE_U8, detect_cells, detect_grid
 from .exception import XmhwException
+from .padding import make_pad
 
 TIME_COLUMNS = ("time_start", "time_end", "time_peak")
 INTER_VARIABLES = ["ts", "seas", "thresh", "bthresh", "events", "relSeas", "relThresh", "relThreshNorm",
@@ -238,13 +239,69 @@ def detect(
     """Applies the Hobday et al. (2016) marine heat wave definition to a temperature timeseries.
 
     Same signature, defaults, exceptions and return values as ``xmhw.xmhw.detect``
-    (xmhw/xmhw.py:310-372).  Differences: ``maxPadLength`` is not supported (quirk Q10,
-    as in threshold()); for GridSeries input the return is an EventDataset (compact table, dense on
+    (xmhw/xmhw.py:310-372).  Differences: for GridSeries input the return is an EventDataset (compact table, dense on
     request) and, with ``intermediate``, an InterDataset.  The device stage is always the HIP path.
     """
     return _detect(temp, th, se, detect_cells, tdim, minDuration, joinGaps, maxGap, maxPadLength, coldSpells,
                    intermediate, anynans, tstep, grid_compute=detect_grid)
 
+
+
+def threshold_detect(
+    temp,
+    tdim="time",
+    climatologyPeriod=[None, None],
+    pctile=90,
+    windowHalfWidth=5,
+    smoothPercentile=True,
+    smoothPercentileWidth=31,
+    maxPadLength=None,
+    coldSpells=False,
+    tstep=False,
+    anynans=False,
+    skipna=False,
+    minDuration=5,
+    joinGaps=True,
+    maxGap=2,
+    intermediate=False,
+):
+    """``clim = threshold(temp, ...)`` followed by ``detect(temp, clim['thresh'], clim['seas'], ...)``
+    (the reference's usual pair, docs/gettingstarted.rst:37-45) with the series uploaded ONCE: the
+    compacted device copy of every column slab made by threshold() stays in HBM (60.6 GB for the
+    0.25 degree 40-year grid, device.ResidentSeries) and detect() runs on it.  Returns
+    ``(clim, mhw)`` or ``(clim, mhw, mhw_inter)`` with ``intermediate``; every value is identical to
+    the two separate calls with the same arguments.  When the climatology period selects a part of
+    the time axis, or the series does not leave room in HBM, or ``intermediate`` is asked for (the
+    per-step columns take the host-compacted path), detect() uploads the series again as the separate
+    call would."""
+    from .api import _threshold
+    from .device import ResidentSeries, calc_clim_device, calc_clim_grid_device
+    if maxGap >= minDuration:                                  # detect()'s check, before any work is done
+        raise XmhwException("Maximum gap between mhw events should"
+                            + " be smaller than event minimum duration")
+    store = ResidentSeries()
+
+    def clim_grid(*a, **k):
+        return calc_clim_grid_device(*a, resident=store, **k)
+
+    def events_grid(*a, **k):
+        return detect_grid(*a, resident=store, **k)
+
+    try:
+        clim = _threshold(temp, calc_clim_device, tdim, climatologyPeriod, pctile, windowHalfWidth,
+                          smoothPercentile, smoothPercentileWidth, maxPadLength, coldSpells, tstep,
+                          anynans, skipna, grid_compute=clim_grid)
+        if _is_xarray(clim):
+            th, se = clim["thresh"], clim["seas"]
+        else:
+            th, se = climatology_series(clim, "thresh"), climatology_series(clim, "seas")
+        out = _detect(temp, th, se, detect_cells, tdim, minDuration, joinGaps, maxGap,
+                      maxPadLength, coldSpells, intermediate, anynans, tstep, grid_compute=events_grid)
+    finally:
+        store.free()
+    if intermediate:
+        return (clim,) + tuple(out)
+    return clim, out
 
 def _detect(temp, th, se, compute, tdim="time", minDuration=5, joinGaps=True, maxGap=2, maxPadLength=None,
             coldSpells=False, intermediate=False, anynans=False, tstep=False, grid_compute=None):
@@ -255,8 +312,6 @@ def _detect(temp, th, se, compute, tdim="time", minDuration=5, joinGaps=True, ma
     if maxGap >= minDuration:                                  # xmhw.py:373-378
         raise XmhwException("Maximum gap between mhw events should"
                             + " be smaller than event minimum duration")
-    if maxPadLength:
-        raise XmhwException("maxPadLength (interpolate_na) is not supported by xmhw_amd")
     is_xr = _is_xarray(temp)
     values, dims, coords, coord_attrs, attrs = _unpack(temp, tdim)
     if tdim not in dims:
@@ -301,12 +356,18 @@ def _detect(temp, th, se, compute, tdim="time", minDuration=5, joinGaps=True, ma
         raise XmhwException("th and se have different doy coordinates")
     doy = cal.add_doy(time, keep_tstep=tstep)                  # xmhw.py:404 (no calendar sniffing here)
 
-    if on_device:
-        res = grid_compute(stacked, anynans, sec, thc, doy, doys, minDuration, joinGaps, maxGap, coldSpells,
-                           intermediate, clim_stacked=clim_stacked)
-        keep = res["keep"]
-    else:
-        res = compute(ts, sec, thc, doy, doys, minDuration, joinGaps, maxGap, coldSpells, intermediate)
+    pad = make_pad(maxPadLength, time)                         # xmhw.py:407-410, after land_check
+    extra = {} if pad is None else {"pad": pad}
+    try:
+        if on_device:
+            res = grid_compute(stacked, anynans, sec, thc, doy, doys, minDuration, joinGaps, maxGap, coldSpells,
+                               intermediate, clim_stacked=clim_stacked, **extra)
+            keep = res["keep"]
+        else:
+            res = compute(ts, sec, thc, doy, doys, minDuration, joinGaps, maxGap, coldSpells, intermediate, **extra)
+    finally:
+        if pad is not None:
+            pad.free()
     table, offsets = res["table"], res["offsets"]
     if coldSpells:                                             # flip_cold(), xmhw/features.py:298-315
         table = table.copy()

@@ -125,10 +125,12 @@ def _table_only_device(h, d_ts, isz, se_ptr, th_ptr, ldc, D, rows, T, n, neg, mi
             b.free()
 
 
-def _table_only_batch(h, ts, seas, thresh, rows, T, n, isz, neg, minDuration, joinGaps, maxGap):
+def _table_only_batch(h, ts, seas, thresh, rows, T, n, isz, neg, minDuration, joinGaps, maxGap, pad=None):
     bufs = []
     try:
         d_ts = DeviceBuffer.from_array(ts); bufs.append(d_ts)
+        if pad is not None:
+            pad.apply(d_ts.ptr, isz, T, n)
         d_se = DeviceBuffer.from_array(seas); bufs.append(d_se)
         d_th = DeviceBuffer.from_array(thresh); bufs.append(d_th)
         return _table_only_device(h, d_ts, isz, d_se.ptr, d_th.ptr, n, thresh.shape[0], rows, T, n, neg, minDuration,
@@ -139,7 +141,7 @@ def _table_only_batch(h, ts, seas, thresh, rows, T, n, isz, neg, minDuration, jo
 
 
 def detect_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
-                 intermediate=False, max_batch_bytes=64 << 30, per_step_kernels=False):
+                 intermediate=False, max_batch_bytes=64 << 30, per_step_kernels=False, pad=None):
     """define_events() (xmhw/identify.py:329-412) for all cells of a dense (T, C) series on the
     GPU: th.sel(doy=ts.doy) + exceedance + mhw_filter() + mhw_df() + mhw_features()
     (xmhw/features.py:22-315), without the xarray/pandas packaging.
@@ -155,6 +157,8 @@ def detect_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxG
     Without `intermediate` no per-step array is produced on the device either (bit-packed
     exceedances, one thread per event); per_step_kernels=True forces the per-step kernels
     (detect_events + event_stats) that `intermediate` needs — both give the same table.
+    ``pad`` (padding.PadSpec): maxPadLength's interpolate_na on the device copy of every batch
+    (xmhw/xmhw.py:409-410); the `ts` column of `intermediate` is the interpolated series.
     """
     ts, seas, thresh, rows = _check_inputs(ts, seas, thresh, doy, doys)
     T, C = ts.shape
@@ -176,13 +180,18 @@ def detect_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxG
         if not intermediate and not per_step_kernels:
             tab, counts = _table_only_batch(h, np.ascontiguousarray(ts[:, c0:c1]), np.ascontiguousarray(seas[:, c0:c1]),
                                             np.ascontiguousarray(thresh[:, c0:c1]), rows, T, n, isz, neg,
-                                            minDuration, joinGaps, maxGap)
+                                            minDuration, joinGaps, maxGap, pad=pad)
             tables.append(tab)
             counts_all.append(counts)
             continue
         bufs = []
         try:
             d_ts = DeviceBuffer.from_array(np.ascontiguousarray(ts[:, c0:c1])); bufs.append(d_ts)
+            if pad is not None:
+                pad.apply(d_ts.ptr, isz, T, n)
+                if intermediate:
+                    filled = d_ts.to_array((T, n), ts.dtype)
+                    inter["ts"][:, c0:c1] = -filled if coldSpells else filled
             d_th = DeviceBuffer.from_array(np.ascontiguousarray(thresh[:, c0:c1])); bufs.append(d_th)
             d_se = DeviceBuffer.from_array(np.ascontiguousarray(seas[:, c0:c1])); bufs.append(d_se)
             d_ev, d_st, d_en = (DeviceBuffer(4 * T * n) for _ in range(3))
@@ -231,7 +240,8 @@ def detect_cells(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxG
 
 
 def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
-                intermediate=False, max_batch_bytes=None, clim_stacked=False, columns=None, exchange=None):
+                intermediate=False, max_batch_bytes=None, clim_stacked=False, columns=None, exchange=None,
+                resident=None, pad=None):
     """detect_cells() for an UNCOMPACTED stacked host series (T, N): land_check()'s mask and
     compaction run on the device (device.compact_columns), slab by slab.  The climatologies are
     either already compacted (D, C) arrays, or - clim_stacked=True - uncompacted (D, N) arrays whose
@@ -242,8 +252,10 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
     masked and compacted first, then ``exchange(n_kept)`` must return (offset of this block's first
     survivor among all survivors, total number of survivors) - the climatology columns are taken at
     that offset - and the result covers the block only (keep has c1 - c0 entries, no error for an
-    all-land block)."""
-    from .device import _grid_batch, compact_columns, decode_on_host, device_itemsize, is_packed
+    all-land block).  ``resident`` (device.ResidentSeries filled by calc_clim_grid_device for the same host
+    array and mask rule): its compacted device slabs are used instead of a second upload."""
+    from .device import ResidentSeries, _grid_batch, compact_columns, decode_on_host, device_itemsize, is_packed
+    rkey = ResidentSeries.key_of(stacked, anynans) if resident is not None else None
     if is_packed(stacked):
         if intermediate:
             stacked = decode_on_host(stacked)       # the per-step path compacts on the host anyway
@@ -265,7 +277,7 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
             raise XmhwException(f"temp, th and se do not have the same ocean cells: {ts_c.shape[1]}, "
                                 f"{thresh_c.shape[1]}, {seas_c.shape[1]}")
         r = detect_cells(ts_c, seas_c, thresh_c, doy, doys, minDuration, joinGaps, maxGap, coldSpells, intermediate,
-                         max_batch_bytes if max_batch_bytes is not None else 64 << 30)
+                         max_batch_bytes if max_batch_bytes is not None else 64 << 30, pad=pad)
         r["keep"] = keep
         return r
 
@@ -307,6 +319,9 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
         cb = _grid_batch(stacked, max_batch_bytes, per_cell_extra=6 * D * 8 + T // 8 + 64)
         c0, c1 = (0, N) if columns is None else (int(columns[0]), int(columns[1]))
         slabs = [(lo, min(c1, lo + cb)) for lo in range(c0, c1, cb)]
+        reuse = resident is not None and columns is None and resident.matches(rkey, c0, c1)
+        if reuse:
+            slabs = [b for b, _, _, _ in resident.slabs]
         held = []                                   # sharded: compacted slabs wait for the offset exchange
         try:
             if columns is not None:
@@ -321,6 +336,8 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
                 if columns is not None:
                     d_ts, keep = held[i]
                     held[i] = (None, keep)
+                elif reuse:
+                    _, d_ts, keep, _ = resident.slabs[i]
                 else:
                     d_ts, keep = compact_columns(stacked, lo, hi, anynans)
                 keeps.append(keep)
@@ -328,12 +345,15 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
                 if d_ts is None:
                     continue
                 try:
+                    if pad is not None:
+                        pad.apply(d_ts.ptr, isz, T, n)      # (a retained slab is already interpolated: a no-op then)
                     if k0 + n > C:
                         raise XmhwException(f"temp has more ocean cells than th and se ({C})")
                     tab, counts = _table_only_device(h, d_ts, isz, d_se.ptr + 8 * k0, d_th.ptr + 8 * k0, C, D, rows, T,
                                                      n, neg, minDuration, joinGaps, maxGap)
                 finally:
-                    d_ts.free()
+                    if not reuse:
+                        d_ts.free()
                 tables.append(tab)
                 counts_all.append(counts)
                 k0 += n

@@ -213,7 +213,7 @@ def clim_finish(plan, th_in, se_in, C, feb29_fix, smooth, width, th_out, se_out,
 
 def calc_clim_device(ts, doy, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
                      tstep, coldSpells=False, kernel="auto", nchunks=0, max_batch_bytes=32 << 30,
-                     narrowing=True):
+                     narrowing=True, pad=None):
     """calc_clim() (xmhw/xmhw.py:250-307) for all cells of a dense host (T, C)
     array on the GPU.  Returns (doys[D] int64, thresh[D, C], seas[D, C]).
 
@@ -222,6 +222,7 @@ def calc_clim_device(ts, doy, pctile, windowHalfWidth, smoothPercentile, smoothP
     identical to a single call.  PCIe-inclusive: the input is copied to the device.
     float64 input whose samples are all float32-representable runs on the float32 ring kernel
     (decided on the device, see xmhw_plan_set_narrowing); narrowing=False forces the float64 one.
+    ``pad`` (padding.PadSpec): maxPadLength's interpolate_na, applied to the device copy of every batch.
     """
     ts = native_float(ts)
     if ts.ndim != 2:
@@ -252,6 +253,8 @@ def calc_clim_device(ts, doy, pctile, windowHalfWidth, smoothPercentile, smoothP
             n = min(cb, C - lo)
             slab = np.ascontiguousarray(ts[:, lo:lo + n])
             h.memcpy_h2d(d_ts.ptr, slab)
+            if pad is not None:
+                pad.apply(d_ts.ptr, isz, T, n)
             clim_raw(plan, d_ts, isz, n, pctile / 100.0, coldSpells, raw_th, raw_se)
             if finish:
                 clim_finish(plan, raw_th, raw_se, n, feb29_fix, smoothPercentile, smoothPercentileWidth,
@@ -429,6 +432,52 @@ def device_itemsize(stacked):
     return stacked.decoded_dtype.itemsize if is_packed(stacked) else stacked.dtype.itemsize
 
 
+class ResidentSeries:
+    """The compacted device copies of a stacked host series' column slabs, kept between two entry
+    points that work on the SAME host array (threshold() then detect(): xmhw_amd.threshold_detect),
+    so that the series crosses PCIe once.  An entry is ((lo, hi), DeviceBuffer or None, keep mask,
+    item size).  The store only accepts a series that leaves room to work in
+    (``XMHW_AMD_RESIDENT_FRACTION`` of the device's HBM, default 0.45: 130 GB on an MI355X); the
+    consumer falls back to its own upload when the key does not match or nothing was retained."""
+
+    def __init__(self):
+        self.key = None
+        self.slabs = []
+
+    @staticmethod
+    def key_of(stacked, anynans):
+        a = np.asarray(stacked)
+        decode = repr(getattr(stacked, "decode", None)) if is_packed(stacked) else ""
+        return (a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str, decode, bool(anynans))
+
+    def accepts(self, stacked):
+        try:
+            h = hip()
+            hbm = h.device_info(h.get_device())["hbm_bytes"]
+        except Exception:
+            return False
+        frac = float(_os.environ.get("XMHW_AMD_RESIDENT_FRACTION", "0.45"))
+        return stacked.shape[0] * stacked.shape[1] * device_itemsize(stacked) <= frac * hbm
+
+    def begin(self, key):
+        self.free()
+        self.key = key
+
+    def add(self, bounds, d_ts, keep, isz):
+        self.slabs.append((tuple(bounds), d_ts, keep, isz))
+
+    def matches(self, key, c0, c1):
+        return (self.key is not None and self.key == key and bool(self.slabs)
+                and self.slabs[0][0][0] == c0 and self.slabs[-1][0][1] == c1)
+
+    def free(self):
+        for _, d_ts, _, _ in self.slabs:
+            if d_ts is not None:
+                d_ts.free()
+        self.slabs = []
+        self.key = None
+
+
 class SlabPrefetcher:
     """Iterates over column slabs of a host array with the NEXT slab's upload (and decode) running in
     a background thread while the caller computes on the current one: pageable pitched copies are
@@ -505,7 +554,7 @@ def _grid_batch(stacked, max_batch_bytes, per_cell_extra=0, pipeline=True):
     return cb
 
 
-def _grid_block_on_device(plan, stacked, c0, c1, anynans, pctile, coldSpells, feb29_fix, smooth, width):
+def _grid_block_on_device(plan, stacked, c0, c1, anynans, pctile, coldSpells, feb29_fix, smooth, width, pad=None):
     """One rank's column block: mask, compact, climatology, placement back on the block's grid --
     results stay on the device as a dense (2D, w) block.  Returns (keep, doys, DeviceBuffer, None)."""
     h = hip()
@@ -523,6 +572,8 @@ def _grid_block_on_device(plan, stacked, c0, c1, anynans, pctile, coldSpells, fe
             h.stream_sync(0)
             return keep, plan.doys.copy(), block, None
         bufs.append(d_ts)
+        if pad is not None:
+            pad.apply(d_ts.ptr, isz, stacked.shape[0], n)
         raw_th, raw_se = DeviceBuffer(8 * D * n), DeviceBuffer(8 * D * n)
         bufs += [raw_th, raw_se]
         clim_raw(plan, d_ts, isz, n, pctile / 100.0, coldSpells, raw_th, raw_se)
@@ -557,7 +608,7 @@ def _grid_block_on_device(plan, stacked, c0, c1, anynans, pctile, coldSpells, fe
 
 def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
                           tstep, coldSpells=False, kernel="auto", nchunks=0, max_batch_bytes=None,
-                          narrowing=True, columns=None, scatter=True, device_block=False):
+                          narrowing=True, columns=None, scatter=True, device_block=False, resident=None, pad=None):
     """land_check() + calc_clim() for an UNCOMPACTED stacked host array (T, N): the land mask, the
     compaction and the placement of the results back on the grid (what unstack('cell') does) run on
     the device, so the host only hands the array over (for a global grid numpy's dropna and
@@ -568,7 +619,12 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
     keep and the arrays then cover c1 - c0 columns and an all-land slab is not an error).
     ``device_block=True`` (sharded runs) leaves the result on the device: the third return value is
     a DeviceBuffer holding ONE dense (2D, c1 - c0) float64 block -- the D thresh rows, then the D seas
-    rows, on the grid with NaN at the dropped cells -- ready for xmhw_gather_blocks; the fourth is None."""
+    rows, on the grid with NaN at the dropped cells -- ready for xmhw_gather_blocks; the fourth is None.
+    ``resident`` (a ResidentSeries) keeps every slab's compacted device copy for a later consumer of the
+    same host array instead of freeing it.  ``pad`` (padding.PadSpec): maxPadLength's interpolate_na, applied
+    to every compacted slab AFTER the mask (the reference interpolates after land_check, xmhw.py:137-160);
+    a retained slab is the interpolated one."""
+    rkey = ResidentSeries.key_of(stacked, anynans) if resident is not None else None
     if is_packed(stacked):
         if stacked.ndim != 2 or stacked.strides[1] != stacked.dtype.itemsize:
             raise XmhwException("a file view must have contiguous rows (time, cells)")
@@ -592,9 +648,12 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
                 raise XmhwException(f"a block of {c1 - c0} columns does not fit this device in one piece "
                                     f"({cb} columns do): use more ranks")
             return _grid_block_on_device(plan, stacked, c0, c1, anynans, pctile, coldSpells, feb29_fix,
-                                         smoothPercentile, smoothPercentileWidth)
+                                         smoothPercentile, smoothPercentileWidth, pad=pad)
         slabs = [(lo, min(c1, lo + cb)) for lo in range(c0, c1, cb)]
         many = len(slabs) > 1
+        retain = resident is not None and resident.accepts(stacked)
+        if retain:
+            resident.begin(rkey)
         th = se = None
         if many and scatter:
             # results go straight to their columns of the full-width host arrays (pitched device-to-host copy)
@@ -612,14 +671,18 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
             _tl = _time.perf_counter()
             keeps.append(keep)
             w = hi - lo
+            if retain:
+                resident.add((lo, hi), d_ts, keep, isz)
             if d_ts is None:
                 if th is not None:
                     th[:, lo - c0:hi - c0] = np.nan
                     se[:, lo - c0:hi - c0] = np.nan
                 continue
             n = int(keep.sum())
-            bufs = [d_ts]
+            bufs = [] if retain else [d_ts]
             try:
+                if pad is not None:
+                    pad.apply(d_ts.ptr, isz, T, n)
                 raw_th, raw_se = DeviceBuffer(8 * D * n), DeviceBuffer(8 * D * n)
                 bufs += [raw_th, raw_se]
                 clim_raw(plan, d_ts, isz, n, pctile / 100.0, coldSpells, raw_th, raw_se)

@@ -172,7 +172,7 @@ def make_sharded_compute(transport, dst=0, compute=None):
     inner = compute or calc_clim_device
 
     def sharded(ts, doy, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
-                tstep, coldSpells=False):
+                tstep, coldSpells=False, **extra):          # extra: e.g. pad= (maxPadLength), per-column work
         C = ts.shape[1]
         lo, hi = slab_bounds(C, transport.size)[transport.rank]
         doys = np.unique(np.asarray(doy, dtype=np.int64))
@@ -181,7 +181,7 @@ def make_sharded_compute(transport, dst=0, compute=None):
             if hi <= lo:
                 return np.empty((doys.shape[0], 0)), np.empty((doys.shape[0], 0))
             _, th, se = inner(np.ascontiguousarray(ts[:, lo:hi]), doy, pctile, windowHalfWidth, smoothPercentile,
-                              smoothPercentileWidth, tstep, coldSpells)
+                              smoothPercentileWidth, tstep, coldSpells, **extra)
             return th, se
 
         th_r, se_r = _stage(transport, local)
@@ -205,13 +205,13 @@ def make_sharded_grid_compute(transport, dst=0, grid_compute=None):
     inner = grid_compute or calc_clim_grid_device
 
     def sharded(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
-                tstep, coldSpells=False):
+                tstep, coldSpells=False, **extra):
         N = stacked.shape[1]
         lo, hi = slab_bounds(N, transport.size)[transport.rank]
 
         def local():
             return inner(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile,
-                         smoothPercentileWidth, tstep, coldSpells, columns=(lo, hi))
+                         smoothPercentileWidth, tstep, coldSpells, columns=(lo, hi), **extra)
 
         keep_r, doys, th_r, se_r = _stage(transport, local)
         D = doys.shape[0]
@@ -236,11 +236,11 @@ def make_sharded_grid_compute(transport, dst=0, grid_compute=None):
 
 
 def _device_grid_compute(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
-                         tstep, coldSpells=False, columns=None):
+                         tstep, coldSpells=False, columns=None, **extra):
     """calc_clim_grid_device for one rank's block with the results LEFT ON THE DEVICE as one dense
     (2D, w) float64 block (thresh rows, then seas rows), ready for xmhw_gather_blocks."""
     return calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile,
-                                 smoothPercentileWidth, tstep, coldSpells, columns=columns, device_block=True)
+                                 smoothPercentileWidth, tstep, coldSpells, columns=columns, device_block=True, **extra)
 
 
 def threshold_sharded(temp, transport, dst=0, _compute=None, _grid_compute=None, **kwargs):
@@ -268,7 +268,7 @@ def make_sharded_detect(transport, dst=0, compute=None):
     BOOL_VARIABLES = set(INTERMEDIATE_U8) | {"bthresh"}
 
     def sharded(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
-                intermediate=False):
+                intermediate=False, **extra):
         T, C = ts.shape
         lo, hi = slab_bounds(C, transport.size)[transport.rank]
 
@@ -277,7 +277,7 @@ def make_sharded_detect(transport, dst=0, compute=None):
                 return dict(table=np.zeros((0, ncol)), offsets=np.zeros(1, dtype=np.int64), inter=None)
             return inner(np.ascontiguousarray(ts[:, lo:hi]), np.ascontiguousarray(seas[:, lo:hi]),
                          np.ascontiguousarray(thresh[:, lo:hi]), doy, doys, minDuration, joinGaps, maxGap,
-                         coldSpells, intermediate)
+                         coldSpells, intermediate, **extra)
 
         res = _stage(transport, local)
         counts = np.diff(res["offsets"]).astype(np.float64)[None, :]
@@ -320,7 +320,7 @@ def make_sharded_detect_grid(transport, dst=0, grid_compute=None):
     ncol = len(EVENT_COLUMNS)
 
     def sharded(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
-                intermediate=False, clim_stacked=False):
+                intermediate=False, clim_stacked=False, **extra):
         N = stacked.shape[1]
         lo, hi = slab_bounds(N, transport.size)[transport.rank]
         if intermediate:
@@ -340,7 +340,7 @@ def make_sharded_detect_grid(transport, dst=0, grid_compute=None):
         def local():
             try:
                 return inner(stacked, anynans, seas, thresh, doy, doys, minDuration, joinGaps, maxGap, coldSpells,
-                             False, clim_stacked=clim_stacked, columns=(lo, hi), exchange=exchange)
+                             False, clim_stacked=clim_stacked, columns=(lo, hi), exchange=exchange, **extra)
             except Exception:
                 if not state["exchanged"]:
                     exchange(0)
