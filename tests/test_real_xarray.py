@@ -66,3 +66,29 @@ def test_threshold_and_detect_with_real_xarray_on_the_gpu():
     mhw = xmhw_amd.detect(da, ds["thresh"], ds["seas"])
     assert isinstance(mhw, xr.Dataset) and mhw["duration"].dims == ("events", "lat", "lon")
     assert str(mhw["time_start"].dtype).startswith("datetime64")
+
+
+def test_pad_oracle_equals_real_interpolate_na():
+    """oracle/pad_oracle.py (the checker of the pad_gaps kernel) against the real
+    DataArray.interpolate_na(dim, max_gap=...), including its type rules"""
+    import pad_oracle as po
+    from xmhw_amd import padding
+    rng = np.random.default_rng(5)
+    T, C = 400, 12
+    time = np.datetime64("2001-01-01") + np.arange(T).astype("timedelta64[D]")
+    for dtype in (np.float32, np.float64):
+        y = rng.normal(size=(T, C)).astype(dtype)
+        for c in range(C):
+            for _ in range(8):
+                a = int(rng.integers(0, T))
+                y[a:a + int(rng.integers(1, 9)), c] = np.nan
+        y[:, 0] = np.nan
+        da = xr.DataArray(y, dims=("time", "cell"), coords={"time": time})
+        for gap in (np.timedelta64(2, "D"), np.timedelta64(5, "D"), "3D"):
+            ref = da.interpolate_na(dim="time", max_gap=gap).values
+            got = po.interpolate_na(y, po.interp_index(time), padding.max_gap_value(gap, time))
+            npt.assert_array_equal(got, ref)
+    with pytest.raises(TypeError):
+        da.interpolate_na(dim="time", max_gap=5)            # what the reference's documented call runs into
+    with pytest.raises(TypeError):
+        padding.max_gap_value(5, time)
