@@ -414,7 +414,7 @@ def run(args):
             "physical_cores": pool.physical, "logical_cpus": pool.logical,
             "sample": f"first {ncpu} cells of the same synthetic input ({ncpu // r['processes']} per process), per-cell numpy "
                       f"restatement (366 x np.quantile + mean per cell, as xmhw/xmhw.py:184-197 does one calc_clim per "
-                      f"cell), one spawned process per physical core; pool start-up and the pool index outside the timed "
+                      f"cell), one spawned process per usable core (physical cores, capped by the cgroup CPU quota); pool start-up and the pool index outside the timed "
                       f"region; excludes xarray/dask per-cell overhead, so it flatters the reference",
             "wall_s": r["wall_s"],
             "max_rel_diff_vs_gpu": float(np.nanmax(np.abs(g_th - r["thresh"]) / np.abs(r["thresh"]))),

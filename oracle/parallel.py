@@ -119,7 +119,12 @@ class OraclePool:
     def __init__(self, doy, windowHalfWidth=5, workers=None):
         phys, logical = physical_cores()
         self.physical, self.logical = phys, logical
-        self.workers = int(workers or phys)
+        # one worker per physical core, but not more than the cgroup lets run at once: 128 processes on a
+        # 16-CPU quota measure the throttle, not the function
+        quota = cpu_quota()
+        usable = phys if quota is None else max(1, min(phys, int(-(-quota // 1))))
+        self.quota = quota
+        self.workers = int(workers or usable)
         ctx = mp.get_context("spawn")
         oracle_dir = os.path.dirname(os.path.abspath(__file__))
         # the workers only ever run functions of THIS module: keep multiprocessing from re-importing

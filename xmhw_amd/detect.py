@@ -356,6 +356,9 @@ def _detect(temp, th, se, compute, tdim="time", minDuration=5, joinGaps=True, ma
         raise XmhwException("th and se have different doy coordinates")
     doy = cal.add_doy(time, keep_tstep=tstep)                  # xmhw.py:404 (no calendar sniffing here)
 
+    import time as _time
+    from .device import _trace
+    _t0 = _time.perf_counter()
     pad = make_pad(maxPadLength, time)                         # xmhw.py:407-410, after land_check
     extra = {} if pad is None else {"pad": pad}
     try:
@@ -368,6 +371,7 @@ def _detect(temp, th, se, compute, tdim="time", minDuration=5, joinGaps=True, ma
     finally:
         if pad is not None:
             pad.free()
+    _trace("detect: device stage", _t0)
     table, offsets = res["table"], res["offsets"]
     if coldSpells:                                             # flip_cold(), xmhw/features.py:298-315
         table = table.copy()

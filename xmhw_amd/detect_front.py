@@ -254,7 +254,9 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
     that offset - and the result covers the block only (keep has c1 - c0 entries, no error for an
     all-land block).  ``resident`` (device.ResidentSeries filled by calc_clim_grid_device for the same host
     array and mask rule): its compacted device slabs are used instead of a second upload."""
-    from .device import ResidentSeries, _grid_batch, compact_columns, decode_on_host, device_itemsize, is_packed
+    import time as _time
+    from .device import ResidentSeries, _grid_batch, _trace, compact_columns, decode_on_host, device_itemsize, is_packed
+    _t_all = _time.perf_counter()
     rkey = ResidentSeries.key_of(stacked, anynans) if resident is not None else None
     if is_packed(stacked):
         if intermediate:
@@ -287,8 +289,18 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
             return host_path(host_compact(np.asarray(seas, dtype=np.float64))[0],
                              host_compact(np.asarray(thresh, dtype=np.float64))[0])
         return host_path(seas, thresh)
-    seas = np.ascontiguousarray(seas, dtype=np.float64)
-    thresh = np.ascontiguousarray(thresh, dtype=np.float64)
+    def rows_as_they_are(a):
+        # threshold() hands its climatologies over as row-pitched views when an all-land band was cut
+        # from the grid (landmask.compress_axis): the pitched upload takes them as they are; only other
+        # layouts / dtypes are copied (2 x 2.5 GB on the host for a global grid otherwise)
+        a = np.asarray(a)
+        if a.ndim == 2 and a.dtype == np.float64 and a.dtype.isnative and (a.shape[1] <= 1 or a.strides[1] == 8) \
+                and a.strides[0] >= 8 * a.shape[1]:
+            return a
+        return np.ascontiguousarray(a, dtype=np.float64)
+
+    seas = rows_as_they_are(seas)
+    thresh = rows_as_they_are(thresh)
     if seas.ndim != 2 or thresh.ndim != 2 or seas.shape[0] != thresh.shape[0]:
         raise XmhwException("seas and thresh must be (D, cells) arrays")
     D = thresh.shape[0]
@@ -339,7 +351,9 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
                 elif reuse:
                     _, d_ts, keep, _ = resident.slabs[i]
                 else:
+                    _tl = _time.perf_counter()
                     d_ts, keep = compact_columns(stacked, lo, hi, anynans)
+                    _trace(f"detect: upload + mask + compact [{lo},{hi})", _tl)
                 keeps.append(keep)
                 n = int(keep.sum())
                 if d_ts is None:
@@ -349,8 +363,10 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
                         pad.apply(d_ts.ptr, isz, T, n)      # (a retained slab is already interpolated: a no-op then)
                     if k0 + n > C:
                         raise XmhwException(f"temp has more ocean cells than th and se ({C})")
+                    _tl = _time.perf_counter()
                     tab, counts = _table_only_device(h, d_ts, isz, d_se.ptr + 8 * k0, d_th.ptr + 8 * k0, C, D, rows, T,
                                                      n, neg, minDuration, joinGaps, maxGap)
+                    _trace(f"detect: bits + runs + event table ({tab.shape[0]} events)", _tl)
                 finally:
                     if not reuse:
                         d_ts.free()
@@ -364,6 +380,7 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
     finally:
         for b in clim_bufs:
             b.free()
+    _trace("detect_grid: all slabs", _t_all)
     keep = np.concatenate(keeps) if keeps else np.zeros(0, dtype=bool)
     if columns is None:
         if not keep.any():

@@ -68,6 +68,7 @@ _POOL = []
 _POOL_SLOTS = 4
 _POOL_MIN = 1 << 30
 _POOL_MAX_BYTES = int(float(_os.environ.get("XMHW_AMD_POOL_GB", "96")) * (1 << 30))
+_TRACE = _os.environ.get("XMHW_AMD_TRACE", "0") != "0"
 
 
 def release_device_cache():
@@ -106,6 +107,12 @@ class DeviceBuffer:
                 i = min(fit, key=lambda k: _POOL[k][0])
                 self.capacity, self.ptr, _ = _POOL.pop(i)
                 return
+        if _TRACE and self.nbytes >= _POOL_MIN:
+            import time as _time
+            _t0 = _time.perf_counter()
+            self.ptr = self._h.malloc(self.nbytes)
+            _trace(f"hipMalloc {self.nbytes / 1e9:.2f} GB (pool: {[round(c / 1e9, 2) for c, _, _ in _POOL]})", _t0)
+            return
         self.ptr = self._h.malloc(self.nbytes)   # out of memory: the pool is drained and the call retried (_lib)
 
     @classmethod
@@ -129,6 +136,11 @@ class DeviceBuffer:
             if (self.capacity >= _POOL_MIN and len(_POOL) < _POOL_SLOTS
                     and device_cache_bytes() + self.capacity <= _POOL_MAX_BYTES):
                 _POOL.append((self.capacity, self.ptr, self.device))
+            elif _TRACE and self.capacity >= _POOL_MIN:
+                import time as _time
+                _t0 = _time.perf_counter()
+                self._h.free(self.ptr)
+                _trace(f"hipFree {self.capacity / 1e9:.2f} GB (pool: {[round(c / 1e9, 2) for c, _, _ in _POOL]})", _t0)
             else:
                 self._h.free(self.ptr)
             self.ptr = 0
@@ -283,7 +295,6 @@ _STAGE = {}
 _USE_STAGING = _os.environ.get("XMHW_AMD_STAGING", "1") != "0"
 _STAGE_BYTES = 1 << 30
 _STAGE_THREADS = int(_os.environ.get("XMHW_AMD_STAGE_THREADS", "32"))
-_TRACE = _os.environ.get("XMHW_AMD_TRACE", "0") != "0"
 
 
 def _trace(label, t0):
@@ -550,8 +561,27 @@ def _grid_batch(stacked, max_batch_bytes, per_cell_extra=0, pipeline=True):
         per_cell += T * stacked.dtype.itemsize            # the next slab's upload is resident too
     cb = int(max(1, min(N, max_batch_bytes // max(per_cell, 1))))
     if pipeline and T * N * stacked.dtype.itemsize >= (4 << 30):
-        cb = min(cb, -(-N // 8))
+        # the first slab's upload overlaps nothing: 16 slabs leave 1/16 of the PCIe time exposed
+        # (XMHW_AMD_SLABS overrides; a slab still holds tens of thousands of cells)
+        nslabs = max(1, int(_os.environ.get("XMHW_AMD_SLABS", "16")))
+        cb = min(cb, max(-(-N // nslabs), min(N, 16384)))
     return cb
+
+
+def _prefault(*arrays):
+    """Touch every page of freshly allocated result arrays in a background thread: the kernel zeroes a
+    page on its first write (6 GB for a global 0.25 degree grid, 0.23 s inside the first device-to-host
+    copy otherwise), and that can happen while the first slab is still on its way to the device."""
+    import threading
+
+    def touch():
+        for a in arrays:
+            flat = a.reshape(-1)
+            flat[::512] = 0.0            # one write per 4 KB (numpy releases the GIL for the strided fill)
+
+    t = threading.Thread(target=touch, daemon=True)
+    t.start()
+    return t
 
 
 def _grid_block_on_device(plan, stacked, c0, c1, anynans, pctile, coldSpells, feb29_fix, smooth, width, pad=None):
@@ -659,6 +689,7 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
             # results go straight to their columns of the full-width host arrays (pitched device-to-host copy)
             th = np.empty((D, c1 - c0))
             se = np.empty((D, c1 - c0))
+            _prefault(th, se)
         # slab k+1 is uploaded (and decoded) by a second thread while slab k computes
         pre = SlabPrefetcher(stacked, slabs)
         import time as _time
