@@ -293,7 +293,7 @@ def calc_clim_device(ts, doy, pctile, windowHalfWidth, smoothPercentile, smoothP
 # the other buffer is being filled.
 _STAGE = {}
 _USE_STAGING = _os.environ.get("XMHW_AMD_STAGING", "1") != "0"
-_STAGE_BYTES = 1 << 30
+_STAGE_BYTES = int(_os.environ.get("XMHW_AMD_STAGE_MB", "256")) << 20   # per buffer, two of them; 128-1024 MB measured alike, the small ones ramp up faster per slab
 _STAGE_THREADS = int(_os.environ.get("XMHW_AMD_STAGE_THREADS", "32"))
 
 
