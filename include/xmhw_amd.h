@@ -81,6 +81,13 @@ int xmhw_event_sync(void *event);                           /* block the host un
 int xmhw_decode(const void *raw_dev, int raw_itemsize, int big_endian, int64_t rows, int64_t cols,
                 int64_t ld_raw, void *out_dev, int out_itemsize, int64_t ld_out, int has_scale,
                 double scale_factor, double add_offset, int has_fill, double fill_value, void *stream);
+/* File bytes -> a (page-locked) host buffer without mapping the file: `rows` strips of row_bytes bytes,
+ * row_pitch apart in the file starting at file_offset, are read with pread() into a dense buffer.
+ * Thread-safe; the ingest path calls it from many threads at once (copies out of an mmap() of the same
+ * file queue up on the process's page-fault path instead).  Replaces the read half of
+ * xr.open_dataset(...) (docs/gettingstarted.rst:30-33) for netCDF classic files.                   */
+int xmhw_read_rows(int fd, int64_t file_offset, int64_t row_pitch, int64_t row_bytes, int64_t rows,
+                   void *dst_host);
 /* maxPadLength: `ts.interpolate_na(dim=tdim, max_gap=maxPadLength)` (xmhw/xmhw.py:159-160, :409-410;
  * xarray's linear interpolate_na with use_coordinate=True) on the device copy of a compacted series
  * (T, C), leading dimension ld, IN PLACE.  x_dev[T] = the numeric time coordinate (float64; for

@@ -105,3 +105,38 @@ def test_cf_time_decoding():
     assert d[2].dayofyr == 360 and d[3].year == 2002 and d[3].calendar == "360_day"
     with pytest.raises(XmhwException):
         ingest.decode_time([0], "fortnights since 2000-01-01")
+
+
+def test_read_rows_and_file_window(tmp_path):
+    """xmhw_read_rows (pread into a dense buffer; host-only entry of the C ABI) and the window arithmetic
+    that maps a view of the mapped variable back to file offsets (device._file_window)"""
+    import os
+    from xmhw_amd import _xmhw_hip as h
+    from xmhw_amd import netcdf3
+    from xmhw_amd.device import _file_window
+    T, ny, nx = 9, 5, 7
+    data = np.arange(T * ny * nx, dtype=np.float32).reshape(T, ny, nx)
+    other = np.arange(T, dtype=np.float64)            # a second record variable: rows of `sst` become pitched
+    path = str(tmp_path / "two_records.nc")
+    netcdf3.write_classic(path, {"time": T, "y": ny, "x": nx},
+                          {"sst": (("time", "y", "x"), data, {}), "aux": (("time",), other, {})}, record_dim="time")
+    f = netcdf3.File(path)
+    v = np.asarray(f.variables["sst"].data).reshape(T, ny * nx)
+    assert v.strides[0] > ny * nx * 4                 # interleaved with `aux`
+    file = dict(fd=f.fileno(), address=f.map_address, length=f.map_length)
+    view = v[:, 3:20]
+    fd, off, pitch = _file_window(view, file)
+    dst = np.zeros(view.shape, dtype=">f4")
+    h.read_rows(fd, off, pitch, view.shape[1] * 4, T, dst.ctypes.data)
+    npt.assert_array_equal(dst, view)
+    npt.assert_array_equal(dst.astype(np.float32), data.reshape(T, -1)[:, 3:20])
+    # a part of the rows, as the staging threads ask for them
+    part = np.zeros((4, view.shape[1]), dtype=">f4")
+    h.read_rows(fd, off + 2 * pitch, pitch, view.shape[1] * 4, 4, part.ctypes.data)
+    npt.assert_array_equal(part, view[2:6])
+    # views that are not windows of the file are refused (the copy path takes them)
+    assert _file_window(np.ascontiguousarray(view), file) is None
+    assert _file_window(view[:, ::2], file) is None
+    with pytest.raises(h.InvalidArgument):
+        h.read_rows(fd, off, pitch, view.shape[1] * 4, T + 50, np.zeros((T + 50, view.shape[1]), ">f4").ctypes.data)
+    f.close()

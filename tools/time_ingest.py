@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--years", type=int, nargs=2, default=[1982, 2021])
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="a third call under cProfile (host-side hot spots to stderr)")
     args = ap.parse_args()
     import xmhw_amd
     from xmhw_amd import ingest, netcdf3
@@ -70,11 +71,25 @@ def main():
     t_write = time.perf_counter() - t0
     fbytes = os.path.getsize(path)
     out = {"file": path, "kind": args.kind, "file_GB": fbytes / 1e9, "T": T, "cells": N, "write_s": t_write}
-    for k in (1, 2):
+    for k in (1, 2, 3) if args.profile else (1, 2):
+        pr = None
+        if args.profile and k == 3:
+            import cProfile
+            pr = cProfile.Profile()
+            pr.enable()
         t0 = time.perf_counter()
         temp = ingest.open_series(path, "sst")
+        t_open = time.perf_counter() - t0
         ds = xmhw_amd.threshold(temp)
         dt_s = time.perf_counter() - t0
+        if pr is not None:
+            import io
+            import pstats
+            pr.disable()
+            s_ = io.StringIO()
+            pstats.Stats(pr, stream=s_).sort_stats("tottime").print_stats(18)
+            print(s_.getvalue()[:6000], file=sys.stderr)
+        out[f"open_s_{k}"] = t_open
         out[f"threshold_s_{k}"] = dt_s
         out[f"file_GBps_{k}"] = fbytes / 1e9 / dt_s
         out[f"float32_equiv_GBps_{k}"] = 4 * T * N / 1e9 / dt_s

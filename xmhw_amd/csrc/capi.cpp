@@ -2,6 +2,9 @@
 #include "../../include/xmhw_amd.h"
 
 #include <hip/hip_runtime.h>
+#include <unistd.h>
+
+#include <cerrno>
 
 #include <algorithm>
 #include <cstdio>
@@ -731,6 +734,31 @@ int xmhw_decode(const void* raw_dev, int raw_itemsize, int big_endian, int64_t r
     if (e == hipErrorInvalidValue)
         return fail(XMHW_ERR_UNSUPPORTED, "decode: stored/decoded type pair not supported (int16->f32/f64, f32->f32, f64->f64)");
     if (e != hipSuccess) return hip_fail(e, "decode launch");
+    return XMHW_OK;
+}
+int xmhw_read_rows(int fd, int64_t file_offset, int64_t row_pitch, int64_t row_bytes, int64_t rows, void* dst_host) {
+    // pread() copies from the page cache (or the disk) straight into the caller's buffer -- for the ingest
+    // path a page-locked staging buffer: no page of the file is ever mapped into this process, so many
+    // threads calling this at once do not queue up on the address space's page-fault path the way
+    // copies out of an mmap() do
+    if (fd < 0 || file_offset < 0 || row_pitch < row_bytes || row_bytes < 0 || rows < 0)
+        return fail(XMHW_ERR_INVALID, "bad fd/offset/pitch/row_bytes/rows");
+    if (rows == 0 || row_bytes == 0) return XMHW_OK;
+    if (!dst_host) return fail(XMHW_ERR_INVALID, "NULL destination");
+    char* dst = static_cast<char*>(dst_host);
+    for (int64_t r = 0; r < rows; ++r) {
+        int64_t done = 0;
+        while (done < row_bytes) {
+            const ssize_t got = ::pread(fd, dst + r * row_bytes + done, static_cast<size_t>(row_bytes - done),
+                                        static_cast<off_t>(file_offset + r * row_pitch + done));
+            if (got < 0) {
+                if (errno == EINTR) continue;
+                return fail(XMHW_ERR_INVALID, std::string("pread: ") + std::strerror(errno));
+            }
+            if (got == 0) return fail(XMHW_ERR_INVALID, "pread: unexpected end of file");
+            done += got;
+        }
+    }
     return XMHW_OK;
 }
 int xmhw_pad_gaps(void* ts_dev, int itemsize, int64_t T, int64_t C, int64_t ld, const double* x_dev, double max_gap,

@@ -403,6 +403,12 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     }, py::arg("raw"), py::arg("raw_itemsize"), py::arg("big_endian"), py::arg("rows"), py::arg("cols"), py::arg("ld_raw"),
        py::arg("out"), py::arg("out_itemsize"), py::arg("ld_out"), py::arg("has_scale"), py::arg("scale"),
        py::arg("offset"), py::arg("has_fill"), py::arg("fill"), py::arg("stream") = 0);
+    m.def("read_rows", [](int fd, int64_t off, int64_t pitch, int64_t row_bytes, int64_t rows, uintptr_t dst) {
+        py::gil_scoped_release r;
+        int rc = xmhw_read_rows(fd, off, pitch, row_bytes, rows, vp(dst));
+        py::gil_scoped_acquire a;
+        check(rc);
+    }, py::arg("fd"), py::arg("file_offset"), py::arg("row_pitch"), py::arg("row_bytes"), py::arg("rows"), py::arg("dst"));
     m.def("pad_gaps", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, uintptr_t x, double max_gap,
                          uintptr_t stream) {
         check(xmhw_pad_gaps(vp(ts), itemsize, T, C, ld, static_cast<const double*>(vp(x)), max_gap, vp(stream)));

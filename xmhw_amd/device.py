@@ -293,6 +293,7 @@ def calc_clim_device(ts, doy, pctile, windowHalfWidth, smoothPercentile, smoothP
 # the other buffer is being filled.
 _STAGE = {}
 _USE_STAGING = _os.environ.get("XMHW_AMD_STAGING", "1") != "0"
+_USE_PREAD = _os.environ.get("XMHW_AMD_PREAD", "1") != "0"
 _STAGE_BYTES = int(_os.environ.get("XMHW_AMD_STAGE_MB", "256")) << 20   # per buffer, two of them; 128-1024 MB measured alike, the small ones ramp up faster per slab
 _STAGE_THREADS = int(_os.environ.get("XMHW_AMD_STAGE_THREADS", "32"))
 
@@ -329,14 +330,31 @@ def release_staging():
     _STAGE.clear()
 
 
-def _staged_upload(dst_ptr, src):
-    """src: 2-D host array view (rows contiguous, any row pitch) -> dense device array at dst_ptr"""
+def _file_window(src, file):
+    """(fd, offset of src[0, 0] in the file, row pitch) if the 2-D view `src` lies inside the mapped file
+    described by `file` (PackedArray.decode['file']) with contiguous rows, else None"""
+    if not file or src.ndim != 2 or src.shape[0] == 0 or src.shape[1] == 0:
+        return None
+    if src.strides[1] != src.dtype.itemsize or src.strides[0] < src.shape[1] * src.dtype.itemsize:
+        return None
+    off = src.__array_interface__["data"][0] - file["address"]
+    last = off + (src.shape[0] - 1) * src.strides[0] + src.shape[1] * src.dtype.itemsize
+    if off < 0 or last > file["length"]:
+        return None
+    return file["fd"], off, src.strides[0]
+
+
+def _staged_upload(dst_ptr, src, file=None):
+    """src: 2-D host array view (rows contiguous, any row pitch) -> dense device array at dst_ptr.
+    `file`: the view is a window of a mapped file -- its rows are then read with pread() straight into
+    the staging buffers (xmhw_read_rows) instead of being copied out of the mapping."""
     h = hip()
     st = _stage()
     T, n = src.shape
     row_bytes = n * src.dtype.itemsize
     rows_per = max(1, _STAGE_BYTES // max(row_bytes, 1))
     pool = st["pool"]
+    win = _file_window(src, file) if _USE_PREAD else None
     for k, r0 in enumerate(range(0, T, rows_per)):
         r1 = min(T, r0 + rows_per)
         b = k % 2
@@ -344,8 +362,14 @@ def _staged_upload(dst_ptr, src):
             h.event_sync(st["events"][b])                  # the DMA that last read this buffer is done
         view = st["views"][b][: (r1 - r0) * row_bytes].view(src.dtype).reshape(r1 - r0, n)
         step = max(1, -(-(r1 - r0) // _STAGE_THREADS))
-        futs = [pool.submit(np.copyto, view[a - r0:min(r1, a + step) - r0], src[a:min(r1, a + step)])
-                for a in range(r0, r1, step)]
+        if win is not None:
+            fd, off, pitch = win
+            futs = [pool.submit(h.read_rows, fd, off + a * pitch, pitch, row_bytes, min(r1, a + step) - a,
+                                st["ptrs"][b] + (a - r0) * row_bytes)
+                    for a in range(r0, r1, step)]
+        else:
+            futs = [pool.submit(np.copyto, view[a - r0:min(r1, a + step) - r0], src[a:min(r1, a + step)])
+                    for a in range(r0, r1, step)]
         for f in futs:
             f.result()
         h.memcpy_h2d_async(dst_ptr + r0 * row_bytes, st["ptrs"][b], (r1 - r0) * row_bytes, st["stream"])
@@ -368,7 +392,8 @@ def upload_columns(stacked, lo, hi):
     d_raw = DeviceBuffer(raw_isz * T * n)
     try:
         if raw_isz * T * n >= _STAGE_MIN and _USE_STAGING:
-            _staged_upload(d_raw.ptr, np.asarray(stacked)[:, lo:hi])
+            _staged_upload(d_raw.ptr, np.asarray(stacked)[:, lo:hi],
+                           file=stacked.decode.get("file") if is_packed(stacked) else None)
         elif lo == 0 and hi == stacked.shape[1] and stacked.flags.c_contiguous:
             h.memcpy_h2d(d_raw.ptr, np.asarray(stacked))
         else:

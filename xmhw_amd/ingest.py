@@ -107,7 +107,9 @@ def open_series(path, varname=None, tdim=None):
     else:
         raise XmhwException(f"{path}: {var.name} is stored as {var.dtype}; the device decoder takes int16, float32, float64")
     decode = dict(scale=None if scale is None else float(scale), offset=None if offset is None else float(offset),
-                  fill=None if fill is None else float(fill), out=np.dtype(out).name)
+                  fill=None if fill is None else float(fill), out=np.dtype(out).name,
+                  # where the bytes live, for uploads that pread() instead of faulting the mapping in
+                  file=dict(fd=f.fileno(), address=f.map_address, length=f.map_length))
     coords, coord_attrs = {}, {}
     for d in var.dims:
         if d in f.variables and f.variables[d].dims == (d,):

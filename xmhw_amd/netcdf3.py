@@ -141,6 +141,9 @@ class File:
         self.numrecs = numrecs
         self.variables = {}
         base = np.frombuffer(self._mm, dtype=np.uint8)
+        # for readers that want to pread() instead of touching the mapping (xmhw_amd.device._staged_upload)
+        self.map_address = base.__array_interface__["data"][0]
+        self.map_length = len(self._mm)
         for (nm, dimids, at, t, vsize, begin), rr in zip(raw_vars, is_rec):
             dt = np.dtype(_TYPES[t])
             shape = [dim_len[d] for d in dimids]
@@ -166,6 +169,9 @@ class File:
                 count = int(np.prod(shape, dtype=np.int64)) if shape else 1
                 data = base[begin:begin + count * dt.itemsize].view(dt).reshape(shape)
             self.variables[nm] = Variable(nm, [dim_names[d] for d in dimids], shape, dt, at, data, rr)
+
+    def fileno(self):
+        return self._f.fileno()
 
     def close(self):
         self.variables = {}
