@@ -137,6 +137,7 @@ def test_read_rows_and_file_window(tmp_path):
     # views that are not windows of the file are refused (the copy path takes them)
     assert _file_window(np.ascontiguousarray(view), file) is None
     assert _file_window(view[:, ::2], file) is None
+    big = np.zeros((T + 50, view.shape[1]), ">f4")     # (kept in a name: the callee writes through the raw address)
     with pytest.raises(h.InvalidArgument):
-        h.read_rows(fd, off, pitch, view.shape[1] * 4, T + 50, np.zeros((T + 50, view.shape[1]), ">f4").ctypes.data)
+        h.read_rows(fd, off, pitch, view.shape[1] * 4, T + 50, big.ctypes.data)
     f.close()
