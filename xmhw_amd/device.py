@@ -596,7 +596,8 @@ def _grid_batch(stacked, max_batch_bytes, per_cell_extra=0, pipeline=True):
 def _prefault(*arrays):
     """Touch every page of freshly allocated result arrays in a background thread: the kernel zeroes a
     page on its first write (6 GB for a global 0.25 degree grid, 0.23 s inside the first device-to-host
-    copy otherwise), and that can happen while the first slab is still on its way to the device."""
+    copy otherwise), and that can happen while the first slab is still on its way to the device.
+    The toucher writes zeros, so the caller JOINS the returned thread before the first result is stored."""
     import threading
 
     def touch():
@@ -695,6 +696,7 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
     finish = feb29_fix or smoothPercentile
     keeps, ths, ses = [], [], []
     pre = None
+    touching = None
     try:
         cb = _grid_batch(stacked, max_batch_bytes, per_cell_extra=4 * D * 8)
         c0, c1 = (0, N) if columns is None else (int(columns[0]), int(columns[1]))
@@ -714,7 +716,7 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
             # results go straight to their columns of the full-width host arrays (pitched device-to-host copy)
             th = np.empty((D, c1 - c0))
             se = np.empty((D, c1 - c0))
-            _prefault(th, se)
+            touching = _prefault(th, se)
         # slab k+1 is uploaded (and decoded) by a second thread while slab k computes
         pre = SlabPrefetcher(stacked, slabs)
         import time as _time
@@ -731,6 +733,9 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
                 resident.add((lo, hi), d_ts, keep, isz)
             if d_ts is None:
                 if th is not None:
+                    if touching is not None:
+                        touching.join()            # the page toucher WRITES: it must be done before any result lands
+                        touching = None
                     th[:, lo - c0:hi - c0] = np.nan
                     se[:, lo - c0:hi - c0] = np.nan
                 continue
@@ -760,6 +765,9 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
                 _trace("kernels + scatter", _tl)
                 _tl = _time.perf_counter()
                 if th is not None:
+                    if touching is not None:
+                        touching.join()            # (see above; normally long finished: it runs during the first upload)
+                        touching = None
                     h.memcpy2d_d2h(th, lo - c0, w, out_th.ptr)
                     h.memcpy2d_d2h(se, lo - c0, w, out_se.ptr)
                     _trace("results to host (pitched)", _tl)
@@ -789,6 +797,8 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
             se[:, a - c0:b - c0] = y
         return keep, plan.doys.copy(), th, se
     finally:
+        if touching is not None:
+            touching.join()
         if pre is not None:
             pre.close()
         plan.destroy()
