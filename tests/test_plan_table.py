@@ -94,6 +94,29 @@ def test_too_many_tracks_falls_back_to_generic():
     assert p.kernel == "generic"
 
 
+def test_ring2_layout_choice():
+    """the second-generation float32 ring kernel: 8 lanes per cell unless the 4-lane layout pads fewer
+    tracks (capi.cpp: ring2_resolved); outside its instantiations the round-1 kernel runs (-1)"""
+    from xmhw_amd.device import Plan
+
+    def years(n, w=5, ring2=None):
+        t = np.arange("1982-01-01", f"{1982 + n}-01-01", dtype="datetime64[D]")
+        return Plan(ora.add_doy(t), w, ring2=ring2)
+
+    assert years(40).ring2_in_use() == 0                      # 8 x 5 = 40 tracks exactly
+    assert years(30).ring2_in_use() == 0                      # 8 x 4 and 4 x 8 both pad 2: a tie goes to 8 lanes
+    assert years(20).ring2_in_use() == 7                      # 4 x 5 = 20 exactly, 8 x 3 would pad 4
+    assert Plan(np.tile(np.arange(1, 1461), 20), 5).ring2_in_use() == 7      # config 5's tstep axis
+    assert years(20, ring2=0).ring2_in_use() == 0             # forced
+    assert years(40, ring2=7).ring2_in_use() == 7
+    assert years(40, ring2=-1).ring2_in_use() == -1           # round-1 kernel
+    assert years(10).ring2_in_use() == -1                     # 10 tracks: not instantiated
+    assert years(40, w=3).ring2_in_use() == -1                # other windows: round-1 kernel
+    from xmhw_amd.exception import XmhwException
+    with pytest.raises(Exception):
+        years(40, ring2=9)
+
+
 def test_bad_arguments():
     from xmhw_amd.exception import XmhwException
     with pytest.raises(XmhwException):
