@@ -156,64 +156,7 @@ def test_no_leap_year_in_period(dev):
     npt.assert_array_equal(s0, s1)
 
 
-def random_ring2_case(rng):
-    """a random plan inside ring2's instantiations (w = 5, 17..40 tracks) with random data hazards"""
-    kind = rng.choice(["daily", "daily_partial", "tstep", "tstep_short"])
-    ny = int(rng.integers(17, 41))
-    if kind in ("tstep", "tstep_short"):
-        n = int(rng.integers(12, 90)) if kind == "tstep" else int(rng.integers(12, 20))
-        doy = np.tile(np.arange(1, n + 1), ny)
-        tstep = True
-    else:
-        y0 = int(rng.integers(1950, 1985))
-        if kind == "daily":
-            time = np.arange(f"{y0}-01-01", f"{y0 + ny}-01-01", dtype="datetime64[D]")
-        else:
-            a = np.datetime64(f"{y0}-01-01") + int(rng.integers(1, 360))
-            time = np.arange(a, a + int(365.25 * (ny - 1)) - int(rng.integers(0, 300)), dtype="datetime64[D]")
-        doy = ora.add_doy(time)
-        tstep = False
-    T = doy.shape[0]
-    C = int(rng.choice([1, 7, 8, 9, 15, 16, 17, 31, 33, 64, 65, 130]))
-    t = np.arange(T)[:, None]
-    x = rng.uniform(-2, 25) + rng.uniform(0, 10, C) * np.sin(2 * np.pi * (t - rng.uniform(0, 365, C)) / 365.25) \
-        + rng.normal(size=(T, C)) * rng.uniform(0.01, 3)
-    quant = rng.choice([0, 0, 0.01, 0.5, 2.0])
-    if quant:
-        x = np.round(x / quant) * quant
-    x = x.astype(np.float32)
-    nanfrac = rng.choice([0.0, 0.0, 0.0, 0.02, 0.3, 0.95])
-    if nanfrac:
-        x[rng.random((T, C)) < nanfrac] = np.nan
-    hazard = rng.integers(0, 6)
-    if hazard == 0:
-        x[:, rng.integers(0, C)] = np.nan                          # an all-NaN cell
-    elif hazard == 1:
-        x[rng.integers(0, T, 5), rng.integers(0, C, 5)] = np.inf
-    elif hazard == 2:
-        x[rng.integers(0, T, 5), rng.integers(0, C, 5)] = -np.inf
-    elif hazard == 3:
-        x[:, rng.integers(0, C)] = 4.25                            # a constant cell: every key ties
-    pct = float(rng.choice([0, 1, 10, 50, 75, 90, 90, 90, 95, 99, 100]))
-    return x, doy, pct, tstep, bool(rng.integers(0, 2)), int(rng.integers(0, 4))
-
-
-def check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks, msg=""):
-    t0, s0, _ = _raw(dev, x, doy, pct / 100.0, cold, kernel="generic")
-    seen = set()
-    for v in (None, 0, 7):
-        plan = dev.Plan(doy, 5, ring2=v)
-        use = plan.ring2_in_use()
-        plan.destroy()
-        if use < 0 or use in seen:
-            continue
-        seen.add(use)
-        t1, s1, st = _raw(dev, x, doy, pct / 100.0, cold, nchunks, ring2=use)
-        assert st[0] > 0, "the ring2 kernel did not run"
-        with np.errstate(invalid="ignore"):
-            npt.assert_array_equal(t1, t0, err_msg=f"{msg} variant {use}")
-            npt.assert_allclose(s1, s0, rtol=1e-12, atol=1e-300, equal_nan=True, err_msg=f"{msg} variant {use}")
-    return seen
+from tools.fuzz_ring2 import check_ring2_case, random_ring2_case      # generator + checker shared with the long fuzz
 
 
 @pytest.mark.parametrize("seed", [11, 12])

@@ -1,16 +1,103 @@
-"""Long randomised cross-check of the ring2 kernel (both lane layouts) against the generic kernel:
-the generator and the check of tests/test_gpu_ring2.py::test_ring2_random_cases_equal_generic_kernel,
-as many cases as asked for.   python tools/fuzz_ring2.py [--cases 400] [--seed 1]"""
+"""Long randomised cross-check of the ring2 kernel (both lane layouts) against the GENERIC KERNEL (an
+independent algorithm on the same device), on random plans inside ring2's instantiations.  The generator
+and the checker are shared with tests/test_gpu_ring2.py::test_ring2_random_cases_equal_generic_kernel.
+
+    python tools/fuzz_ring2.py [--cases 400] [--seed 1]
+"""
 import argparse
 import os
 import sys
 import time
 
 import numpy as np
+import numpy.testing as npt
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
-    sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from xmhw_amd.calendar import add_doy      # noqa: E402
+
+
+def _raw(dev, x, doy, q, negate, nchunks=0, kernel="ring", ring2=-1):
+    """raw (unfinished) thresh / seas of one kernel + its debug pass counters"""
+    h = dev.hip()
+    T, C = x.shape
+    plan = dev.Plan(doy, 5, kernel=kernel, nchunks=nchunks, ring2=ring2)
+    bufs = []
+    try:
+        d_ts = dev.DeviceBuffer.from_array(x); bufs.append(d_ts)
+        th, se = dev.DeviceBuffer(8 * plan.D * C), dev.DeviceBuffer(8 * plan.D * C)
+        bufs += [th, se]
+        h.plan_debug_stats(plan.handle, 1, False)
+        dev.clim_raw(plan, d_ts, 4, C, q, negate, th, se)
+        h.stream_sync(0)
+        st = h.plan_debug_stats(plan.handle, 1, True)
+        return th.to_array((plan.D, C), np.float64), se.to_array((plan.D, C), np.float64), st
+    finally:
+        for b in bufs:
+            b.free()
+        plan.destroy()
+
+
+def random_ring2_case(rng):
+    """a random plan inside ring2's instantiations (w = 5, 17..40 tracks) with random data hazards"""
+    kind = rng.choice(["daily", "daily_partial", "tstep", "tstep_short"])
+    ny = int(rng.integers(17, 41))
+    if kind in ("tstep", "tstep_short"):
+        n = int(rng.integers(12, 90)) if kind == "tstep" else int(rng.integers(12, 20))
+        doy = np.tile(np.arange(1, n + 1), ny)
+        tstep = True
+    else:
+        y0 = int(rng.integers(1950, 1985))
+        if kind == "daily":
+            time = np.arange(f"{y0}-01-01", f"{y0 + ny}-01-01", dtype="datetime64[D]")
+        else:
+            a = np.datetime64(f"{y0}-01-01") + int(rng.integers(1, 360))
+            time = np.arange(a, a + int(365.25 * (ny - 1)) - int(rng.integers(0, 300)), dtype="datetime64[D]")
+        doy = add_doy(time)
+        tstep = False
+    T = doy.shape[0]
+    C = int(rng.choice([1, 7, 8, 9, 15, 16, 17, 31, 33, 64, 65, 130]))
+    t = np.arange(T)[:, None]
+    x = rng.uniform(-2, 25) + rng.uniform(0, 10, C) * np.sin(2 * np.pi * (t - rng.uniform(0, 365, C)) / 365.25) \
+        + rng.normal(size=(T, C)) * rng.uniform(0.01, 3)
+    quant = rng.choice([0, 0, 0.01, 0.5, 2.0])
+    if quant:
+        x = np.round(x / quant) * quant
+    x = x.astype(np.float32)
+    nanfrac = rng.choice([0.0, 0.0, 0.0, 0.02, 0.3, 0.95])
+    if nanfrac:
+        x[rng.random((T, C)) < nanfrac] = np.nan
+    hazard = rng.integers(0, 6)
+    if hazard == 0:
+        x[:, rng.integers(0, C)] = np.nan                          # an all-NaN cell
+    elif hazard == 1:
+        x[rng.integers(0, T, 5), rng.integers(0, C, 5)] = np.inf
+    elif hazard == 2:
+        x[rng.integers(0, T, 5), rng.integers(0, C, 5)] = -np.inf
+    elif hazard == 3:
+        x[:, rng.integers(0, C)] = 4.25                            # a constant cell: every key ties
+    pct = float(rng.choice([0, 1, 10, 50, 75, 90, 90, 90, 95, 99, 100]))
+    return x, doy, pct, tstep, bool(rng.integers(0, 2)), int(rng.integers(0, 4))
+
+
+def check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks, msg=""):
+    t0, s0, _ = _raw(dev, x, doy, pct / 100.0, cold, kernel="generic")
+    seen = set()
+    for v in (None, 0, 7):
+        plan = dev.Plan(doy, 5, ring2=v)
+        use = plan.ring2_in_use()
+        plan.destroy()
+        if use < 0 or use in seen:
+            continue
+        seen.add(use)
+        t1, s1, st = _raw(dev, x, doy, pct / 100.0, cold, nchunks, ring2=use)
+        assert st[0] > 0, "the ring2 kernel did not run"
+        with np.errstate(invalid="ignore"):
+            npt.assert_array_equal(t1, t0, err_msg=f"{msg} variant {use}")
+            npt.assert_allclose(s1, s0, rtol=1e-12, atol=1e-300, equal_nan=True, err_msg=f"{msg} variant {use}")
+    return seen
 
 
 def main():
@@ -21,14 +108,13 @@ def main():
     from xmhw_amd._lib import require_gpu
     require_gpu()
     import xmhw_amd.device as dev
-    import test_gpu_ring2 as t
     rng = np.random.default_rng(args.seed)
     t0 = time.perf_counter()
     layouts = {0: 0, 7: 0}
     for i in range(args.cases):
-        x, doy, pct, tstep, cold, nchunks = t.random_ring2_case(rng)
-        seen = t.check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks,
-                                  msg=f"seed {args.seed} case {i}: T={x.shape[0]} C={x.shape[1]} pct={pct} tstep={tstep} cold={cold}")
+        x, doy, pct, tstep, cold, nchunks = random_ring2_case(rng)
+        seen = check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks,
+                                msg=f"seed {args.seed} case {i}: T={x.shape[0]} C={x.shape[1]} pct={pct} tstep={tstep} cold={cold}")
         for v in seen:
             layouts[v] += 1
     print(f"{args.cases} random cases, runs per layout {layouts}: 0 mismatches against the generic kernel "
