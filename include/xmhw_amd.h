@@ -136,7 +136,8 @@ int xmhw_plan_table(const xmhw_plan *plan, int32_t years_per_lane, uint32_t *tab
                     int32_t *ntracks_padded);
 
 /* debug: ring-kernel pass counters {rows, 32-bit count passes, extractions, cold starts,
- * fast steps, 8-bit probes, code-ring rebuilds, 0} (per wave, summed since the last read);
+ * fast steps, 8-bit probes, code-ring rebuilds} per wave, then count passes summed over CELLS (what
+ * each cell needed on its own); all summed since the last read;
  * enable != 0 allocates the counters; out8 receives 8 values                          */
 int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out8);
 

@@ -54,7 +54,13 @@ def main():
             dev.clim_raw(plan, ts, 4, C, 0.9, False, th, se)
             h.event_record(e1, 0)
             ms.append(h.event_elapsed_ms(e0, e1))
-        st = h.plan_debug_stats(plan.handle, 1, True).astype(np.float64)
+        st_raw = h.plan_debug_stats(plan.handle, 1, True)
+        st = st_raw.astype(np.float64)
+        hist = None
+        if v in (0, 5, 6, 7):         # no code ring: slots 5 and 6 hold the per-cell histogram of count passes
+            a, b = int(st_raw[5]), int(st_raw[6])
+            hist = [a & 0xFFFFFFFF, a >> 32, b & 0xFFFFFFFF, b >> 32]
+            st[5] = st[6] = 0.0
         sub = dev.DeviceBuffer(8 * D * idx.size)
         h.gather_cells(th.ptr, 8, D, C, d_idx.ptr, idx.size, sub.ptr, idx.size)
         h.stream_sync(0)
@@ -72,6 +78,9 @@ def main():
                           "count_passes_per_row": st[1] / rows, "extractions_per_row": st[2] / rows,
                           "cold_per_row": st[3] / rows, "fast_steps_per_row": st[4] / rows,
                           "probes8_per_row": st[5] / rows, "rebases_per_row": st[6] / rows,
+                          # what a cell needs on its own (the wave runs the maximum over its 8 or 16 cells)
+                          "count_passes_per_cell_row": st[7] / (float(C) * D * args.reps),
+                          "cell_rows_needing_0_1_2_3plus_passes": None if hist is None else [round(x / max(sum(hist), 1), 4) for x in hist],
                           "thresh_bit_identical_to_first": bool(np.array_equal(got, ref[0], equal_nan=True)),
                           "seas_max_rel_diff": float(np.nanmax(np.abs(got_se - ref[1]) / np.abs(ref[1])))}), flush=True)
         for b in (th, se, sub):

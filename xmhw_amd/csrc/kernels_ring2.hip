@@ -312,6 +312,8 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     float kpr = 8192.0f;      // keys per rank near the target
     bool clean = false;       // wave-uniform: every lane's rings hold valid keys only
     uint32_t st_count = 0, st_extract = 0, st_rows = 0, st_cold = 0, st_fast = 0, st_probe8 = 0, st_rebase = 0;
+    uint32_t st_cell = 0;     // per lane: count passes in which this lane's cell was not yet settled
+    uint32_t st_k0 = 0, st_k1 = 0, st_k2 = 0, st_k3 = 0;     // per lane: rows that needed 0 / 1 / 2 / >= 3 passes
 
     // PROBE8 state: 8-bit codes of the ring keys relative to (cbase, cshift); valid while have_code
     uint32_t codes[PROBE8 ? NW : 1];
@@ -703,6 +705,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                 }
             }
             uint32_t alo = 0, ahi = 0, pe = 0, Fe = 0, top_span = 0;
+            uint32_t k_row = 0;       // STATS: count passes this cell needed for this row
             int budget = kBudget2;
             for (;;) {
                 // ---- 32-bit count passes until every cell can be settled by one extraction ----
@@ -724,7 +727,11 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                     off = maxu(1u, minu(off, room - 1u));
                     const uint32_t p = settle ? pl : pl + off;
                     const uint32_t F = count_le(p);
-                    if constexpr (STATS) ++st_count;
+                    if constexpr (STATS) {
+                        ++st_count;
+                        st_cell += settle ? 0u : 1u;      // passes THIS cell needed (the wave runs the maximum)
+                        k_row += settle ? 0u : 1u;
+                    }
                     if (!settle) {
                         if (F <= lo) { pl = p; Fl = F; lreal = 1; }
                         else { ph = p; Fh = F; hreal = 1; }
@@ -787,7 +794,15 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                 budget = 2;
             }
 
-            if constexpr (STATS) ++st_rows;
+            if constexpr (STATS) {
+                ++st_rows;
+                if constexpr (!PROBE8) {      // histogram of the per-cell pass count (slots 5 and 6 are free without a code ring)
+                    st_k0 += k_row == 0 ? 1u : 0u;
+                    st_k1 += k_row == 1 ? 1u : 0u;
+                    st_k2 += k_row == 2 ? 1u : 0u;
+                    st_k3 += k_row >= 3 ? 1u : 0u;
+                }
+            }
             double th = make_nan(), se = make_nan();
             if (n > 0) {
                 th = numpy_lerp(static_cast<double>(__uint_as_float(bits_of_key(alo))),
@@ -855,6 +870,15 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
         atomicAdd(&stats[4], static_cast<unsigned long long>(st_fast));
         atomicAdd(&stats[5], static_cast<unsigned long long>(st_probe8));
         atomicAdd(&stats[6], static_cast<unsigned long long>(st_rebase));
+    }
+    // [7]: count passes summed over CELLS (one lane per cell reports), to set against [1] x cells per wave
+    if (STATS && stats != nullptr && sub == 0 && cell_ok) {
+        atomicAdd(&stats[7], static_cast<unsigned long long>(st_cell));
+        if constexpr (!PROBE8) {
+            // without a code ring slots 5 and 6 carry the per-cell histogram: {k = 0 | k = 1 << 32}, {k = 2 | k >= 3 << 32}
+            atomicAdd(&stats[5], static_cast<unsigned long long>(st_k0) | (static_cast<unsigned long long>(st_k1) << 32));
+            atomicAdd(&stats[6], static_cast<unsigned long long>(st_k2) | (static_cast<unsigned long long>(st_k3) << 32));
+        }
     }
 }
 
