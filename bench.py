@@ -72,7 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--cells", type=int, default=0, help="total cells (strong) / cells per GPU (weak, N=1); 0: the preset's")
     ap.add_argument("--slabs", type=int, default=0, help="launches per step (0: 1 at N=1, 4 at N>1)")
     ap.add_argument("--kernel", default="auto")
-    ap.add_argument("--ring2", type=int, default=None, help="ring2 variant override (-2 auto, -1 round-1 kernel, 0..7)")
+    ap.add_argument("--ring2", type=int, default=None, help="ring2 variant override (-2 auto, -1 round-1 kernel, 0..11)")
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")

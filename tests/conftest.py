@@ -13,6 +13,18 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "timeout: pytest-timeout's per-test limit")
+
+
+def pytest_collection_modifyitems(config, items):
+    # a kernel that never returns would hold the GPU box until the driver's own limit: every GPU test
+    # gets a deadline (pytest-timeout, 'thread' method: the process exits even from inside a blocking
+    # HIP call); the slowest of them takes well under a minute
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(420, method="thread"))
 
 
 @pytest.fixture(scope="session")

@@ -11,7 +11,7 @@ import xmhw_oracle as ora
 import oracle_fast as fast
 
 pytestmark = pytest.mark.gpu
-VARIANTS = [0, 1, 2, 4, 5, 7]
+VARIANTS = [0, 1, 2, 4, 5, 7, 8, 9, 10]
 
 
 @pytest.fixture(scope="module")
@@ -169,4 +169,4 @@ def test_ring2_random_cases_equal_generic_kernel(dev, seed):
         x, doy, pct, tstep, cold, nchunks = random_ring2_case(rng)
         layouts |= check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks,
                                     msg=f"seed {seed} case {i}: T={x.shape[0]} C={x.shape[1]} pct={pct} tstep={tstep} cold={cold}")
-    assert layouts == {0, 7}
+    assert layouts == {0, 7, 8, 10}

@@ -103,10 +103,10 @@ def test_ring2_layout_choice():
         t = np.arange("1982-01-01", f"{1982 + n}-01-01", dtype="datetime64[D]")
         return Plan(ora.add_doy(t), w, ring2=ring2)
 
-    assert years(40).ring2_in_use() == 0                      # 8 x 5 = 40 tracks exactly
-    assert years(30).ring2_in_use() == 0                      # 8 x 4 and 4 x 8 both pad 2: a tie goes to 8 lanes
-    assert years(20).ring2_in_use() == 7                      # 4 x 5 = 20 exactly, 8 x 3 would pad 4
-    assert Plan(np.tile(np.arange(1, 1461), 20), 5).ring2_in_use() == 7      # config 5's tstep axis
+    assert years(40).ring2_in_use() == 8                      # 8 x 5 = 40 tracks exactly
+    assert years(30).ring2_in_use() == 8                      # 8 x 4 and 4 x 8 both pad 2: a tie goes to 8 lanes
+    assert years(20).ring2_in_use() == 10                     # 4 x 5 = 20 exactly, 8 x 3 would pad 4
+    assert Plan(np.tile(np.arange(1, 1461), 20), 5).ring2_in_use() == 10     # config 5's tstep axis
     assert years(20, ring2=0).ring2_in_use() == 0             # forced
     assert years(40, ring2=7).ring2_in_use() == 7
     assert years(40, ring2=-1).ring2_in_use() == -1           # round-1 kernel
@@ -114,7 +114,7 @@ def test_ring2_layout_choice():
     assert years(40, w=3).ring2_in_use() == -1                # other windows: round-1 kernel
     from xmhw_amd.exception import XmhwException
     with pytest.raises(Exception):
-        years(40, ring2=9)
+        years(40, ring2=12)
 
 
 def test_bad_arguments():

@@ -57,7 +57,7 @@ def main():
         st_raw = h.plan_debug_stats(plan.handle, 1, True)
         st = st_raw.astype(np.float64)
         hist = None
-        if v in (0, 5, 6, 7):         # no code ring: slots 5 and 6 hold the per-cell histogram of count passes
+        if v in (0, 5, 6, 7, 8, 9, 10, 11):   # no code ring: slots 5 and 6 hold the per-cell histogram of count passes
             a, b = int(st_raw[5]), int(st_raw[6])
             hist = [a & 0xFFFFFFFF, a >> 32, b & 0xFFFFFFFF, b >> 32]
             st[5] = st[6] = 0.0

@@ -85,7 +85,7 @@ def random_ring2_case(rng):
 def check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks, msg=""):
     t0, s0, _ = _raw(dev, x, doy, pct / 100.0, cold, kernel="generic")
     seen = set()
-    for v in (None, 0, 7):
+    for v in (None, 0, 7, 8, 10):
         plan = dev.Plan(doy, 5, ring2=v)
         use = plan.ring2_in_use()
         plan.destroy()
@@ -110,7 +110,7 @@ def main():
     import xmhw_amd.device as dev
     rng = np.random.default_rng(args.seed)
     t0 = time.perf_counter()
-    layouts = {0: 0, 7: 0}
+    layouts = {0: 0, 7: 0, 8: 0, 10: 0}
     for i in range(args.cases):
         x, doy, pct, tstep, cold, nchunks = random_ring2_case(rng)
         seen = check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks,

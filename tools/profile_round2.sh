@@ -11,7 +11,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r2; mkdir -p $O
 timeout 600 python3 $R/bench.py > $O/r2_bench.json 2> $O/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-pmc > $O/trace.log 2>&1
 cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/r2_kernel_stats.csv
-timeout 900 bash $R/tools/pmc_ring2.sh r2final 0 > /dev/null 2>&1
+timeout 900 bash $R/tools/pmc_ring2.sh r2final 8 > /dev/null 2>&1
 cp $R/gpurun_out/pmc_r2final/summary.txt $O/r2_pmc_sq_ring2.txt
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfgtrace -- python3 $R/tools/trace_configs.py > $O/cfgtrace.log 2>&1
 grep '^{' $O/cfgtrace.log > $O/r2_configs.jsonl

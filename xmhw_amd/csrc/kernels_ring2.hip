@@ -157,27 +157,44 @@ __device__ __forceinline__ double value_of_key(uint32_t k) {   // 0 for an inval
     return k == kInv ? 0.0 : static_cast<double>(f);
 }
 
-// J smallest (position-wise, ties repeated) distances above a pivot, ascending.
-template <int J>
+// The smallest distances above a pivot, ascending (ties repeated).  Every lane keeps the J smallest of ITS
+// keys (insert: J instructions per key); the lanes of a cell then merge into the JM >= J smallest of the
+// cell.  With JM > J the merged list can be longer than what one lane contributes: an entry is EXACT (the
+// true order statistic of the whole pool) as long as it does not exceed the cell's horizon = the smallest
+// J-th entry of any lane, because every key a lane did not list is at least that lane's J-th one.  A
+// lane's J-th smallest key above the pivot is on average the cell's (J x lanes)-th, so the horizon lies far
+// beyond the JM-th entry except when one lane happens to hold J of the cell's JM nearest keys (about 1 % of
+// the rows for J = 5, JM = 8, 8 lanes); the caller checks and takes the repair path then.
+template <int J, int JM = J>
 struct Top2 {
-    uint32_t m[J];
+    static_assert(JM >= J && JM <= 8, "merged width: J..8");
+    uint32_t m[JM];
     __device__ __forceinline__ void reset() {
 #pragma unroll
-        for (int i = 0; i < J; ++i) m[i] = 0xFFFFFFFFu;
+        for (int i = 0; i < JM; ++i) m[i] = 0xFFFFFFFFu;
     }
     __device__ __forceinline__ void insert(uint32_t d) {
 #pragma unroll
         for (int i = J - 1; i >= 1; --i) m[i] = med3u(m[i - 1], m[i], d);
         m[0] = minu(m[0], d);
     }
+    // the cell's horizon (call BEFORE merge_cell): min over the cell's lanes of the J-th listed distance
+    template <int SUBS>
+    __device__ __forceinline__ uint32_t horizon() const {
+        uint32_t g = m[J - 1];
+        g = minu(g, dpp2<kR8>(g));
+        g = minu(g, dpp2<kR4>(g));
+        if constexpr (SUBS == 8) g = minu(g, dpp2<kR2>(g));
+        return g;
+    }
     template <int CTRL>
     __device__ __forceinline__ void merge() {
-        uint32_t b[J];
+        uint32_t b[JM];
 #pragma unroll
-        for (int i = 0; i < J; ++i) b[i] = dpp2<CTRL>(m[i]);
+        for (int i = 0; i < JM; ++i) b[i] = dpp2<CTRL>(m[i]);
 #pragma unroll
-        for (int i = 0; i < J; ++i) m[i] = minu(m[i], b[J - 1 - i]);
-        constexpr int OFF = 8 - J;
+        for (int i = 0; i < JM; ++i) m[i] = minu(m[i], b[JM - 1 - i]);
+        constexpr int OFF = 8 - JM;
 #pragma unroll
         for (int d = 4; d >= 1; d >>= 1) {
 #pragma unroll
@@ -199,10 +216,10 @@ struct Top2 {
     }
     __device__ __forceinline__ uint32_t at(uint32_t j) const {
         // a chain of selects; the empty asm keeps the compiler from turning it into a dynamically
-        // indexed array (which it would place in LDS: a store of all J entries + a dependent read)
+        // indexed array (which it would place in LDS: a store of all entries + a dependent read)
         uint32_t r = m[0];
 #pragma unroll
-        for (int i = 1; i < J; ++i) {
+        for (int i = 1; i < JM; ++i) {
             r = (j == static_cast<uint32_t>(i)) ? m[i] : r;
             asm volatile("" : "+v"(r));
         }
@@ -211,7 +228,7 @@ struct Top2 {
     __device__ __forceinline__ uint32_t count_below(uint32_t d) const {
         uint32_t c = 0;
 #pragma unroll
-        for (int i = 0; i < J; ++i) c += (m[i] < d) ? 1u : 0u;
+        for (int i = 0; i < JM; ++i) c += (m[i] < d) ? 1u : 0u;
         return c;
     }
 };
@@ -222,7 +239,7 @@ constexpr int kBudget2 = 6;
 
 // sflags[step]: bit 0 = SIMPLE (every real track pushes a valid sample and is counted; padded
 // tracks push invalid).  ntracks = real tracks (tracks >= ntracks are padding).
-template <int W, int YPS, int PB, int JX, int SUBS, bool STATS>
+template <int W, int YPS, int PB, int JX, int JMX, int SUBS, bool STATS>
 __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, int32_t step_min, const DevChunk* __restrict__ chunks, double q,
@@ -238,9 +255,11 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     static_assert(PB == 0 || PB == 8 || PB == 16, "code ring of 8 or 16 bits");
     constexpr bool PROBE8 = PB != 0;             // (name kept: "closes the bracket on a code ring")
     constexpr int J = JX;
+    constexpr int JM = JMX;                      // width of the merged list (the window of acceptable ranks is JM - 1 wide)
+    static_assert(JM >= J, "merged list at least as long as a lane's");
     constexpr int CPW = PB == 16 ? 2 : 4;        // codes per 32-bit word
     constexpr uint32_t LMAX = PB == 16 ? 65534u : 254u;   // levels 1..LMAX are exact thresholds; LMAX + 1 = padding
-    constexpr uint32_t SLACK = J - 2;
+    constexpr uint32_t SLACK = JM - 2;
     constexpr int NK = YPS * R;                 // keys per lane
     constexpr int NW = PB == 16 ? (NK + 1) / 2 : (NK + 3) / 4;            // code words per lane
     constexpr uint32_t ALLC = (1u << YPS) - 1u;
@@ -705,12 +724,17 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                 }
             }
             uint32_t alo = 0, ahi = 0, pe = 0, Fe = 0, top_span = 0;
+            // the wide window (JM > J) rests on the horizon check below; a cell that fails it once falls back
+            // to the window of the lanes' own list length for the rest of the row, where every merged entry is
+            // exact by construction (the cell's J nearest keys are each among their lane's J nearest), so the
+            // loop ends exactly as it does for JM == J
+            uint32_t slack = SLACK;
             uint32_t k_row = 0;       // STATS: count passes this cell needed for this row
             int budget = kBudget2;
             for (;;) {
                 // ---- 32-bit count passes until every cell can be settled by one extraction ----
                 for (int it = 0;; ++it) {
-                    const bool settle = resolved || (lo - Fl <= SLACK) || (ph - pl <= 1u);
+                    const bool settle = resolved || (lo - Fl <= slack) || (ph - pl <= 1u);
                     if (__all(settle) || it >= budget) break;
                     const uint32_t room = ph - pl;
                     const bool both = lreal != 0 && hreal != 0;
@@ -738,11 +762,11 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                     }
                 }
                 // ---- extraction: the J smallest keys above the pivot --------------------
-                const bool window = (lo - Fl <= SLACK);
+                const bool window = (lo - Fl <= slack);
                 const bool adjacent = !window && (ph - pl <= 1u);
                 const uint32_t px = adjacent ? ph : pl;
                 const uint32_t base = px + 1u;
-                Top2<J> top;
+                Top2<J, JM> top;
                 top.reset();
                 if (wallc) {
 #pragma unroll
@@ -758,17 +782,22 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                             top.insert(((cmask >> y) & 1u) ? d : 0xFFFFFFFFu);
                         }
                 }
+                // entries of the merged list up to the horizon are exact order statistics (see Top2)
+                const uint32_t horizon = JM > J ? top.template horizon<SUBS>() : 0xFFFFFFFFu;
                 top.template merge_cell<SUBS>();
                 if constexpr (STATS) ++st_extract;
                 if (!resolved) {
-                    if (window) {
-                        const uint32_t j = lo - Fl;
-                        alo = base + top.at(j);
-                        ahi = need2 ? base + top.at(j + 1u) : alo;
+                    const uint32_t j = window ? lo - Fl : 0u;
+                    const uint32_t d_lo = top.at(j), d_hi = need2 ? top.at(j + 1u) : d_lo;
+                    const bool exact = d_hi <= horizon || j + (need2 ? 1u : 0u) < static_cast<uint32_t>(J);
+                    if (window && !exact) slack = J - 2;
+                    if (window && exact) {
+                        alo = base + d_lo;
+                        ahi = base + d_hi;
                         pe = pl; Fe = Fl;
-                        top_span = top.m[J - 1] - top.m[0];
+                        top_span = top.m[J - 1] - top.m[0];      // (code-ring variants: JM == J)
                         resolved = true;
-                    } else if (adjacent) {
+                    } else if (adjacent && !window) {
                         alo = ph;
                         ahi = (need2 && lo + 1u >= Fh) ? base + top.m[0] : ph;
                         pe = ph; Fe = Fh;
@@ -777,7 +806,8 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                 }
                 if (__all(resolved)) break;
                 // ---- repair (tie-heavy data): count at the largest extracted key ---------
-                const uint32_t dj = top.m[J - 1];
+                // (every key below base + dj is in the merged list: dj is within the horizon and within the list)
+                const uint32_t dj = minu(top.m[JM - 1], horizon);
                 const uint32_t pj = base + dj;
                 const uint32_t Fj = count_le(resolved ? pl : pj);
                 if constexpr (STATS) ++st_count;
@@ -892,13 +922,18 @@ struct Ring2Entry { int w, yps, subs, variant; Ring2Kernel fn, fn_stats; };
 //   3: 16-bit probes, J = 4              4: 16-bit probes, J = 3
 //   5: 32-bit count passes, J = 4        6: 32-bit count passes, J = 6
 //   7: as 0 with 4 lanes per cell (16 cells per wave, twice the tracks per lane)
-#define XMHW_R2V(W, Y, S, V, PB, JX) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, S, false>, clim_ring2_f32<W, Y, PB, JX, S, true>}
-#define XMHW_R2(W, Y) XMHW_R2V(W, Y, 8, 0, 0, 5), XMHW_R2V(W, Y, 8, 1, 8, 5), XMHW_R2V(W, Y, 8, 2, 16, 5), \
-                      XMHW_R2V(W, Y, 8, 3, 16, 4), XMHW_R2V(W, Y, 8, 4, 16, 3), XMHW_R2V(W, Y, 8, 5, 0, 4), \
-                      XMHW_R2V(W, Y, 8, 6, 0, 6)
+//   8 / 9: as 0 / 7 with the lanes' J = 5 lists merged into the cell's 8 nearest keys (window of 7 ranks)
+//   10 / 11: as 9 with 7 / 6 merged keys (4 lanes per cell: a lane holds 5 of the cell's 8 nearest more often)
+#define XMHW_R2V(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>}
+#define XMHW_R2(W, Y) XMHW_R2V(W, Y, 8, 0, 0, 5, 5), XMHW_R2V(W, Y, 8, 1, 8, 5, 5), XMHW_R2V(W, Y, 8, 2, 16, 5, 5), \
+                      XMHW_R2V(W, Y, 8, 3, 16, 4, 4), XMHW_R2V(W, Y, 8, 4, 16, 3, 3), XMHW_R2V(W, Y, 8, 5, 0, 4, 4), \
+                      XMHW_R2V(W, Y, 8, 6, 0, 6, 6), XMHW_R2V(W, Y, 8, 8, 0, 5, 8)
 const Ring2Entry kRing2[] = {
     XMHW_R2(5, 3), XMHW_R2(5, 4), XMHW_R2(5, 5),
-    XMHW_R2V(5, 5, 4, 7, 0, 5), XMHW_R2V(5, 8, 4, 7, 0, 5), XMHW_R2V(5, 10, 4, 7, 0, 5),
+    XMHW_R2V(5, 5, 4, 7, 0, 5, 5), XMHW_R2V(5, 8, 4, 7, 0, 5, 5), XMHW_R2V(5, 10, 4, 7, 0, 5, 5),
+    XMHW_R2V(5, 5, 4, 9, 0, 5, 8), XMHW_R2V(5, 8, 4, 9, 0, 5, 8), XMHW_R2V(5, 10, 4, 9, 0, 5, 8),
+    XMHW_R2V(5, 5, 4, 10, 0, 5, 7), XMHW_R2V(5, 8, 4, 10, 0, 5, 7), XMHW_R2V(5, 10, 4, 10, 0, 5, 7),
+    XMHW_R2V(5, 5, 4, 11, 0, 5, 6), XMHW_R2V(5, 8, 4, 11, 0, 5, 6), XMHW_R2V(5, 10, 4, 11, 0, 5, 6),
 };
 #undef XMHW_R2
 #undef XMHW_R2V
@@ -909,7 +944,7 @@ const Ring2Entry* find_ring2(int32_t w, int32_t yps, int32_t subs, int32_t varia
 }
 }  // namespace
 
-int32_t ring2_subs(int32_t variant) { return variant == 7 ? 4 : 8; }
+int32_t ring2_subs(int32_t variant) { return (variant == 7 || variant >= 9) ? 4 : 8; }
 
 int32_t ring2_pick_yps(int32_t w, int32_t ntracks, int32_t variant) {
     const int32_t subs = ring2_subs(variant);
