@@ -187,13 +187,20 @@ struct Top2 {
         if constexpr (SUBS == 8) g = minu(g, dpp2<kR2>(g));
         return g;
     }
-    template <int CTRL>
+    // FIRST: both lists still have their entries J..JM-1 at "infinity" (nothing merged yet), which the
+    // compiler cannot know: those compares and lane exchanges are left out by hand
+    template <int CTRL, bool FIRST = false>
     __device__ __forceinline__ void merge() {
-        uint32_t b[JM];
+        constexpr int N = FIRST ? J : JM;        // live entries of the partner's list
+        uint32_t b[N];
 #pragma unroll
-        for (int i = 0; i < JM; ++i) b[i] = dpp2<CTRL>(m[i]);
+        for (int i = 0; i < N; ++i) b[i] = dpp2<CTRL>(m[i]);
 #pragma unroll
-        for (int i = 0; i < JM; ++i) m[i] = minu(m[i], b[JM - 1 - i]);
+        for (int i = 0; i < JM; ++i) {
+            const int k = JM - 1 - i;            // partner entry in the bitonic half-cleaner
+            if (i < N && k < N) m[i] = minu(m[i], b[k]);
+            else if (k < N) m[i] = b[k];         // own entry is infinite
+        }                                        // (partner entry infinite: own entry stays)
         constexpr int OFF = 8 - JM;
 #pragma unroll
         for (int d = 4; d >= 1; d >>= 1) {
@@ -210,9 +217,21 @@ struct Top2 {
     }
     template <int SUBS>
     __device__ __forceinline__ void merge_cell() {
-        merge<kR8>();
+        merge<kR8, true>();
         merge<kR4>();
         if constexpr (SUBS == 8) merge<kR2>();
+    }
+    // entries j and j + 1 with one chain of compares
+    __device__ __forceinline__ void at2(uint32_t j, uint32_t& a, uint32_t& b) const {
+        a = m[0];
+        b = m[1];
+#pragma unroll
+        for (int i = 1; i < JM; ++i) {
+            const bool hit = j == static_cast<uint32_t>(i);
+            a = hit ? m[i] : a;
+            b = hit ? m[i + 1 < JM ? i + 1 : i] : b;
+            asm volatile("" : "+v"(a), "+v"(b));
+        }
     }
     __device__ __forceinline__ uint32_t at(uint32_t j) const {
         // a chain of selects; the empty asm keeps the compiler from turning it into a dynamically
@@ -788,7 +807,9 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                 if constexpr (STATS) ++st_extract;
                 if (!resolved) {
                     const uint32_t j = window ? lo - Fl : 0u;
-                    const uint32_t d_lo = top.at(j), d_hi = need2 ? top.at(j + 1u) : d_lo;
+                    uint32_t d_lo, d_nx;
+                    top.at2(j, d_lo, d_nx);      // (j + 1 <= JM - 1 inside the window)
+                    const uint32_t d_hi = need2 ? d_nx : d_lo;
                     const bool exact = d_hi <= horizon || j + (need2 ? 1u : 0u) < static_cast<uint32_t>(J);
                     if (window && !exact) slack = J - 2;
                     if (window && exact) {
