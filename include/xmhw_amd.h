@@ -141,7 +141,7 @@ int xmhw_plan_table(const xmhw_plan *plan, int32_t years_per_lane, uint32_t *tab
  * enable != 0 allocates the counters; out8 receives 8 values                          */
 int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out8);
 
-/* second-generation float32 ring kernel (w = 5, 17..40 tracks; xmhw_amd/csrc/kernels_ring2.hip),
+/* second-generation float32 ring kernel (w = 5, 9..48 tracks; xmhw_amd/csrc/kernels_ring2.hip),
  * used by default where it is instantiated.  variant: -2 = auto (the default: 8, or 10 where the
  * 4-lane layout pads fewer tracks, e.g. 20 tracks), -1 = off (round-1 kernel), 0 = 8 lanes per
  * cell with 32-bit count passes and a 5-key extraction list, 7 = the same with 4 lanes per cell,

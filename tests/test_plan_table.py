@@ -110,7 +110,11 @@ def test_ring2_layout_choice():
     assert years(20, ring2=0).ring2_in_use() == 0             # forced
     assert years(40, ring2=7).ring2_in_use() == 7
     assert years(40, ring2=-1).ring2_in_use() == -1           # round-1 kernel
-    assert years(10).ring2_in_use() == -1                     # 10 tracks: not instantiated
+    assert years(10).ring2_in_use() == 10                     # 10 tracks: 4 x 3 = 12 slots against 8 x 2 = 16
+    assert years(16).ring2_in_use() == 8                      # 16 tracks: 8 x 2 = 4 x 4 exactly: a tie goes to 8 lanes
+    assert years(43).ring2_in_use() == 8                      # 41..48 tracks (OISST 1982-2024): 8 x 6
+    assert years(49).ring2_in_use() == -1                     # beyond: round-1 kernel (16 lanes per cell)
+    assert years(8).ring2_in_use() == -1                      # 8 tracks or fewer: round-1 kernel
     assert years(40, w=3).ring2_in_use() == -1                # other windows: round-1 kernel
     from xmhw_amd.exception import XmhwException
     with pytest.raises(Exception):

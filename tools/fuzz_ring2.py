@@ -41,9 +41,9 @@ def _raw(dev, x, doy, q, negate, nchunks=0, kernel="ring", ring2=-1):
 
 
 def random_ring2_case(rng):
-    """a random plan inside ring2's instantiations (w = 5, 17..40 tracks) with random data hazards"""
+    """a random plan inside ring2's instantiations (w = 5, 9..48 tracks) with random data hazards"""
     kind = rng.choice(["daily", "daily_partial", "tstep", "tstep_short"])
-    ny = int(rng.integers(17, 41))
+    ny = int(rng.integers(9, 49))
     if kind in ("tstep", "tstep_short"):
         n = int(rng.integers(12, 90)) if kind == "tstep" else int(rng.integers(12, 20))
         doy = np.tile(np.arange(1, n + 1), ny)

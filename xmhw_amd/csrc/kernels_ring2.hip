@@ -955,6 +955,10 @@ const Ring2Entry kRing2[] = {
     XMHW_R2V(5, 5, 4, 9, 0, 5, 8), XMHW_R2V(5, 8, 4, 9, 0, 5, 8), XMHW_R2V(5, 10, 4, 9, 0, 5, 8),
     XMHW_R2V(5, 5, 4, 10, 0, 5, 7), XMHW_R2V(5, 8, 4, 10, 0, 5, 7), XMHW_R2V(5, 10, 4, 10, 0, 5, 7),
     XMHW_R2V(5, 5, 4, 11, 0, 5, 6), XMHW_R2V(5, 8, 4, 11, 0, 5, 6), XMHW_R2V(5, 10, 4, 11, 0, 5, 6),
+    // shorter and longer records (9..16 and 41..48 tracks: 10-year series, OISST 1982-today), shipped layouts
+    // and their plain counterparts only
+    XMHW_R2V(5, 2, 8, 0, 0, 5, 5), XMHW_R2V(5, 2, 8, 8, 0, 5, 8), XMHW_R2V(5, 6, 8, 0, 0, 5, 5), XMHW_R2V(5, 6, 8, 8, 0, 5, 8),
+    XMHW_R2V(5, 3, 4, 7, 0, 5, 5), XMHW_R2V(5, 3, 4, 10, 0, 5, 7), XMHW_R2V(5, 4, 4, 7, 0, 5, 5), XMHW_R2V(5, 4, 4, 10, 0, 5, 7),
 };
 #undef XMHW_R2
 #undef XMHW_R2V
