@@ -212,7 +212,18 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
             // kernel (stops at the first lossy sample) -> float64 kernel (runs only if flagged).
             const uint32_t* run_flag = nullptr;
             e = hipSuccess;
-            if (plan->narrowing && plan->yps) {
+            const int32_t v2 = ring2_resolved(plan);
+            if (plan->narrowing && plan->yps2 && v2 >= 0 && xmhw::ring2_narrowing_supported(h.w, plan->yps2, v2)) {
+                // the second-generation kernel narrows too (the shipped layouts)
+                if (!plan->d_narrow_flag) HIP_TRY(hipMalloc(&plan->d_narrow_flag, sizeof(uint32_t)));
+                e = xmhw::launch_narrow_probe(reinterpret_cast<const double*>(ts), h.T, C, ld, plan->d_narrow_flag, st);
+                if (e == hipSuccess)
+                    e = xmhw::launch_ring2_f32_narrowing(reinterpret_cast<const double*>(ts), C, ld, h.T, plan->d_table2,
+                                                         plan->d_sflags, h.step_min, plan->d_chunks, plan->nchunks, h.w,
+                                                         plan->yps2, h.ntracks, v2, q, negate, thresh, seas, ldo, st,
+                                                         plan->d_narrow_flag);
+                run_flag = plan->d_narrow_flag;
+            } else if (plan->narrowing && plan->yps) {
                 if (!plan->d_narrow_flag) HIP_TRY(hipMalloc(&plan->d_narrow_flag, sizeof(uint32_t)));
                 e = xmhw::launch_ring_f32_narrowing(reinterpret_cast<const double*>(ts), h.T, C, ld, plan->d_table,
                                                     h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps,

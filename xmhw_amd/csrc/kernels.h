@@ -28,6 +28,13 @@ hipError_t launch_ring_f32(const float* ts, int64_t C, int64_t ld, const uint32_
 // second-generation float32 ring kernel (kernels_ring2.hip): 8 lanes per cell, tracks dealt y-major;
 // variant bit 0 = 8-bit SAD probes, bit 1 = extraction skips empty ring positions
 int32_t ring2_pick_yps(int32_t w, int32_t ntracks, int32_t variant);   // tracks per lane, 0 if not instantiated
+bool ring2_narrowing_supported(int32_t w, int32_t yps, int32_t variant);   // float64 -> float32 narrowing instantiation exists
+hipError_t launch_narrow_probe(const double* ts, int64_t Tn, int64_t C, int64_t ld, uint32_t* narrow_flag, hipStream_t stream);
+hipError_t launch_ring2_f32_narrowing(const double* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
+                                      const uint32_t* sflags, int32_t step_min, const DevChunk* chunks,
+                                      int32_t nchunks, int32_t w, int32_t yps, int32_t ntracks, int32_t variant,
+                                      double q, int negate, double* thresh, double* seas, int64_t ldo,
+                                      hipStream_t stream, uint32_t* narrow_flag);
 int32_t ring2_subs(int32_t variant);                                    // lanes per cell of that variant
 hipError_t launch_ring2_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
                             const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,

@@ -657,6 +657,18 @@ hipError_t launch_ring_f32(const float* ts, int64_t C, int64_t ld, const uint32_
     return hipGetLastError();
 }
 
+// clears the flag and queues the sparse look at the float64 series (shared with the ring2 narrowing launch)
+hipError_t launch_narrow_probe(const double* ts, int64_t Tn, int64_t C, int64_t ld, uint32_t* narrow_flag,
+                               hipStream_t stream) {
+    if (!narrow_flag) return hipErrorInvalidValue;
+    hipError_t err = hipMemsetAsync(narrow_flag, 0, sizeof(uint32_t), stream);
+    if (err != hipSuccess) return err;
+    if (C <= 0 || Tn <= 0) return hipSuccess;
+    hipLaunchKernelGGL(narrow_probe, dim3(static_cast<unsigned>((C + 255) / 256)), dim3(256), 0, stream, ts, Tn, C,
+                       ld, narrow_flag);
+    return hipGetLastError();
+}
+
 hipError_t launch_ring_f32_narrowing(const double* ts, int64_t Tn, int64_t C, int64_t ld, const uint32_t* table,
                                      int32_t step_min, const DevChunk* chunks, int32_t nchunks, int32_t w,
                                      int32_t yps, int32_t subs, double q, int negate, double* thresh, double* seas,

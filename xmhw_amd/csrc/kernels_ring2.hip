@@ -258,13 +258,22 @@ constexpr int kBudget2 = 6;
 
 // sflags[step]: bit 0 = SIMPLE (every real track pushes a valid sample and is counted; padded
 // tracks push invalid).  ntracks = real tracks (tracks >= ntracks are padding).
-template <int W, int YPS, int PB, int JX, int JMX, int SUBS, bool STATS>
+// TI = float, or double for float64 input whose samples are float32-representable (decoded int16 /
+// float32 archives promoted by a reader): the samples are narrowed on load; `narrow_flag` (TI = double
+// only) is set as soon as a sample does not survive the round trip, the kernel gives up and the float64
+// kernel queued behind it (which looks at the same flag) does the work instead.
+template <int W, int YPS, int PB, int JX, int JMX, int SUBS, bool STATS, typename TI = float>
 __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
-    const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
+    const TI* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, int32_t step_min, const DevChunk* __restrict__ chunks, double q,
     int negate, int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
-    unsigned long long* __restrict__ stats) {
+    unsigned long long* __restrict__ stats, uint32_t* __restrict__ narrow_flag) {
     static_assert(W == 5, "count_le11 is written for an 11-sample window");
+    constexpr bool kNarrow = sizeof(TI) == 8;
+    if constexpr (kNarrow) {
+        if (*narrow_flag != 0) return;           // the probe (or another workgroup) already found a lossy sample
+    }
+    bool lossy = false;
     constexpr int R = 2 * W + 1;
     static_assert(SUBS == 8 || SUBS == 4, "8 lanes per cell (8 cells per wave) or 4 (16 cells per wave)");
     constexpr int NTP = SUBS * YPS;
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     const uint32_t* tab = table + sub;           // y-major: entry of slot y at tab[step * NTP + y * SUBS]
     // lanes beyond the last cell work on a copy of the last cell (and store nothing): a partly filled
     // wave then takes the same fast steps as a full one
-    const float* col = ts + (cell_ok ? cell : C - 1);
+    const TI* col = ts + (cell_ok ? cell : C - 1);
     const uint32_t negmask = negate ? 0xFFFFFFFFu : 0u;
     const uint32_t tmax = static_cast<uint32_t>(Tn - 1);
     // padding: only the last slot of a lane can be a padded track
@@ -334,14 +343,14 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
 #pragma unroll
         for (int y = 0; y < YPS; ++y) tix[y] += (y == YPS - 1) ? last_step : 1u;
     };
-    auto request = [&](float (&x)[YPS]) {
+    auto request = [&](TI (&x)[YPS]) {
 #pragma unroll
         for (int y = 0; y < YPS; ++y) x[y] = col[static_cast<int64_t>(tix[y]) * ld];
     };
 
-    float x_cur[YPS];
+    TI x_raw[YPS];            // as loaded (consumed one row after the request)
     point_at(ch.warm_start);
-    request(x_cur);
+    request(x_raw);
 
     int m = (ch.warm_start - step_min) % R;
     // carried across rows, uniform over the 8 lanes of a cell (kept as integers, not as lane masks)
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     bool rotate = false;
     for (; s < ch.end && !rotate; ++s) {
         // ---- prefetch: the samples of step s+1 (consumed one row later) ------------------
-        float x_nxt[YPS];
+        TI x_nxt[YPS];
         const uint32_t sf_nn = s + 2 < ch.end ? __builtin_amdgcn_readfirstlane(sflags[s + 2 - step_min]) : 0u;
         if (s + 1 < ch.end) {
             const uint32_t sfn = sf_nxt;
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
             request(x_nxt);
         } else {
 #pragma unroll
-            for (int y = 0; y < YPS; ++y) x_nxt[y] = 0.0f;
+            for (int y = 0; y < YPS; ++y) x_nxt[y] = static_cast<TI>(0);
         }
         const uint32_t sf = sf_cur;
 
@@ -393,6 +402,13 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
         bool wave_hold = false;
         // NaN among the loaded samples?  (the sum propagates NaN; inf - inf also lands here and
         // merely takes the general step)
+        // the samples of this row as float32 (narrowed and checked for float64 input)
+        float x_cur[YPS];
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) {
+            x_cur[y] = static_cast<float>(x_raw[y]);
+            if constexpr (kNarrow) lossy |= (static_cast<TI>(x_cur[y]) != x_raw[y]) && (x_raw[y] == x_raw[y]);
+        }
         float xs = x_cur[0];
 #pragma unroll
         for (int y = 1; y < YPS; ++y) xs += x_cur[y];
@@ -886,9 +902,17 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
             }
         }
 
-        if ((s & 63) == 63) __syncthreads();
+        if constexpr (kNarrow) {
+            // (no rendezvous here: a wave that has seen a lossy sample leaves, and the others must not wait for it)
+            if ((s & 63) == 63 && __any(lossy)) {
+                if (lossy) atomicOr(narrow_flag, 1u);
+                return;
+            }
+        } else {
+            if ((s & 63) == 63) __syncthreads();
+        }
 #pragma unroll
-        for (int y = 0; y < YPS; ++y) x_cur[y] = x_nxt[y];
+        for (int y = 0; y < YPS; ++y) x_raw[y] = x_nxt[y];
         sf_cur = sf_nxt;
         sf_nxt = sf_nn;
     }
@@ -913,6 +937,9 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
         have_code = 0;         // byte positions moved: rebuild the code ring
     }
     }
+    if constexpr (kNarrow) {
+        if (lossy) atomicOr(narrow_flag, 1u);
+    }
     if (STATS && stats != nullptr && lane == 0) {
         atomicAdd(&stats[0], static_cast<unsigned long long>(st_rows));
         atomicAdd(&stats[1], static_cast<unsigned long long>(st_count));
@@ -936,8 +963,12 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
 // ---------------------------------------------------------------------------
 namespace {
 typedef void (*Ring2Kernel)(const float*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*, int32_t,
-                            const DevChunk*, double, int, int32_t, double*, double*, int64_t, unsigned long long*);
-struct Ring2Entry { int w, yps, subs, variant; Ring2Kernel fn, fn_stats; };
+                            const DevChunk*, double, int, int32_t, double*, double*, int64_t, unsigned long long*,
+                            uint32_t*);
+typedef void (*Ring2KernelN)(const double*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*, int32_t,
+                             const DevChunk*, double, int, int32_t, double*, double*, int64_t, unsigned long long*,
+                             uint32_t*);
+struct Ring2Entry { int w, yps, subs, variant; Ring2Kernel fn, fn_stats; Ring2KernelN fn_narrow; };
 // variant -> (code-ring bits, extraction width, lanes per cell); the _stats twin carries the debug pass counters
 //   0: 32-bit count passes, J = 5        1: 8-bit probes, J = 5      2: 16-bit probes, J = 5
 //   3: 16-bit probes, J = 4              4: 16-bit probes, J = 3
@@ -945,23 +976,27 @@ struct Ring2Entry { int w, yps, subs, variant; Ring2Kernel fn, fn_stats; };
 //   7: as 0 with 4 lanes per cell (16 cells per wave, twice the tracks per lane)
 //   8 / 9: as 0 / 7 with the lanes' J = 5 lists merged into the cell's 8 nearest keys (window of 7 ranks)
 //   10 / 11: as 9 with 7 / 6 merged keys (4 lanes per cell: a lane holds 5 of the cell's 8 nearest more often)
-#define XMHW_R2V(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>}
+#define XMHW_R2V(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>, nullptr}
+// the shipped layouts also exist for float64 input that narrows to float32 without loss
+#define XMHW_R2N(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>, \
+                                          clim_ring2_f32<W, Y, PB, JX, JM, S, false, double>}
 #define XMHW_R2(W, Y) XMHW_R2V(W, Y, 8, 0, 0, 5, 5), XMHW_R2V(W, Y, 8, 1, 8, 5, 5), XMHW_R2V(W, Y, 8, 2, 16, 5, 5), \
                       XMHW_R2V(W, Y, 8, 3, 16, 4, 4), XMHW_R2V(W, Y, 8, 4, 16, 3, 3), XMHW_R2V(W, Y, 8, 5, 0, 4, 4), \
-                      XMHW_R2V(W, Y, 8, 6, 0, 6, 6), XMHW_R2V(W, Y, 8, 8, 0, 5, 8)
+                      XMHW_R2V(W, Y, 8, 6, 0, 6, 6), XMHW_R2N(W, Y, 8, 8, 0, 5, 8)
 const Ring2Entry kRing2[] = {
     XMHW_R2(5, 3), XMHW_R2(5, 4), XMHW_R2(5, 5),
     XMHW_R2V(5, 5, 4, 7, 0, 5, 5), XMHW_R2V(5, 8, 4, 7, 0, 5, 5), XMHW_R2V(5, 10, 4, 7, 0, 5, 5),
     XMHW_R2V(5, 5, 4, 9, 0, 5, 8), XMHW_R2V(5, 8, 4, 9, 0, 5, 8), XMHW_R2V(5, 10, 4, 9, 0, 5, 8),
-    XMHW_R2V(5, 5, 4, 10, 0, 5, 7), XMHW_R2V(5, 8, 4, 10, 0, 5, 7), XMHW_R2V(5, 10, 4, 10, 0, 5, 7),
+    XMHW_R2N(5, 5, 4, 10, 0, 5, 7), XMHW_R2N(5, 8, 4, 10, 0, 5, 7), XMHW_R2N(5, 10, 4, 10, 0, 5, 7),
     XMHW_R2V(5, 5, 4, 11, 0, 5, 6), XMHW_R2V(5, 8, 4, 11, 0, 5, 6), XMHW_R2V(5, 10, 4, 11, 0, 5, 6),
     // shorter and longer records (9..16 and 41..48 tracks: 10-year series, OISST 1982-today), shipped layouts
     // and their plain counterparts only
-    XMHW_R2V(5, 2, 8, 0, 0, 5, 5), XMHW_R2V(5, 2, 8, 8, 0, 5, 8), XMHW_R2V(5, 6, 8, 0, 0, 5, 5), XMHW_R2V(5, 6, 8, 8, 0, 5, 8),
-    XMHW_R2V(5, 3, 4, 7, 0, 5, 5), XMHW_R2V(5, 3, 4, 10, 0, 5, 7), XMHW_R2V(5, 4, 4, 7, 0, 5, 5), XMHW_R2V(5, 4, 4, 10, 0, 5, 7),
+    XMHW_R2V(5, 2, 8, 0, 0, 5, 5), XMHW_R2N(5, 2, 8, 8, 0, 5, 8), XMHW_R2V(5, 6, 8, 0, 0, 5, 5), XMHW_R2N(5, 6, 8, 8, 0, 5, 8),
+    XMHW_R2V(5, 3, 4, 7, 0, 5, 5), XMHW_R2N(5, 3, 4, 10, 0, 5, 7), XMHW_R2V(5, 4, 4, 7, 0, 5, 5), XMHW_R2N(5, 4, 4, 10, 0, 5, 7),
 };
 #undef XMHW_R2
 #undef XMHW_R2V
+#undef XMHW_R2N
 const Ring2Entry* find_ring2(int32_t w, int32_t yps, int32_t subs, int32_t variant) {
     for (const auto& e : kRing2)
         if (e.w == w && e.yps == yps && e.subs == subs && e.variant == variant) return &e;
@@ -995,7 +1030,30 @@ hipError_t launch_ring2_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
     const int64_t cells_per_block = (64 / subs) * kWaves2;
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
     hipLaunchKernelGGL(stats ? e->fn_stats : e->fn, grid, dim3(64 * kWaves2), 0, stream, ts, C, ld, Tn, table, sflags, step_min,
-                       chunks, q, negate, ntracks, thresh, seas, ldo, stats);
+                       chunks, q, negate, ntracks, thresh, seas, ldo, stats, static_cast<uint32_t*>(nullptr));
+    return hipGetLastError();
+}
+
+bool ring2_narrowing_supported(int32_t w, int32_t yps, int32_t variant) {
+    const Ring2Entry* e = find_ring2(w, yps, ring2_subs(variant), variant);
+    return e != nullptr && e->fn_narrow != nullptr;
+}
+
+// float64 input on the float32 kernel: the flag must have been cleared and the sparse probe queued by the
+// caller (launch_narrow_probe, kernels_ring.hip); the kernel leaves as soon as the flag is set
+hipError_t launch_ring2_f32_narrowing(const double* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
+                                      const uint32_t* sflags, int32_t step_min, const DevChunk* chunks,
+                                      int32_t nchunks, int32_t w, int32_t yps, int32_t ntracks, int32_t variant,
+                                      double q, int negate, double* thresh, double* seas, int64_t ldo,
+                                      hipStream_t stream, uint32_t* narrow_flag) {
+    const int32_t subs = ring2_subs(variant);
+    const Ring2Entry* e = find_ring2(w, yps, subs, variant);
+    if (!e || !e->fn_narrow || !narrow_flag) return hipErrorInvalidValue;
+    if (C <= 0 || nchunks <= 0) return hipSuccess;
+    const int64_t cells_per_block = (64 / subs) * kWaves2;
+    dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
+    hipLaunchKernelGGL(e->fn_narrow, grid, dim3(64 * kWaves2), 0, stream, ts, C, ld, Tn, table, sflags, step_min, chunks, q,
+                       negate, ntracks, thresh, seas, ldo, static_cast<unsigned long long*>(nullptr), narrow_flag);
     return hipGetLastError();
 }
 
