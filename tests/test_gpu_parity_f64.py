@@ -191,3 +191,15 @@ def test_long_float64_record_narrows_onto_the_16_lane_ring(dev):
     tg, sg, _ = run(rand, kernel="generic")
     npt.assert_array_equal(tr, tg)
     npt.assert_array_equal(sr, sg)
+
+
+@pytest.mark.parametrize("seed", [61, 62])
+def test_float64_random_cases_equal_generic_kernel(dev, seed):
+    """the float64 path as the library takes it (probe -> ring2 narrowing -> ring2 64-bit mode / round-1 float64
+    ring) on random plans with full-precision doubles, exact repeats and distinct doubles sharing the high word
+    of their key: raw percentile bit-identical to the generic float64 kernel"""
+    from tools.fuzz_ring2 import check_f64_case, random_f64_case
+    rng = np.random.default_rng(seed)
+    for i in range(16):
+        x, doy, pct, tstep, cold, nchunks = random_f64_case(rng)
+        check_f64_case(dev, x, doy, pct, tstep, cold, nchunks, msg=f"seed {seed} case {i}")

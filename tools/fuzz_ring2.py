@@ -19,18 +19,18 @@ if ROOT not in sys.path:
 from xmhw_amd.calendar import add_doy      # noqa: E402
 
 
-def _raw(dev, x, doy, q, negate, nchunks=0, kernel="ring", ring2=-1):
+def _raw(dev, x, doy, q, negate, nchunks=0, kernel="ring", ring2=-1, narrowing=True):
     """raw (unfinished) thresh / seas of one kernel + its debug pass counters"""
     h = dev.hip()
     T, C = x.shape
-    plan = dev.Plan(doy, 5, kernel=kernel, nchunks=nchunks, ring2=ring2)
+    plan = dev.Plan(doy, 5, kernel=kernel, nchunks=nchunks, ring2=ring2, narrowing=narrowing)
     bufs = []
     try:
         d_ts = dev.DeviceBuffer.from_array(x); bufs.append(d_ts)
         th, se = dev.DeviceBuffer(8 * plan.D * C), dev.DeviceBuffer(8 * plan.D * C)
         bufs += [th, se]
         h.plan_debug_stats(plan.handle, 1, False)
-        dev.clim_raw(plan, d_ts, 4, C, q, negate, th, se)
+        dev.clim_raw(plan, d_ts, x.dtype.itemsize, C, q, negate, th, se)
         h.stream_sync(0)
         st = h.plan_debug_stats(plan.handle, 1, True)
         return th.to_array((plan.D, C), np.float64), se.to_array((plan.D, C), np.float64), st
@@ -100,16 +100,61 @@ def check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks, msg=""):
     return seen
 
 
+def random_f64_case(rng):
+    """as random_ring2_case with genuinely float64 samples: full-precision doubles, exact repeats (quantised),
+    and clusters of DISTINCT doubles that share the high word of their 64-bit key (within 2^-20 relative), which
+    is what the low-word pass of the 64-bit mode has to sort out"""
+    x32, doy, pct, tstep, cold, nchunks = random_ring2_case(rng)
+    x = x32.astype(np.float64)
+    T, C = x.shape
+    mode = rng.integers(0, 4)
+    if mode == 0:                                           # full precision
+        x = x + rng.normal(size=x.shape) * 1e-9
+    elif mode == 1:                                         # near ties: a few levels, jittered in the low word only
+        lev = np.round(x * 2.0) / 2.0
+        x = lev * (1.0 + rng.integers(0, 7, size=x.shape) * 1e-9)
+    elif mode == 2:                                         # mixture: repeats, near ties and free values
+        lev = np.round(x)
+        pick = rng.integers(0, 3, size=x.shape)
+        x = np.where(pick == 0, lev, np.where(pick == 1, lev * (1.0 + rng.integers(0, 3, size=x.shape) * 3e-8), x + 1e-7))
+    else:                                                   # float32-representable: the narrowing path (kept for contrast)
+        pass
+    x[np.isnan(x32)] = np.nan
+    x[np.isinf(x32)] = x32[np.isinf(x32)]
+    return x, doy, pct, tstep, cold, nchunks
+
+
+def check_f64_case(dev, x, doy, pct, tstep, cold, nchunks, msg=""):
+    """the float64 path as the library takes it (narrowing probe -> ring2 narrowing -> ring2 64-bit mode or the
+    round-1 float64 ring) against the generic float64 kernel: raw percentile bit for bit"""
+    t0, s0, _ = _raw(dev, x, doy, pct / 100.0, cold, kernel="generic")
+    for narrowing in (True, False):
+        t1, s1, _ = _raw(dev, x, doy, pct / 100.0, cold, nchunks, kernel="auto", ring2=None, narrowing=narrowing)
+        with np.errstate(invalid="ignore"):
+            npt.assert_array_equal(t1, t0, err_msg=f"{msg} narrowing={narrowing}")
+            # (float64 sums are not exact: a running sum and a direct one differ by rounding, which shows
+            # relative to a mean that crosses zero -- hence the absolute term)
+            npt.assert_allclose(s1, s0, rtol=1e-12, atol=1e-12, equal_nan=True, err_msg=f"{msg} narrowing={narrowing}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=400)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     args = ap.parse_args()
     from xmhw_amd._lib import require_gpu
     require_gpu()
     import xmhw_amd.device as dev
     rng = np.random.default_rng(args.seed)
     t0 = time.perf_counter()
+    if args.dtype == "f64":
+        for i in range(args.cases):
+            x, doy, pct, tstep, cold, nchunks = random_f64_case(rng)
+            check_f64_case(dev, x, doy, pct, tstep, cold, nchunks,
+                           msg=f"seed {args.seed} case {i}: T={x.shape[0]} C={x.shape[1]} pct={pct} tstep={tstep} cold={cold}")
+        print(f"{args.cases} random float64 cases: 0 mismatches against the generic kernel ({time.perf_counter() - t0:.0f} s)")
+        return
     layouts = {0: 0, 7: 0, 8: 0, 10: 0}
     for i in range(args.cases):
         x, doy, pct, tstep, cold, nchunks = random_ring2_case(rng)

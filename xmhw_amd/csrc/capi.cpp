@@ -91,10 +91,31 @@ struct xmhw_plan {
 
 namespace {
 
+int32_t ring2_resolved(const xmhw_plan* p);
+
+// float64 samples on the second-generation kernel's 64-bit mode: instantiated for this plan and not switched off
+bool x64_usable(const xmhw_plan* p) {
+    static const bool on = [] { const char* v = std::getenv("XMHW_RING2_F64"); return !(v && v[0] == '0'); }();
+    const int32_t v2 = ring2_resolved(p);
+    if (!on || v2 < 0) return false;
+    const int32_t y2 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, v2);
+    return y2 > 0 && xmhw::ring2_x64_supported(p->host.w, y2, v2);
+}
+
 int32_t resolve_kernel(const xmhw_plan* p, int elem_bytes) {
-    const int32_t yps = elem_bytes == 8 ? xmhw::ring64_pick_yps(p->host.w, p->host.ntracks)
-                                        : xmhw::ring_pick(p->host.w, p->host.ntracks, elem_bytes, nullptr);
     if (p->host.kernel_choice == XMHW_KERNEL_GENERIC) return XMHW_KERNEL_GENERIC;
+    if (elem_bytes == 8) {
+        // float64: the second-generation kernel's 64-bit mode where it is instantiated.  The round-1 float64
+        // ring (kernels_ring64.hip) is no longer chosen automatically: the randomised cross-check of round 2
+        // (tools/fuzz_ring2.py --dtype f64) found it returning wrong rows on clustered doubles (distinct
+        // values within 1e-9 of each other mixed with repeats); it answers only to an explicit
+        // XMHW_KERNEL_RING request on plans the 64-bit mode does not cover.  Everything else is generic.
+        const bool x64 = x64_usable(p);
+        if (p->host.kernel_choice == XMHW_KERNEL_RING)
+            return (x64 || xmhw::ring64_pick_yps(p->host.w, p->host.ntracks)) ? XMHW_KERNEL_RING : -1;
+        return x64 ? XMHW_KERNEL_RING : XMHW_KERNEL_GENERIC;
+    }
+    const int32_t yps = xmhw::ring_pick(p->host.w, p->host.ntracks, elem_bytes, nullptr);
     if (p->host.kernel_choice == XMHW_KERNEL_RING) return yps ? XMHW_KERNEL_RING : -1;
     return yps ? XMHW_KERNEL_RING : XMHW_KERNEL_GENERIC;
 }
@@ -231,10 +252,18 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
                                                     plan->d_narrow_flag);
                 run_flag = plan->d_narrow_flag;
             }
-            if (e == hipSuccess)
-                e = xmhw::launch_ring_f64(reinterpret_cast<const double*>(ts), C, ld, plan->d_table64,
-                                          h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps64, q,
-                                          negate, thresh, seas, ldo, st, plan->d_stats, run_flag);
+            // genuinely float64 samples: the second-generation kernel's 64-bit mode where it is instantiated
+            // (XMHW_RING2_F64=0 keeps the round-1 float64 kernel), the round-1 float64 ring otherwise
+            if (e == hipSuccess) {
+                if (plan->yps2 && x64_usable(plan))
+                    e = xmhw::launch_ring2_f64(reinterpret_cast<const double*>(ts), C, ld, h.T, plan->d_table2, plan->d_sflags,
+                                               h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps2, h.ntracks, v2, q,
+                                               negate, thresh, seas, ldo, st, run_flag);
+                else
+                    e = xmhw::launch_ring_f64(reinterpret_cast<const double*>(ts), C, ld, plan->d_table64,
+                                              h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps64, q,
+                                              negate, thresh, seas, ldo, st, plan->d_stats, run_flag);
+            }
         }
     } else {
         const uint32_t* run_flag = nullptr;
@@ -243,7 +272,18 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
             // no float64 ring for this plan (e.g. a record of more than 48 tracks), but the float32 ring
             // covers it: float32-representable data still takes the fast kernel, the generic one
             // runs only if the narrowing gave up
-            if (plan->narrowing && plan->yps && plan->host.kernel_choice == XMHW_KERNEL_AUTO) {
+            const int32_t v2 = ring2_resolved(plan);
+            if (plan->narrowing && plan->yps2 && v2 >= 0 && xmhw::ring2_narrowing_supported(h.w, plan->yps2, v2) &&
+                plan->host.kernel_choice == XMHW_KERNEL_AUTO) {
+                if (!plan->d_narrow_flag) HIP_TRY(hipMalloc(&plan->d_narrow_flag, sizeof(uint32_t)));
+                e = xmhw::launch_narrow_probe(reinterpret_cast<const double*>(ts), h.T, C, ld, plan->d_narrow_flag, st);
+                if (e == hipSuccess)
+                    e = xmhw::launch_ring2_f32_narrowing(reinterpret_cast<const double*>(ts), C, ld, h.T, plan->d_table2,
+                                                         plan->d_sflags, h.step_min, plan->d_chunks, plan->nchunks, h.w,
+                                                         plan->yps2, h.ntracks, v2, q, negate, thresh, seas, ldo, st,
+                                                         plan->d_narrow_flag);
+                run_flag = plan->d_narrow_flag;
+            } else if (plan->narrowing && plan->yps && plan->host.kernel_choice == XMHW_KERNEL_AUTO) {
                 if (!plan->d_narrow_flag) HIP_TRY(hipMalloc(&plan->d_narrow_flag, sizeof(uint32_t)));
                 e = xmhw::launch_ring_f32_narrowing(reinterpret_cast<const double*>(ts), h.T, C, ld, plan->d_table,
                                                     h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps,

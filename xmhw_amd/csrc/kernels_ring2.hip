@@ -69,6 +69,20 @@ __device__ __forceinline__ double cell_sum(double v) {
     if constexpr (SUBS == 8) v += dpp2_f64<kR2>(v);
     return v;
 }
+template <int SUBS>
+__device__ __forceinline__ uint32_t cell_max(uint32_t v) {
+    uint32_t o = dpp2<kR8>(v); v = v > o ? v : o;
+    o = dpp2<kR4>(v); v = v > o ? v : o;
+    if constexpr (SUBS == 8) { o = dpp2<kR2>(v); v = v > o ? v : o; }
+    return v;
+}
+template <int SUBS>
+__device__ __forceinline__ uint32_t cell_min(uint32_t v) {
+    uint32_t o = dpp2<kR8>(v); v = v < o ? v : o;
+    o = dpp2<kR4>(v); v = v < o ? v : o;
+    if constexpr (SUBS == 8) { o = dpp2<kR2>(v); v = v < o ? v : o; }
+    return v;
+}
 __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -155,6 +169,26 @@ __device__ __forceinline__ uint32_t opaque(uint32_t v) {
 __device__ __forceinline__ double value_of_key(uint32_t k) {   // 0 for an invalid key
     const float f = __uint_as_float(bits_of_key(k));
     return k == kInv ? 0.0 : static_cast<double>(f);
+}
+
+// float64 samples as 64-bit order-preserving keys, split into a HIGH word (sign, exponent, 20 mantissa
+// bits: what the selection works on) and a LOW word (the remaining 32 mantissa bits: looked at only when
+// the two order statistics have been found).  negmask = 0 or 0xFFFFFFFF as for the float32 keys.
+__device__ __forceinline__ void key64_of(double v, uint32_t negmask, uint32_t& hi, uint32_t& lo) {
+    const uint64_t b = static_cast<uint64_t>(__double_as_longlong(v));
+    const uint32_t bh = static_cast<uint32_t>(b >> 32), bl = static_cast<uint32_t>(b);
+    const uint32_t sgn = ashr31(bh);                         // all ones for a negative sample
+    hi = bh ^ (sgn | 0x80000000u) ^ negmask;
+    lo = bl ^ sgn ^ negmask;
+}
+// the double a VALID key pair stands for (the negated sample under coldSpells)
+__device__ __forceinline__ double double_of_key64(uint32_t hi, uint32_t lo) {
+    const uint32_t sgn = ~ashr31(hi);                        // all ones if the value is negative
+    const uint32_t bh = hi ^ (sgn | 0x80000000u), bl = lo ^ sgn;
+    return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(bh) << 32) | bl));
+}
+__device__ __forceinline__ double value_of_key64(uint32_t hi, uint32_t lo) {      // 0 for an invalid key
+    return hi == kInv ? 0.0 : double_of_key64(hi, lo);
 }
 
 // The smallest distances above a pivot, ascending (ties repeated).  Every lane keeps the J smallest of ITS
@@ -262,16 +296,27 @@ constexpr int kBudget2 = 6;
 // float32 archives promoted by a reader): the samples are narrowed on load; `narrow_flag` (TI = double
 // only) is set as soon as a sample does not survive the round trip, the kernel gives up and the float64
 // kernel queued behind it (which looks at the same flag) does the work instead.
-template <int W, int YPS, int PB, int JX, int JMX, int SUBS, bool STATS, typename TI = float>
+// X64 (TI = double): genuinely float64 samples.  The rings hold the HIGH words of the 64-bit keys (the
+// whole selection runs on them exactly as on float32 keys) and, in a second set of tuples, the LOW words;
+// once the two order statistics are known by their high words, one pass over the rings fetches the low
+// words (a tie of high words -- two distinct doubles within 2^-20 relative of each other at the target
+// rank, or repeated values -- is settled there by successive minima of the low words).  `narrow_flag` is
+// then the RUN flag: the kernel is queued behind the narrowing one and returns unless that one gave up.
+template <int W, int YPS, int PB, int JX, int JMX, int SUBS, bool STATS, typename TI = float, bool X64 = false>
 __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     const TI* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, int32_t step_min, const DevChunk* __restrict__ chunks, double q,
     int negate, int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
     unsigned long long* __restrict__ stats, uint32_t* __restrict__ narrow_flag) {
     static_assert(W == 5, "count_le11 is written for an 11-sample window");
-    constexpr bool kNarrow = sizeof(TI) == 8;
+    static_assert(!X64 || (sizeof(TI) == 8 && PB == 0), "the 64-bit mode takes double input and no code ring");
+    constexpr bool kX64 = X64;
+    constexpr bool kNarrow = sizeof(TI) == 8 && !X64;
     if constexpr (kNarrow) {
         if (*narrow_flag != 0) return;           // the probe (or another workgroup) already found a lossy sample
+    }
+    if constexpr (kX64) {
+        if (narrow_flag != nullptr && *narrow_flag == 0) return;     // the narrowing kernel did the work
     }
     bool lossy = false;
     constexpr int R = 2 * W + 1;
@@ -316,6 +361,9 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     RingT ring[YPS];
 #pragma unroll
     for (int y = 0; y < YPS; ++y) ring[y] = kInv;
+    RingT ringlo[kX64 ? YPS : 1];     // X64: low words of the keys, slot for slot
+#pragma unroll
+    for (int y = 0; y < (kX64 ? YPS : 1); ++y) ringlo[y] = kInv;
     double lsum = 0.0;        // sum of the valid samples in this lane's rings (all tracks)
     uint32_t nval = 0;        // number of valid keys in this lane's rings (all tracks)
 
@@ -403,31 +451,50 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
         // NaN among the loaded samples?  (the sum propagates NaN; inf - inf also lands here and
         // merely takes the general step)
         // the samples of this row as float32 (narrowed and checked for float64 input)
-        float x_cur[YPS];
+        float x_cur[kX64 ? 1 : YPS];
+        uint32_t kin_lo[kX64 ? YPS : 1], kout_lo[kX64 ? YPS : 1];      // X64: low words
+        uint32_t khi[kX64 ? YPS : 1];                                   // X64: high words of this row's samples
 #pragma unroll
         for (int y = 0; y < YPS; ++y) {
-            x_cur[y] = static_cast<float>(x_raw[y]);
+            if constexpr (!kX64) x_cur[y] = static_cast<float>(x_raw[y]);
             if constexpr (kNarrow) lossy |= (static_cast<TI>(x_cur[y]) != x_raw[y]) && (x_raw[y] == x_raw[y]);
+            if constexpr (kX64) key64_of(static_cast<double>(x_raw[y]), negmask, khi[y], kin_lo[y]);
         }
-        float xs = x_cur[0];
+        bool row_nan;
+        if constexpr (kX64) {
+            bool nn_ = false;
 #pragma unroll
-        for (int y = 1; y < YPS; ++y) xs += x_cur[y];
-        const bool fast = (sf & 1u) && clean && !__any(xs != xs);
+            for (int y = 0; y < YPS; ++y) nn_ |= x_raw[y] != x_raw[y];
+            row_nan = nn_;
+        } else {
+            float xs = x_cur[0];
+#pragma unroll
+            for (int y = 1; y < YPS; ++y) xs += x_cur[y];
+            row_nan = xs != xs;
+        }
+        const bool fast = (sf & 1u) && clean && !__any(row_nan);
+        auto key_in = [&](int y) -> uint32_t {
+            if constexpr (kX64) return khi[y];
+            else return key_of_bits(__float_as_uint(x_cur[y]), negmask);
+        };
+        auto is_nan = [&](int y) -> bool { return x_raw[y] != x_raw[y]; };
         if (fast) {
             if constexpr (STATS) ++st_fast;
 #pragma unroll
-            for (int y = 0; y < YPS; ++y) kin[y] = key_of_bits(__float_as_uint(x_cur[y]), negmask);
+            for (int y = 0; y < YPS; ++y) kin[y] = key_in(y);
             kin[YPS - 1] |= padmask;
+            if constexpr (kX64) kin_lo[YPS - 1] |= padmask;
         } else if (sf & 1u) {
             // a simple step by the table, but a NaN was loaded or invalid keys sit in the rings: every
             // real track pushes and is pooled, only the samples need looking at
 #pragma unroll
             for (int y = 0; y < YPS; ++y) {
-                const float xv = x_cur[y];
-                const bool ok = xv == xv;
-                kin[y] = ok ? key_of_bits(__float_as_uint(xv), negmask) : kInv;
+                const bool ok = !is_nan(y);
+                kin[y] = ok ? key_in(y) : kInv;
+                if constexpr (kX64) kin_lo[y] = ok ? kin_lo[y] : kInv;
             }
             kin[YPS - 1] |= padmask;
+            if constexpr (kX64) kin_lo[YPS - 1] |= padmask;
         } else {
             // calendar edges, Feb 29, chunk warm-up: decode the step's table entries
             uint32_t e_cur[YPS];
@@ -438,35 +505,53 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                 const uint32_t code = e_cur[y] >> 1;
                 cmask |= (e_cur[y] & 1u) << y;
                 hmask |= (code == kCodeHold ? 1u : 0u) << y;
-                const float xv = x_cur[y];
-                const bool ok = code >= 2u && xv == xv;
-                kin[y] = ok ? key_of_bits(__float_as_uint(xv), negmask) : kInv;
+                const bool ok = code >= 2u && !is_nan(y);
+                kin[y] = ok ? key_in(y) : kInv;
+                if constexpr (kX64) kin_lo[y] = ok ? kin_lo[y] : kInv;
             }
             wave_hold = __any(hmask != 0);
         }
         // ---- the one place where the rings are written (slot m of every track) ------------
 #pragma unroll
         for (int y = 0; y < YPS; ++y) kout[y] = ring[y][m];
+        if constexpr (kX64) {
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) kout_lo[y] = ringlo[y][m];
+        }
         if (wave_hold) {
 #pragma unroll
-            for (int y = 0; y < YPS; ++y) kin[y] = ((hmask >> y) & 1u) ? kout[y] : kin[y];
+            for (int y = 0; y < YPS; ++y) {
+                kin[y] = ((hmask >> y) & 1u) ? kout[y] : kin[y];
+                if constexpr (kX64) kin_lo[y] = ((hmask >> y) & 1u) ? kout_lo[y] : kin_lo[y];
+            }
         }
 #pragma unroll
         for (int y = 0; y < YPS; ++y) ring[y][m] = kin[y];
+        if constexpr (kX64) {
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) ringlo[y][m] = kin_lo[y];
+        }
         uint32_t dF = 0;
         if (fast) {
             // running sum: + new samples - evicted samples (padded slot: both are masked to +0.0)
             double din, dout;
 #pragma unroll
             for (int y = 0; y < YPS; ++y) {
-                uint32_t bi = __float_as_uint(x_cur[y]) ^ (negmask & 0x80000000u);
-                uint32_t bo = bits_of_key(kout[y]);
-                if (y == YPS - 1) {
-                    bi &= ~padmask;
-                    bo &= ~padmask;
+                double di, dq;
+                if constexpr (kX64) {
+                    // (a padded slot holds the invalid key: value 0 on both sides)
+                    di = value_of_key64(kin[y], kin_lo[y]);
+                    dq = value_of_key64(kout[y], kout_lo[y]);
+                } else {
+                    uint32_t bi = __float_as_uint(x_cur[y]) ^ (negmask & 0x80000000u);
+                    uint32_t bo = bits_of_key(kout[y]);
+                    if (y == YPS - 1) {
+                        bi &= ~padmask;
+                        bo &= ~padmask;
+                    }
+                    di = static_cast<double>(__uint_as_float(bi));
+                    dq = static_cast<double>(__uint_as_float(bo));
                 }
-                const double di = static_cast<double>(__uint_as_float(bi));
-                const double dq = static_cast<double>(__uint_as_float(bo));
                 din = y == 0 ? di : din + di;
                 dout = y == 0 ? dq : dout + dq;
                 if constexpr (!PROBE8) dF += (kin[y] <= pc ? 1u : 0u) - (kout[y] <= pc ? 1u : 0u);
@@ -476,8 +561,13 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
 #pragma unroll
             for (int y = 0; y < YPS; ++y) {
                 // a held track contributes kin == kout: nothing changes
-                lsum += value_of_key(kin[y]);
-                lsum -= value_of_key(kout[y]);
+                if constexpr (kX64) {
+                    lsum += value_of_key64(kin[y], kin_lo[y]);
+                    lsum -= value_of_key64(kout[y], kout_lo[y]);
+                } else {
+                    lsum += value_of_key(kin[y]);
+                    lsum -= value_of_key(kout[y]);
+                }
                 nval += (kin[y] != kInv ? 1u : 0u) - (kout[y] != kInv ? 1u : 0u);
                 if constexpr (!PROBE8) dF += (kin[y] <= pc ? 1u : 0u) - (kout[y] <= pc ? 1u : 0u);
             }
@@ -539,7 +629,8 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                     for (int k = 0; k < R; ++k) {
                         const uint32_t key = opaque(ring[y][k]);
                         cy += key != kInv ? 1u : 0u;
-                        ty += value_of_key(key);
+                        if constexpr (kX64) ty += value_of_key64(key, opaque(ringlo[y][k]));
+                        else ty += value_of_key(key);
                     }
                     const bool cnt = (cmask >> y) & 1u;
                     nl += cnt ? cy : 0u;
@@ -556,7 +647,10 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                 for (int y = 0; y < YPS; ++y) {
                     double ty = 0.0;
 #pragma unroll
-                    for (int k = 0; k < R; ++k) ty += value_of_key(opaque(ring[y][k]));
+                    for (int k = 0; k < R; ++k) {
+                        if constexpr (kX64) ty += value_of_key64(opaque(ring[y][k]), opaque(ringlo[y][k]));
+                        else ty += value_of_key(opaque(ring[y][k]));
+                    }
                     t += ty;
                     tl += ((cmask >> y) & 1u) ? ty : 0.0;
                 }
@@ -871,9 +965,91 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                 }
             }
             double th = make_nan(), se = make_nan();
+            double v_lo = 0.0, v_hi = 0.0;      // the two order statistics as values
+            if constexpr (kX64) {
+                // ---- low words of the two order statistics (alo, ahi are HIGH words here) ----------
+                // one pass: how many pooled keys carry each high word, and the low word of one of them
+                uint32_t ca = 0, cb = 0, la = 0, lb = 0;
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) {
+                    const bool cnt = wallc || ((cmask >> y) & 1u);
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const uint32_t key = ring[y][k], l = ringlo[y][k];
+                        const bool ea = cnt && key == alo, eb = cnt && key == ahi;
+                        ca += ea ? 1u : 0u;
+                        cb += eb ? 1u : 0u;
+                        la = ea ? l : la;
+                        lb = eb ? l : lb;
+                    }
+                }
+                ca = cell_sum<SUBS>(ca);
+                cb = cell_sum<SUBS>(cb);
+                la = cell_max<SUBS>(la);        // (exact when the cell holds ONE such key: the other lanes offer 0)
+                lb = cell_max<SUBS>(lb);
+                // ties of high words (repeated values, or distinct doubles within 2^-20 of each other at the target
+                // rank): the r-th smallest low word of the group, by successive minima with their multiplicities
+                const bool tie_a = n > 0 && ca > 1u, tie_b = n > 0 && need2 && cb > 1u;
+                if (__any(tie_a || tie_b)) {
+                    // keys below group A: lo itself when A is a single key, otherwise counted
+                    uint32_t below_a = lo;
+                    if (__any(tie_a)) {
+                        const uint32_t c = count_le(tie_a ? alo - 1u : 0u);
+                        below_a = tie_a ? c : lo;
+                    }
+                    const uint32_t ra = lo - below_a;                                   // rank inside group A
+                    const uint32_t rb = ahi == alo ? ra + 1u : lo + 1u - (below_a + ca);  // rank inside group B
+                    auto nth_low = [&](uint32_t H, uint32_t r, bool want) -> uint32_t {
+                        uint32_t prev = 0, rem = r, ans = 0;
+                        bool have_prev = false, open = want;
+                        while (__any(open)) {
+                            uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+                            for (int y = 0; y < YPS; ++y) {
+                                const bool cnt = wallc || ((cmask >> y) & 1u);
+#pragma unroll
+                                for (int k = 0; k < R; ++k) {
+                                    const uint32_t key = opaque(ring[y][k]), l = opaque(ringlo[y][k]);
+                                    const bool in = cnt && key == H && (!have_prev || l > prev);
+                                    mn = in ? minu(mn, l) : mn;
+                                }
+                            }
+                            mn = cell_min<SUBS>(mn);
+                            uint32_t c = 0;
+#pragma unroll
+                            for (int y = 0; y < YPS; ++y) {
+                                const bool cnt = wallc || ((cmask >> y) & 1u);
+#pragma unroll
+                                for (int k = 0; k < R; ++k)
+                                    c += (cnt && opaque(ring[y][k]) == H && opaque(ringlo[y][k]) == mn) ? 1u : 0u;
+                            }
+                            c = cell_sum<SUBS>(c);
+                            if (open) {
+                                if (rem < c || c == 0u) {       // (c == 0 cannot happen for r inside the group; it ends the loop)
+                                    ans = mn;
+                                    open = false;
+                                } else {
+                                    rem -= c;
+                                    prev = mn;
+                                    have_prev = true;
+                                }
+                            }
+                        }
+                        return ans;
+                    };
+                    const uint32_t xa = nth_low(alo, ra, tie_a);
+                    const uint32_t xb = nth_low(ahi, rb, tie_b);
+                    la = tie_a ? xa : la;
+                    lb = tie_b ? xb : lb;
+                }
+                v_lo = double_of_key64(alo, la);
+                v_hi = need2 ? double_of_key64(ahi, lb) : v_lo;
+            } else {
+                v_lo = static_cast<double>(__uint_as_float(bits_of_key(alo)));
+                v_hi = static_cast<double>(__uint_as_float(bits_of_key(ahi)));
+            }
             if (n > 0) {
-                th = numpy_lerp(static_cast<double>(__uint_as_float(bits_of_key(alo))),
-                                static_cast<double>(__uint_as_float(bits_of_key(ahi))), g);
+                th = numpy_lerp(v_lo, v_hi, g);
                 se = total / static_cast<double>(n);
                 if constexpr (!PROBE8) {
                     if (rank_gap > 1 || rank_gap < -1) {
@@ -933,6 +1109,18 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
             uint32_t e0 = ring[y][0];
             ring_sel(e0, last, hy);
             ring[y][0] = e0;
+            if constexpr (kX64) {
+                const uint32_t last_lo = opaque(ringlo[y][R - 1]);
+#pragma unroll
+                for (int k = R - 1; k >= 1; --k) {
+                    uint32_t e = ringlo[y][k];
+                    ring_sel(e, ringlo[y][k - 1], hy);
+                    ringlo[y][k] = e;
+                }
+                uint32_t l0 = ringlo[y][0];
+                ring_sel(l0, last_lo, hy);
+                ringlo[y][0] = l0;
+            }
         }
         have_code = 0;         // byte positions moved: rebuild the code ring
     }
@@ -968,7 +1156,7 @@ typedef void (*Ring2Kernel)(const float*, int64_t, int64_t, int64_t, const uint3
 typedef void (*Ring2KernelN)(const double*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*, int32_t,
                              const DevChunk*, double, int, int32_t, double*, double*, int64_t, unsigned long long*,
                              uint32_t*);
-struct Ring2Entry { int w, yps, subs, variant; Ring2Kernel fn, fn_stats; Ring2KernelN fn_narrow; };
+struct Ring2Entry { int w, yps, subs, variant; Ring2Kernel fn, fn_stats; Ring2KernelN fn_narrow, fn_x64; };
 // variant -> (code-ring bits, extraction width, lanes per cell); the _stats twin carries the debug pass counters
 //   0: 32-bit count passes, J = 5        1: 8-bit probes, J = 5      2: 16-bit probes, J = 5
 //   3: 16-bit probes, J = 4              4: 16-bit probes, J = 3
@@ -976,10 +1164,16 @@ struct Ring2Entry { int w, yps, subs, variant; Ring2Kernel fn, fn_stats; Ring2Ke
 //   7: as 0 with 4 lanes per cell (16 cells per wave, twice the tracks per lane)
 //   8 / 9: as 0 / 7 with the lanes' J = 5 lists merged into the cell's 8 nearest keys (window of 7 ranks)
 //   10 / 11: as 9 with 7 / 6 merged keys (4 lanes per cell: a lane holds 5 of the cell's 8 nearest more often)
-#define XMHW_R2V(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>, nullptr}
-// the shipped layouts also exist for float64 input that narrows to float32 without loss
+#define XMHW_R2V(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>, nullptr, nullptr}
+// the shipped layouts also exist for float64 input: narrowing to float32 where that is lossless, and the
+// 64-bit mode (high / low key words) for genuinely float64 samples
 #define XMHW_R2N(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>, \
-                                          clim_ring2_f32<W, Y, PB, JX, JM, S, false, double>}
+                                          clim_ring2_f32<W, Y, PB, JX, JM, S, false, double>,             \
+                                          clim_ring2_f32<W, Y, PB, JX, JM, S, false, double, true>}
+// (narrowing only: the 64-bit mode would spill heavily at 66 or more keys per lane; those plans keep the
+// round-1 float64 kernel)
+#define XMHW_R2M(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>, \
+                                          clim_ring2_f32<W, Y, PB, JX, JM, S, false, double>, nullptr}
 #define XMHW_R2(W, Y) XMHW_R2V(W, Y, 8, 0, 0, 5, 5), XMHW_R2V(W, Y, 8, 1, 8, 5, 5), XMHW_R2V(W, Y, 8, 2, 16, 5, 5), \
                       XMHW_R2V(W, Y, 8, 3, 16, 4, 4), XMHW_R2V(W, Y, 8, 4, 16, 3, 3), XMHW_R2V(W, Y, 8, 5, 0, 4, 4), \
                       XMHW_R2V(W, Y, 8, 6, 0, 6, 6), XMHW_R2N(W, Y, 8, 8, 0, 5, 8)
@@ -987,16 +1181,17 @@ const Ring2Entry kRing2[] = {
     XMHW_R2(5, 3), XMHW_R2(5, 4), XMHW_R2(5, 5),
     XMHW_R2V(5, 5, 4, 7, 0, 5, 5), XMHW_R2V(5, 8, 4, 7, 0, 5, 5), XMHW_R2V(5, 10, 4, 7, 0, 5, 5),
     XMHW_R2V(5, 5, 4, 9, 0, 5, 8), XMHW_R2V(5, 8, 4, 9, 0, 5, 8), XMHW_R2V(5, 10, 4, 9, 0, 5, 8),
-    XMHW_R2N(5, 5, 4, 10, 0, 5, 7), XMHW_R2N(5, 8, 4, 10, 0, 5, 7), XMHW_R2N(5, 10, 4, 10, 0, 5, 7),
+    XMHW_R2N(5, 5, 4, 10, 0, 5, 7), XMHW_R2M(5, 8, 4, 10, 0, 5, 7), XMHW_R2M(5, 10, 4, 10, 0, 5, 7),
     XMHW_R2V(5, 5, 4, 11, 0, 5, 6), XMHW_R2V(5, 8, 4, 11, 0, 5, 6), XMHW_R2V(5, 10, 4, 11, 0, 5, 6),
     // shorter and longer records (9..16 and 41..48 tracks: 10-year series, OISST 1982-today), shipped layouts
     // and their plain counterparts only
-    XMHW_R2V(5, 2, 8, 0, 0, 5, 5), XMHW_R2N(5, 2, 8, 8, 0, 5, 8), XMHW_R2V(5, 6, 8, 0, 0, 5, 5), XMHW_R2N(5, 6, 8, 8, 0, 5, 8),
+    XMHW_R2V(5, 2, 8, 0, 0, 5, 5), XMHW_R2N(5, 2, 8, 8, 0, 5, 8), XMHW_R2V(5, 6, 8, 0, 0, 5, 5), XMHW_R2M(5, 6, 8, 8, 0, 5, 8),
     XMHW_R2V(5, 3, 4, 7, 0, 5, 5), XMHW_R2N(5, 3, 4, 10, 0, 5, 7), XMHW_R2V(5, 4, 4, 7, 0, 5, 5), XMHW_R2N(5, 4, 4, 10, 0, 5, 7),
 };
 #undef XMHW_R2
 #undef XMHW_R2V
 #undef XMHW_R2N
+#undef XMHW_R2M
 const Ring2Entry* find_ring2(int32_t w, int32_t yps, int32_t subs, int32_t variant) {
     for (const auto& e : kRing2)
         if (e.w == w && e.yps == yps && e.subs == subs && e.variant == variant) return &e;
@@ -1031,6 +1226,29 @@ hipError_t launch_ring2_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
     hipLaunchKernelGGL(stats ? e->fn_stats : e->fn, grid, dim3(64 * kWaves2), 0, stream, ts, C, ld, Tn, table, sflags, step_min,
                        chunks, q, negate, ntracks, thresh, seas, ldo, stats, static_cast<uint32_t*>(nullptr));
+    return hipGetLastError();
+}
+
+bool ring2_x64_supported(int32_t w, int32_t yps, int32_t variant) {
+    const Ring2Entry* e = find_ring2(w, yps, ring2_subs(variant), variant);
+    return e != nullptr && e->fn_x64 != nullptr;
+}
+
+// genuinely float64 samples on the second-generation kernel (64-bit keys as high / low words); run_flag: device
+// flag of the narrowing launch queued before it (nullptr: always run; 0 at run time: nothing to do)
+hipError_t launch_ring2_f64(const double* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
+                            const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,
+                            int32_t w, int32_t yps, int32_t ntracks, int32_t variant, double q, int negate,
+                            double* thresh, double* seas, int64_t ldo, hipStream_t stream, const uint32_t* run_flag) {
+    const int32_t subs = ring2_subs(variant);
+    const Ring2Entry* e = find_ring2(w, yps, subs, variant);
+    if (!e || !e->fn_x64) return hipErrorInvalidValue;
+    if (C <= 0 || nchunks <= 0) return hipSuccess;
+    const int64_t cells_per_block = (64 / subs) * kWaves2;
+    dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
+    hipLaunchKernelGGL(e->fn_x64, grid, dim3(64 * kWaves2), 0, stream, ts, C, ld, Tn, table, sflags, step_min, chunks, q,
+                       negate, ntracks, thresh, seas, ldo, static_cast<unsigned long long*>(nullptr),
+                       const_cast<uint32_t*>(run_flag));
     return hipGetLastError();
 }
 

@@ -24,6 +24,7 @@ constexpr int kCells = 4;
 constexpr int kTopJ = 6;
 constexpr int kCountBudget = 6;
 constexpr uint64_t kKeyNegInf = 0x000FFFFFFFFFFFFFull;  // f64_key(-inf): smallest valid key
+constexpr uint64_t kKeyPosInf = 0xFFF0000000000000ull;  // f64_key(+inf): largest valid key
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
@@ -358,7 +359,11 @@ __global__ __launch_bounds__(256) void clim_ring_f64(
                     uint64_t off = (it < 5) ? static_cast<uint64_t>(stf) : (room >> 1);
                     grow = both ? grow : grow * 2.0f;
                     off = umax64(1ull, umin64(off, room - 1ull));
-                    const uint64_t kp = settle ? kl : kl + off;
+                    // keep the pivot among the keys of real numbers: the key space continues into the NaN
+                    // patterns beyond +-inf, and a pivot there compares false with everything (count 0 where it
+                    // should be n) -- a one-sided secant step on clustered data could overshoot into them
+                    // (found by tools/fuzz_ring2.py --dtype f64 in round 2)
+                    const uint64_t kp = settle ? kl : umin64(umax64(kl + off, kKeyNegInf), kKeyPosInf);
                     const uint32_t F = count_le(key_f64(kp));
                     ++st_count;
                     if (!settle) {
