@@ -287,7 +287,10 @@ def run(args):
     ring_avg_ms = float(np.mean(ring_ms))
     achieved = cells_per_launch * bytes_per_cell / (ring_avg_ms * 1e-3) / 1e9
     v2 = plan.ring2_in_use() if isz == 4 and plan.kernel == "ring" else -1
+    x64 = plan.f64_mode() if isz == 8 and plan.kernel == "ring" else -1
     kname = (f"clim_ring2_f32 (variant {v2})" if v2 >= 0 else
+             f"clim_ring2_f32<double, 64-bit keys> (layout {x64})" if x64 >= 0 else
+             ("clim_ring_f64" if args.kernel == "ring" else "clim_generic") if isz == 8 else
              ("clim_ring_" + args.dtype if plan.kernel == "ring" else "clim_generic"))
 
     result = {

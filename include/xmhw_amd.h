@@ -152,6 +152,11 @@ int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out8);
 int xmhw_plan_set_ring2(xmhw_plan *plan, int32_t variant);
 /* the variant float32 input of this plan will run on, -1 if the round-1 / generic kernel */
 int xmhw_plan_ring2_in_use(const xmhw_plan *plan, int32_t *variant);
+/* genuinely float64 samples (those that do not narrow to float32): the layout variant of the
+ * second-generation kernel's 64-bit mode this plan will run on (8 / 10: the float32 layouts, 12: 16
+ * lanes per cell), or -1 (generic kernel; the round-1 float64 ring only on an explicit
+ * XMHW_KERNEL_RING request).  w = 5, up to 48 tracks.                                           */
+int xmhw_plan_f64_mode(const xmhw_plan *plan, int32_t *variant);
 
 /* ---- the hot path ------------------------------------------------------ *
  * xmhw_clim_raw_*: for every cell, the pooled linear-interpolated quantile

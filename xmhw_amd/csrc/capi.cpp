@@ -73,12 +73,15 @@ struct xmhw_plan {
     int32_t* d_row_ptr = nullptr;
     int32_t* d_centres = nullptr;
     unsigned long long* d_stats = nullptr;  // debug: ring kernel pass counters (xmhw_plan_debug_stats)
+    uint32_t* d_tablex = nullptr;           // 8-lane table of the 64-bit mode when the float32 layout is another one
+    int32_t ypsx = 0;
     uint32_t* d_narrow_flag = nullptr;      // float64 input: set when a sample is not float32-representable
     bool narrowing = true;                  // xmhw_plan_set_narrowing
 
     ~xmhw_plan() {
         if (d_stats) (void)hipFree(d_stats);
         if (d_narrow_flag) (void)hipFree(d_narrow_flag);
+        if (d_tablex) (void)hipFree(d_tablex);
         if (d_table) (void)hipFree(d_table);
         if (d_table64) (void)hipFree(d_table64);
         if (d_table2) (void)hipFree(d_table2);
@@ -93,14 +96,31 @@ namespace {
 
 int32_t ring2_resolved(const xmhw_plan* p);
 
-// float64 samples on the second-generation kernel's 64-bit mode: instantiated for this plan and not switched off
-bool x64_usable(const xmhw_plan* p) {
+// float64 samples on the second-generation kernel's 64-bit mode: which layout, if any.  The float32 layout of
+// the plan (8 or 4 lanes per cell) as long as a lane holds at most 4 tracks (44 keys and their low words fit the
+// registers); otherwise, and for short records, 16 lanes per cell (variant 12, the table of the 16-lane rings).
+struct X64Choice { int32_t variant = -1, yps = 0; };
+X64Choice x64_choice(const xmhw_plan* p) {
     static const bool on = [] { const char* v = std::getenv("XMHW_RING2_F64"); return !(v && v[0] == '0'); }();
-    const int32_t v2 = ring2_resolved(p);
-    if (!on || v2 < 0) return false;
-    const int32_t y2 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, v2);
-    return y2 > 0 && xmhw::ring2_x64_supported(p->host.w, y2, v2);
+    X64Choice c;
+    if (!on || p->ring2_variant == -1) return c;
+    // 8 lanes per cell as long as a lane holds at most 4 tracks (9..32 tracks) ...
+    const int32_t y8 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 8);
+    if (y8 > 0 && y8 <= 4 && xmhw::ring2_x64_supported(p->host.w, y8, 8)) {
+        c.variant = 8;
+        c.yps = y8;
+        return c;
+    }
+    // ... 16 lanes per cell for longer and for very short records (the table of the 16-lane rings)
+    const int32_t y16 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 12);
+    if (y16 > 0 && xmhw::ring2_x64_supported(p->host.w, y16, 12) &&
+        y16 == xmhw::ring64_pick_yps(p->host.w, p->host.ntracks)) {
+        c.variant = 12;
+        c.yps = y16;
+    }
+    return c;
 }
+bool x64_usable(const xmhw_plan* p) { return x64_choice(p).variant >= 0; }
 
 int32_t resolve_kernel(const xmhw_plan* p, int elem_bytes) {
     if (p->host.kernel_choice == XMHW_KERNEL_GENERIC) return XMHW_KERNEL_GENERIC;
@@ -145,9 +165,12 @@ int32_t ring2_resolved(const xmhw_plan* p) {
 int upload(xmhw_plan* p, int64_t C) {
     std::lock_guard<std::mutex> lock(p->mu);
     const int32_t nchunks = auto_chunks(p, C);
+    const X64Choice xc0 = x64_choice(p);
+    const bool need_x = xc0.variant == 8 && !(p->subs2 == 8 && p->yps2 == xc0.yps);
     if (p->uploaded && nchunks == p->nchunks &&
         p->subs2 == xmhw::ring2_subs(ring2_resolved(p)) &&
-        p->yps2 == (ring2_resolved(p) >= 0 ? xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, ring2_resolved(p)) : 0))
+        p->yps2 == (ring2_resolved(p) >= 0 ? xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, ring2_resolved(p)) : 0) &&
+        (!need_x || p->ypsx == xc0.yps))
         return XMHW_OK;
     const xmhw::Plan& h = p->host;
     if (!p->uploaded) {
@@ -182,6 +205,17 @@ int upload(xmhw_plan* p, int64_t C) {
                 HIP_TRY(hipMalloc(&p->d_table2, sizeof(uint32_t) * t2.size()));
                 HIP_TRY(hipMemcpy(p->d_table2, t2.data(), sizeof(uint32_t) * t2.size(), hipMemcpyHostToDevice));
             }
+        }
+    }
+    {
+        // the 64-bit mode's own 8-lane table, when the float32 layout of this plan is a different one
+        const X64Choice xc = x64_choice(p);
+        if (xc.variant == 8 && !(p->subs2 == 8 && p->yps2 == xc.yps) && p->ypsx != xc.yps) {
+            if (p->d_tablex) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p->d_tablex)); p->d_tablex = nullptr; }
+            const std::vector<uint32_t> tx = h.ring_table(8, xc.yps);
+            HIP_TRY(hipMalloc(&p->d_tablex, sizeof(uint32_t) * tx.size()));
+            HIP_TRY(hipMemcpy(p->d_tablex, tx.data(), sizeof(uint32_t) * tx.size(), hipMemcpyHostToDevice));
+            p->ypsx = xc.yps;
         }
     }
     if (p->yps || p->yps64 || p->yps2) {
@@ -255,10 +289,14 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
             // genuinely float64 samples: the second-generation kernel's 64-bit mode where it is instantiated
             // (XMHW_RING2_F64=0 keeps the round-1 float64 kernel), the round-1 float64 ring otherwise
             if (e == hipSuccess) {
-                if (plan->yps2 && x64_usable(plan))
-                    e = xmhw::launch_ring2_f64(reinterpret_cast<const double*>(ts), C, ld, h.T, plan->d_table2, plan->d_sflags,
-                                               h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps2, h.ntracks, v2, q,
-                                               negate, thresh, seas, ldo, st, run_flag);
+                const X64Choice xc = x64_choice(plan);
+                if (xc.variant >= 0)
+                    e = xmhw::launch_ring2_f64(reinterpret_cast<const double*>(ts), C, ld, h.T,
+                                               xc.variant == 12 ? plan->d_table64
+                                               : (plan->subs2 == 8 && plan->yps2 == xc.yps) ? plan->d_table2 : plan->d_tablex,
+                                               plan->d_sflags,
+                                               h.step_min, plan->d_chunks, plan->nchunks, h.w, xc.yps, h.ntracks, xc.variant,
+                                               q, negate, thresh, seas, ldo, st, run_flag);
                 else
                     e = xmhw::launch_ring_f64(reinterpret_cast<const double*>(ts), C, ld, plan->d_table64,
                                               h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps64, q,
@@ -897,6 +935,11 @@ int xmhw_plan_ring2_in_use(const xmhw_plan* plan, int32_t* variant) {
     const bool ring = resolve_kernel(plan, 4) == XMHW_KERNEL_RING;
     const int32_t v2 = ring2_resolved(plan);
     *variant = (ring && v2 >= 0 && xmhw::ring2_pick_yps(plan->host.w, plan->host.ntracks, v2) > 0) ? v2 : -1;
+    return XMHW_OK;
+}
+int xmhw_plan_f64_mode(const xmhw_plan* plan, int32_t* variant) {
+    if (!plan || !variant) return fail(XMHW_ERR_INVALID, "NULL argument");
+    *variant = resolve_kernel(plan, 8) == XMHW_KERNEL_RING ? x64_choice(plan).variant : -1;
     return XMHW_OK;
 }
 int xmhw_plan_destroy(xmhw_plan* plan) {

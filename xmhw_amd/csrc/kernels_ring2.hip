@@ -44,15 +44,17 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t dpp2(uint32_t v) {
     return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), CTRL, 0xF, 0xF, false));
 }
-constexpr int kR8 = 0x128, kR4 = 0x124, kR2 = 0x122;
+constexpr int kR8 = 0x128, kR4 = 0x124, kR2 = 0x122, kR1 = 0x121;      // row_ror:8 / 4 / 2 / 1
 
-// lanes of a cell sit in one 16-lane DPP row: 8 subs at stride 2 (8 cells per wave) or 4 subs at
-// stride 4 (16 cells per wave); the all-reduce is 3 or 2 row rotations
+// lanes of a cell sit in one 16-lane DPP row: 16 subs (one cell per row, 4 cells per wave), 8 subs at
+// stride 2 (8 cells per wave) or 4 subs at stride 4 (16 cells per wave); the all-reduce is 4, 3 or 2 row
+// rotations
 template <int SUBS>
 __device__ __forceinline__ uint32_t cell_sum(uint32_t v) {
     v += dpp2<kR8>(v);
     v += dpp2<kR4>(v);
-    if constexpr (SUBS == 8) v += dpp2<kR2>(v);
+    if constexpr (SUBS >= 8) v += dpp2<kR2>(v);
+    if constexpr (SUBS == 16) v += dpp2<kR1>(v);
     return v;
 }
 template <int CTRL>
@@ -66,21 +68,24 @@ template <int SUBS>
 __device__ __forceinline__ double cell_sum(double v) {
     v += dpp2_f64<kR8>(v);
     v += dpp2_f64<kR4>(v);
-    if constexpr (SUBS == 8) v += dpp2_f64<kR2>(v);
+    if constexpr (SUBS >= 8) v += dpp2_f64<kR2>(v);
+    if constexpr (SUBS == 16) v += dpp2_f64<kR1>(v);
     return v;
 }
 template <int SUBS>
 __device__ __forceinline__ uint32_t cell_max(uint32_t v) {
     uint32_t o = dpp2<kR8>(v); v = v > o ? v : o;
     o = dpp2<kR4>(v); v = v > o ? v : o;
-    if constexpr (SUBS == 8) { o = dpp2<kR2>(v); v = v > o ? v : o; }
+    if constexpr (SUBS >= 8) { o = dpp2<kR2>(v); v = v > o ? v : o; }
+    if constexpr (SUBS == 16) { o = dpp2<kR1>(v); v = v > o ? v : o; }
     return v;
 }
 template <int SUBS>
 __device__ __forceinline__ uint32_t cell_min(uint32_t v) {
     uint32_t o = dpp2<kR8>(v); v = v < o ? v : o;
     o = dpp2<kR4>(v); v = v < o ? v : o;
-    if constexpr (SUBS == 8) { o = dpp2<kR2>(v); v = v < o ? v : o; }
+    if constexpr (SUBS >= 8) { o = dpp2<kR2>(v); v = v < o ? v : o; }
+    if constexpr (SUBS == 16) { o = dpp2<kR1>(v); v = v < o ? v : o; }
     return v;
 }
 __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
@@ -218,7 +223,8 @@ struct Top2 {
         uint32_t g = m[J - 1];
         g = minu(g, dpp2<kR8>(g));
         g = minu(g, dpp2<kR4>(g));
-        if constexpr (SUBS == 8) g = minu(g, dpp2<kR2>(g));
+        if constexpr (SUBS >= 8) g = minu(g, dpp2<kR2>(g));
+        if constexpr (SUBS == 16) g = minu(g, dpp2<kR1>(g));
         return g;
     }
     // FIRST: both lists still have their entries J..JM-1 at "infinity" (nothing merged yet), which the
@@ -253,7 +259,8 @@ struct Top2 {
     __device__ __forceinline__ void merge_cell() {
         merge<kR8, true>();
         merge<kR4>();
-        if constexpr (SUBS == 8) merge<kR2>();
+        if constexpr (SUBS >= 8) merge<kR2>();
+        if constexpr (SUBS == 16) merge<kR1>();
     }
     // entries j and j + 1 with one chain of compares
     __device__ __forceinline__ void at2(uint32_t j, uint32_t& a, uint32_t& b) const {
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     }
     bool lossy = false;
     constexpr int R = 2 * W + 1;
-    static_assert(SUBS == 8 || SUBS == 4, "8 lanes per cell (8 cells per wave) or 4 (16 cells per wave)");
+    static_assert(SUBS == 16 || SUBS == 8 || SUBS == 4, "16, 8 or 4 lanes per cell (4, 8 or 16 cells per wave)");
     constexpr int NTP = SUBS * YPS;
     constexpr int CPWAVE = 64 / SUBS;            // cells per wave
     // PB: width of the code ring the bracket is closed on (0: none, 32-bit count passes only; 8; 16);
@@ -339,8 +346,8 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     // lane = (c / k) * 16 + sub * k + (c % k) with k = 16 / SUBS cells per DPP row
-    const int sub = SUBS == 8 ? (lane >> 1) & 7 : (lane >> 2) & 3;
-    const int cw = SUBS == 8 ? (lane & 1) | ((lane >> 4) << 1) : (lane & 3) | ((lane >> 4) << 2);
+    const int sub = SUBS == 16 ? lane & 15 : SUBS == 8 ? (lane >> 1) & 7 : (lane >> 2) & 3;
+    const int cw = SUBS == 16 ? lane >> 4 : SUBS == 8 ? (lane & 1) | ((lane >> 4) << 1) : (lane & 3) | ((lane >> 4) << 2);
     const int64_t cell = (static_cast<int64_t>(blockIdx.x) * kWaves2 + wave) * CPWAVE + cw;
     const bool cell_ok = cell < C;
     const DevChunk ch = chunks[blockIdx.y];
@@ -1174,6 +1181,9 @@ struct Ring2Entry { int w, yps, subs, variant; Ring2Kernel fn, fn_stats; Ring2Ke
 // round-1 float64 kernel)
 #define XMHW_R2M(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>, \
                                           clim_ring2_f32<W, Y, PB, JX, JM, S, false, double>, nullptr}
+// 16 lanes per cell, 64-bit mode only (variant 12): genuinely float64 samples of plans with more keys per lane
+// than the 8- and 4-lane layouts can hold in registers next to the low words, and of short records
+#define XMHW_R2X(W, Y, S, V, PB, JX, JM) {W, Y, S, V, nullptr, nullptr, nullptr, clim_ring2_f32<W, Y, PB, JX, JM, S, false, double, true>}
 #define XMHW_R2(W, Y) XMHW_R2V(W, Y, 8, 0, 0, 5, 5), XMHW_R2V(W, Y, 8, 1, 8, 5, 5), XMHW_R2V(W, Y, 8, 2, 16, 5, 5), \
                       XMHW_R2V(W, Y, 8, 3, 16, 4, 4), XMHW_R2V(W, Y, 8, 4, 16, 3, 3), XMHW_R2V(W, Y, 8, 5, 0, 4, 4), \
                       XMHW_R2V(W, Y, 8, 6, 0, 6, 6), XMHW_R2N(W, Y, 8, 8, 0, 5, 8)
@@ -1187,11 +1197,13 @@ const Ring2Entry kRing2[] = {
     // and their plain counterparts only
     XMHW_R2V(5, 2, 8, 0, 0, 5, 5), XMHW_R2N(5, 2, 8, 8, 0, 5, 8), XMHW_R2V(5, 6, 8, 0, 0, 5, 5), XMHW_R2M(5, 6, 8, 8, 0, 5, 8),
     XMHW_R2V(5, 3, 4, 7, 0, 5, 5), XMHW_R2N(5, 3, 4, 10, 0, 5, 7), XMHW_R2V(5, 4, 4, 7, 0, 5, 5), XMHW_R2N(5, 4, 4, 10, 0, 5, 7),
+    XMHW_R2X(5, 1, 16, 12, 0, 5, 8), XMHW_R2X(5, 2, 16, 12, 0, 5, 8), XMHW_R2X(5, 3, 16, 12, 0, 5, 8),
 };
 #undef XMHW_R2
 #undef XMHW_R2V
 #undef XMHW_R2N
 #undef XMHW_R2M
+#undef XMHW_R2X
 const Ring2Entry* find_ring2(int32_t w, int32_t yps, int32_t subs, int32_t variant) {
     for (const auto& e : kRing2)
         if (e.w == w && e.yps == yps && e.subs == subs && e.variant == variant) return &e;
@@ -1199,7 +1211,7 @@ const Ring2Entry* find_ring2(int32_t w, int32_t yps, int32_t subs, int32_t varia
 }
 }  // namespace
 
-int32_t ring2_subs(int32_t variant) { return (variant == 7 || variant >= 9) ? 4 : 8; }
+int32_t ring2_subs(int32_t variant) { return variant == 12 ? 16 : (variant == 7 || variant >= 9) ? 4 : 8; }
 
 int32_t ring2_pick_yps(int32_t w, int32_t ntracks, int32_t variant) {
     const int32_t subs = ring2_subs(variant);
@@ -1220,7 +1232,7 @@ hipError_t launch_ring2_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
                             unsigned long long* stats) {
     const int32_t subs = ring2_subs(variant);
     const Ring2Entry* e = find_ring2(w, yps, subs, variant);
-    if (!e) return hipErrorInvalidValue;
+    if (!e || !e->fn) return hipErrorInvalidValue;
     if (C <= 0 || nchunks <= 0) return hipSuccess;
     const int64_t cells_per_block = (64 / subs) * kWaves2;
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));

@@ -140,6 +140,7 @@ PYBIND11_MODULE(_xmhw_hip, m) {
         return out;
     });
     m.def("plan_ring2_in_use", [](uintptr_t p) { int32_t v = -1; check(xmhw_plan_ring2_in_use(pp(p), &v)); return v; });
+    m.def("plan_f64_mode", [](uintptr_t p) { int32_t v = -1; check(xmhw_plan_f64_mode(pp(p), &v)); return v; });
     m.def("plan_set_ring2", [](uintptr_t p, int variant) { check(xmhw_plan_set_ring2(pp(p), variant)); });
 
     m.def("clim_raw", [](uintptr_t plan, uintptr_t ts, int itemsize, int64_t C, int64_t ld, double q, int negate,

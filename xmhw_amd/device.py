@@ -181,6 +181,10 @@ class Plan:
         """variant of the second-generation ring kernel float32 input will run on (-1: none)"""
         return int(self._h.plan_ring2_in_use(self.handle))
 
+    def f64_mode(self):
+        """layout variant of the 64-bit mode float64 samples will run on (-1: generic kernel)"""
+        return int(self._h.plan_f64_mode(self.handle))
+
     def narrowed(self):
         """True if the last float64 clim_raw() of this plan ran on the float32 ring kernel (every
         sample float32-representable)."""
