@@ -50,6 +50,12 @@ def _case(rng, dtype, windows):
     if quant:
         x = np.round(x / quant) * quant
     x = x.astype(dtype)
+    if rng.integers(0, 4) == 0:
+        # clusters of distinct, adjacent values: a few levels, each sample a few ulps off its level
+        lev = (np.round(x.astype(np.float64) * 2.0) / 2.0).astype(dtype)
+        it = np.int32 if dtype == np.float32 else np.int64
+        x = (lev.view(it) + rng.integers(-3, 4, size=x.shape).astype(it)).view(dtype)
+        x = np.where(np.isfinite(x), x, dtype(1.0)).astype(dtype)
     nanfrac = rng.choice([0.0, 0.0, 0.02, 0.3, 0.9])
     if nanfrac:
         x[rng.random((T, C)) < nanfrac] = np.nan

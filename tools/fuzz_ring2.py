@@ -78,12 +78,22 @@ def random_ring2_case(rng):
         x[rng.integers(0, T, 5), rng.integers(0, C, 5)] = -np.inf
     elif hazard == 3:
         x[:, rng.integers(0, C)] = 4.25                            # a constant cell: every key ties
+    elif hazard == 4:
+        # clusters: a few levels, each sample a few float32 ulps off its level (distinct but adjacent keys)
+        lev = np.round(x.astype(np.float64) * 2.0) / 2.0
+        x = (lev.astype(np.float32).view(np.int32) + rng.integers(-3, 4, size=x.shape).astype(np.int32)).view(np.float32)
+        x = np.where(np.isfinite(x), x, np.float32(1.0)).astype(np.float32)
     pct = float(rng.choice([0, 1, 10, 50, 75, 90, 90, 90, 95, 99, 100]))
     return x, doy, pct, tstep, bool(rng.integers(0, 2)), int(rng.integers(0, 4))
 
 
 def check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks, msg=""):
     t0, s0, _ = _raw(dev, x, doy, pct / 100.0, cold, kernel="generic")
+    # the round-1 float32 ring kernel (what other windows and longer records still run on) rides along
+    tr, sr, _ = _raw(dev, x, doy, pct / 100.0, cold, nchunks, ring2=-1)
+    with np.errstate(invalid="ignore"):
+        npt.assert_array_equal(tr, t0, err_msg=f"{msg} round-1 ring")
+        npt.assert_allclose(sr, s0, rtol=1e-12, atol=1e-300, equal_nan=True, err_msg=f"{msg} round-1 ring")
     seen = set()
     for v in (None, 0, 7, 8, 10):
         plan = dev.Plan(doy, 5, ring2=v)
