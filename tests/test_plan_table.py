@@ -116,9 +116,10 @@ def test_ring2_layout_choice():
     assert years(49).ring2_in_use() == -1                     # beyond: round-1 kernel (16 lanes per cell)
     assert years(8).ring2_in_use() == -1                      # 8 tracks or fewer: round-1 kernel
     assert years(40, w=3).ring2_in_use() == -1                # other windows: round-1 kernel
-    # genuinely float64 samples: the 64-bit mode's layout (8 lanes up to 4 tracks per lane, else 16 lanes)
+    # genuinely float64 samples: the 64-bit mode's layout (8 lanes per cell for 9..48 tracks -- low words in
+    # registers or in LDS -- 16 lanes for shorter records)
     assert years(30).f64_mode() == 8 and years(20).f64_mode() == 8 and years(12).f64_mode() == 8
-    assert years(40).f64_mode() == 12 and years(43).f64_mode() == 12 and years(5).f64_mode() == 12
+    assert years(40).f64_mode() == 8 and years(43).f64_mode() == 8 and years(5).f64_mode() == 12
     assert years(49).f64_mode() == -1 and years(40, w=3).f64_mode() == -1        # generic kernel
     with pytest.raises(Exception):
         years(40, ring2=13)

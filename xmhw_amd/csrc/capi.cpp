@@ -104,9 +104,10 @@ X64Choice x64_choice(const xmhw_plan* p) {
     static const bool on = [] { const char* v = std::getenv("XMHW_RING2_F64"); return !(v && v[0] == '0'); }();
     X64Choice c;
     if (!on || p->ring2_variant == -1) return c;
-    // 8 lanes per cell as long as a lane holds at most 4 tracks (9..32 tracks) ...
+    // 8 lanes per cell: low words in registers up to 4 tracks per lane (9..32 tracks), in LDS at 5 and 6 (33..48) ...
     const int32_t y8 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 8);
-    if (y8 > 0 && y8 <= 4 && xmhw::ring2_x64_supported(p->host.w, y8, 8)) {
+    static const bool lds_on = [] { const char* v = std::getenv("XMHW_RING2_F64_LDS"); return !(v && v[0] == '0'); }();
+    if (y8 > 0 && (y8 <= 4 || lds_on) && xmhw::ring2_x64_supported(p->host.w, y8, 8)) {
         c.variant = 8;
         c.yps = y8;
         return c;

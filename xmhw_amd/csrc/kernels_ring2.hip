@@ -309,16 +309,20 @@ constexpr int kBudget2 = 6;
 // words (a tie of high words -- two distinct doubles within 2^-20 relative of each other at the target
 // rank, or repeated values -- is settled there by successive minima of the low words).  `narrow_flag` is
 // then the RUN flag: the kernel is queued behind the narrowing one and returns unless that one gave up.
-template <int W, int YPS, int PB, int JX, int JMX, int SUBS, bool STATS, typename TI = float, bool X64 = false>
+template <int W, int YPS, int PB, int JX, int JMX, int SUBS, bool STATS, typename TI = float, int X64 = 0>
 __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     const TI* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, int32_t step_min, const DevChunk* __restrict__ chunks, double q,
     int negate, int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
     unsigned long long* __restrict__ stats, uint32_t* __restrict__ narrow_flag) {
     static_assert(W == 5, "count_le11 is written for an 11-sample window");
-    static_assert(!X64 || (sizeof(TI) == 8 && PB == 0), "the 64-bit mode takes double input and no code ring");
-    constexpr bool kX64 = X64;
-    constexpr bool kNarrow = sizeof(TI) == 8 && !X64;
+    static_assert(X64 == 0 || (sizeof(TI) == 8 && PB == 0), "the 64-bit mode takes double input and no code ring");
+    constexpr bool kX64 = X64 != 0;
+    // X64 == 2: the low words live in LDS (one column of NK words per thread, conflict-free) instead of a
+    // second set of register tuples -- for plans whose two rings would not fit the register file (5 and
+    // 6 tracks per lane at 8 lanes per cell), at the price of 2 workgroups per CU
+    constexpr bool kLoLds = X64 == 2;
+    constexpr bool kNarrow = sizeof(TI) == 8 && X64 == 0;
     if constexpr (kNarrow) {
         if (*narrow_flag != 0) return;           // the probe (or another workgroup) already found a lossy sample
     }
@@ -368,9 +372,19 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
     RingT ring[YPS];
 #pragma unroll
     for (int y = 0; y < YPS; ++y) ring[y] = kInv;
-    RingT ringlo[kX64 ? YPS : 1];     // X64: low words of the keys, slot for slot
+    RingT ringlo[(kX64 && !kLoLds) ? YPS : 1];     // X64: low words of the keys, slot for slot (register version)
 #pragma unroll
-    for (int y = 0; y < (kX64 ? YPS : 1); ++y) ringlo[y] = kInv;
+    for (int y = 0; y < ((kX64 && !kLoLds) ? YPS : 1); ++y) ringlo[y] = kInv;
+    __shared__ uint32_t lo_lds[kLoLds ? YPS * R * 256 : 1];
+    uint32_t* const lo_col = lo_lds + threadIdx.x;               // slot (y, k) of this thread: lo_col[(y * R + k) * 256]
+    if constexpr (kLoLds) {
+#pragma unroll
+        for (int i = 0; i < YPS * R; ++i) lo_col[i * 256] = kInv;
+    }
+    auto lo_at = [&](int y, int k) -> uint32_t {                 // static slot
+        if constexpr (kLoLds) return lo_col[(y * R + k) * 256];
+        else return ringlo[y][k];
+    };
     double lsum = 0.0;        // sum of the valid samples in this lane's rings (all tracks)
     uint32_t nval = 0;        // number of valid keys in this lane's rings (all tracks)
 
@@ -523,7 +537,10 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
         for (int y = 0; y < YPS; ++y) kout[y] = ring[y][m];
         if constexpr (kX64) {
 #pragma unroll
-            for (int y = 0; y < YPS; ++y) kout_lo[y] = ringlo[y][m];
+            for (int y = 0; y < YPS; ++y) {
+                if constexpr (kLoLds) kout_lo[y] = lo_col[(y * R + m) * 256];
+                else kout_lo[y] = ringlo[y][m];
+            }
         }
         if (wave_hold) {
 #pragma unroll
@@ -536,7 +553,10 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
         for (int y = 0; y < YPS; ++y) ring[y][m] = kin[y];
         if constexpr (kX64) {
 #pragma unroll
-            for (int y = 0; y < YPS; ++y) ringlo[y][m] = kin_lo[y];
+            for (int y = 0; y < YPS; ++y) {
+                if constexpr (kLoLds) lo_col[(y * R + m) * 256] = kin_lo[y];
+                else ringlo[y][m] = kin_lo[y];
+            }
         }
         uint32_t dF = 0;
         if (fast) {
@@ -636,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                     for (int k = 0; k < R; ++k) {
                         const uint32_t key = opaque(ring[y][k]);
                         cy += key != kInv ? 1u : 0u;
-                        if constexpr (kX64) ty += value_of_key64(key, opaque(ringlo[y][k]));
+                        if constexpr (kX64) ty += value_of_key64(key, opaque(lo_at(y, k)));
                         else ty += value_of_key(key);
                     }
                     const bool cnt = (cmask >> y) & 1u;
@@ -655,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                     double ty = 0.0;
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
-                        if constexpr (kX64) ty += value_of_key64(opaque(ring[y][k]), opaque(ringlo[y][k]));
+                        if constexpr (kX64) ty += value_of_key64(opaque(ring[y][k]), opaque(lo_at(y, k)));
                         else ty += value_of_key(opaque(ring[y][k]));
                     }
                     t += ty;
@@ -982,13 +1002,15 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                     const bool cnt = wallc || ((cmask >> y) & 1u);
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
-                        const uint32_t key = ring[y][k], l = ringlo[y][k];
+                        const uint32_t key = ring[y][k], l = lo_at(y, k);
                         const bool ea = cnt && key == alo, eb = cnt && key == ahi;
                         ca += ea ? 1u : 0u;
                         cb += eb ? 1u : 0u;
                         la = ea ? l : la;
                         lb = eb ? l : lb;
                     }
+                    // (LDS version: one track's 11 reads in flight at a time, not all of the lane's at once)
+                    if constexpr (kLoLds) asm volatile("" ::: "memory");
                 }
                 ca = cell_sum<SUBS>(ca);
                 cb = cell_sum<SUBS>(cb);
@@ -1016,7 +1038,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                                 const bool cnt = wallc || ((cmask >> y) & 1u);
 #pragma unroll
                                 for (int k = 0; k < R; ++k) {
-                                    const uint32_t key = opaque(ring[y][k]), l = opaque(ringlo[y][k]);
+                                    const uint32_t key = opaque(ring[y][k]), l = opaque(lo_at(y, k));
                                     const bool in = cnt && key == H && (!have_prev || l > prev);
                                     mn = in ? minu(mn, l) : mn;
                                 }
@@ -1028,7 +1050,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                                 const bool cnt = wallc || ((cmask >> y) & 1u);
 #pragma unroll
                                 for (int k = 0; k < R; ++k)
-                                    c += (cnt && opaque(ring[y][k]) == H && opaque(ringlo[y][k]) == mn) ? 1u : 0u;
+                                    c += (cnt && opaque(ring[y][k]) == H && opaque(lo_at(y, k)) == mn) ? 1u : 0u;
                             }
                             c = cell_sum<SUBS>(c);
                             if (open) {
@@ -1116,7 +1138,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
             uint32_t e0 = ring[y][0];
             ring_sel(e0, last, hy);
             ring[y][0] = e0;
-            if constexpr (kX64) {
+            if constexpr (kX64 && !kLoLds) {
                 const uint32_t last_lo = opaque(ringlo[y][R - 1]);
 #pragma unroll
                 for (int k = R - 1; k >= 1; --k) {
@@ -1127,6 +1149,15 @@ __global__ __launch_bounds__(256, 2) void clim_ring2_f32(
                 uint32_t l0 = ringlo[y][0];
                 ring_sel(l0, last_lo, hy);
                 ringlo[y][0] = l0;
+            }
+            if constexpr (kLoLds) {
+                if ((hmask >> y) & 1u) {         // (per lane: only the holding tracks' columns move)
+                    uint32_t t[R];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) t[k] = lo_col[(y * R + k) * 256];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) lo_col[(y * R + k) * 256] = t[(k + R - 1) % R];
+                }
             }
         }
         have_code = 0;         // byte positions moved: rebuild the code ring
@@ -1176,26 +1207,31 @@ struct Ring2Entry { int w, yps, subs, variant; Ring2Kernel fn, fn_stats; Ring2Ke
 // 64-bit mode (high / low key words) for genuinely float64 samples
 #define XMHW_R2N(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>, \
                                           clim_ring2_f32<W, Y, PB, JX, JM, S, false, double>,             \
-                                          clim_ring2_f32<W, Y, PB, JX, JM, S, false, double, true>}
+                                          clim_ring2_f32<W, Y, PB, JX, JM, S, false, double, 1>}
 // (narrowing only: the 64-bit mode would spill heavily at 66 or more keys per lane; those plans keep the
 // round-1 float64 kernel)
 #define XMHW_R2M(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>, \
                                           clim_ring2_f32<W, Y, PB, JX, JM, S, false, double>, nullptr}
 // 16 lanes per cell, 64-bit mode only (variant 12): genuinely float64 samples of plans with more keys per lane
 // than the 8- and 4-lane layouts can hold in registers next to the low words, and of short records
-#define XMHW_R2X(W, Y, S, V, PB, JX, JM) {W, Y, S, V, nullptr, nullptr, nullptr, clim_ring2_f32<W, Y, PB, JX, JM, S, false, double, true>}
+#define XMHW_R2X(W, Y, S, V, PB, JX, JM) {W, Y, S, V, nullptr, nullptr, nullptr, clim_ring2_f32<W, Y, PB, JX, JM, S, false, double, 1>}
+// narrowing + the 64-bit mode with the low words in LDS (5 and 6 tracks per lane at 8 lanes per cell)
+#define XMHW_R2L(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>, \
+                                          clim_ring2_f32<W, Y, PB, JX, JM, S, false, double>,             \
+                                          clim_ring2_f32<W, Y, PB, JX, JM, S, false, double, 2>}
 #define XMHW_R2(W, Y) XMHW_R2V(W, Y, 8, 0, 0, 5, 5), XMHW_R2V(W, Y, 8, 1, 8, 5, 5), XMHW_R2V(W, Y, 8, 2, 16, 5, 5), \
                       XMHW_R2V(W, Y, 8, 3, 16, 4, 4), XMHW_R2V(W, Y, 8, 4, 16, 3, 3), XMHW_R2V(W, Y, 8, 5, 0, 4, 4), \
-                      XMHW_R2V(W, Y, 8, 6, 0, 6, 6), XMHW_R2N(W, Y, 8, 8, 0, 5, 8)
+                      XMHW_R2V(W, Y, 8, 6, 0, 6, 6)
 const Ring2Entry kRing2[] = {
     XMHW_R2(5, 3), XMHW_R2(5, 4), XMHW_R2(5, 5),
+    XMHW_R2L(5, 3, 8, 8, 0, 5, 8), XMHW_R2N(5, 4, 8, 8, 0, 5, 8), XMHW_R2L(5, 5, 8, 8, 0, 5, 8),
     XMHW_R2V(5, 5, 4, 7, 0, 5, 5), XMHW_R2V(5, 8, 4, 7, 0, 5, 5), XMHW_R2V(5, 10, 4, 7, 0, 5, 5),
     XMHW_R2V(5, 5, 4, 9, 0, 5, 8), XMHW_R2V(5, 8, 4, 9, 0, 5, 8), XMHW_R2V(5, 10, 4, 9, 0, 5, 8),
     XMHW_R2N(5, 5, 4, 10, 0, 5, 7), XMHW_R2M(5, 8, 4, 10, 0, 5, 7), XMHW_R2M(5, 10, 4, 10, 0, 5, 7),
     XMHW_R2V(5, 5, 4, 11, 0, 5, 6), XMHW_R2V(5, 8, 4, 11, 0, 5, 6), XMHW_R2V(5, 10, 4, 11, 0, 5, 6),
     // shorter and longer records (9..16 and 41..48 tracks: 10-year series, OISST 1982-today), shipped layouts
     // and their plain counterparts only
-    XMHW_R2V(5, 2, 8, 0, 0, 5, 5), XMHW_R2N(5, 2, 8, 8, 0, 5, 8), XMHW_R2V(5, 6, 8, 0, 0, 5, 5), XMHW_R2M(5, 6, 8, 8, 0, 5, 8),
+    XMHW_R2V(5, 2, 8, 0, 0, 5, 5), XMHW_R2N(5, 2, 8, 8, 0, 5, 8), XMHW_R2V(5, 6, 8, 0, 0, 5, 5), XMHW_R2L(5, 6, 8, 8, 0, 5, 8),
     XMHW_R2V(5, 3, 4, 7, 0, 5, 5), XMHW_R2N(5, 3, 4, 10, 0, 5, 7), XMHW_R2V(5, 4, 4, 7, 0, 5, 5), XMHW_R2N(5, 4, 4, 10, 0, 5, 7),
     XMHW_R2X(5, 1, 16, 12, 0, 5, 8), XMHW_R2X(5, 2, 16, 12, 0, 5, 8), XMHW_R2X(5, 3, 16, 12, 0, 5, 8),
 };
@@ -1204,6 +1240,7 @@ const Ring2Entry kRing2[] = {
 #undef XMHW_R2N
 #undef XMHW_R2M
 #undef XMHW_R2X
+#undef XMHW_R2L
 const Ring2Entry* find_ring2(int32_t w, int32_t yps, int32_t subs, int32_t variant) {
     for (const auto& e : kRing2)
         if (e.w == w && e.yps == yps && e.subs == subs && e.variant == variant) return &e;
