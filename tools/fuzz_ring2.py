@@ -40,10 +40,10 @@ def _raw(dev, x, doy, q, negate, nchunks=0, kernel="ring", ring2=-1, narrowing=T
         plan.destroy()
 
 
-def random_ring2_case(rng):
+def random_ring2_case(rng, years=(9, 49)):
     """a random plan inside ring2's instantiations (w = 5, 9..48 tracks) with random data hazards"""
     kind = rng.choice(["daily", "daily_partial", "tstep", "tstep_short"])
-    ny = int(rng.integers(9, 49))
+    ny = int(rng.integers(years[0], years[1]))
     if kind in ("tstep", "tstep_short"):
         n = int(rng.integers(12, 90)) if kind == "tstep" else int(rng.integers(12, 20))
         doy = np.tile(np.arange(1, n + 1), ny)
@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--cases", type=int, default=400)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--long", action="store_true", help="records of 49..120 years: the 16- and 32-lane round-1 float32 rings")
     args = ap.parse_args()
     from xmhw_amd._lib import require_gpu
     require_gpu()
@@ -167,7 +168,7 @@ def main():
         return
     layouts = {0: 0, 7: 0, 8: 0, 10: 0}
     for i in range(args.cases):
-        x, doy, pct, tstep, cold, nchunks = random_ring2_case(rng)
+        x, doy, pct, tstep, cold, nchunks = random_ring2_case(rng, (49, 121) if args.long else (9, 49))
         seen = check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks,
                                 msg=f"seed {args.seed} case {i}: T={x.shape[0]} C={x.shape[1]} pct={pct} tstep={tstep} cold={cold}")
         for v in seen:
