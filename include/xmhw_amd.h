@@ -141,13 +141,14 @@ int xmhw_plan_table(const xmhw_plan *plan, int32_t years_per_lane, uint32_t *tab
  * enable != 0 allocates the counters; out8 receives 8 values                          */
 int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out8);
 
-/* second-generation float32 ring kernel (w = 5, 9..48 tracks; xmhw_amd/csrc/kernels_ring2.hip),
+/* second-generation float32 ring kernel (w = 5, 9..96 tracks; xmhw_amd/csrc/kernels_ring2.hip),
  * used by default where it is instantiated.  variant: -2 = auto (the default: 8, or 10 where the
  * 4-lane layout pads fewer tracks, e.g. 20 tracks), -1 = off (round-1 kernel), 0 = 8 lanes per
  * cell with 32-bit count passes and a 5-key extraction list, 7 = the same with 4 lanes per cell,
  * 8 / 10 = 0 / 7 with the lanes' lists merged into the cell's 8 / 7 nearest keys (a wider window of
  * acceptable ranks: fewer count passes), 1..6, 9, 11 = measured alternatives kept for the record
- * (8/16-bit code rings, other list widths).  The environment variable XMHW_RING2 sets the default
+ * (8/16-bit code rings, other list widths), 12 = 16 lanes per cell (49..96 tracks).  The environment
+ * variable XMHW_RING2 sets the default
  * of new plans.  All variants return bit-identical thresh.                                       */
 int xmhw_plan_set_ring2(xmhw_plan *plan, int32_t variant);
 /* the variant float32 input of this plan will run on, -1 if the round-1 / generic kernel */

@@ -113,7 +113,9 @@ def test_ring2_layout_choice():
     assert years(10).ring2_in_use() == 10                     # 10 tracks: 4 x 3 = 12 slots against 8 x 2 = 16
     assert years(16).ring2_in_use() == 8                      # 16 tracks: 8 x 2 = 4 x 4 exactly: a tie goes to 8 lanes
     assert years(43).ring2_in_use() == 8                      # 41..48 tracks (OISST 1982-2024): 8 x 6
-    assert years(49).ring2_in_use() == -1                     # beyond: round-1 kernel (16 lanes per cell)
+    assert years(49).ring2_in_use() == 12 and years(96).ring2_in_use() == 12   # 49..96 tracks: 16 lanes per cell
+    assert years(97).ring2_in_use() == -1                     # beyond: round-1 kernel (32 lanes per cell)
+    assert years(40, ring2=12).ring2_in_use() == -1           # (that layout's short-record entries are float64-only)
     assert years(8).ring2_in_use() == -1                      # 8 tracks or fewer: round-1 kernel
     assert years(40, w=3).ring2_in_use() == -1                # other windows: round-1 kernel
     # genuinely float64 samples: the 64-bit mode's layout (8 lanes per cell for 9..48 tracks -- low words in
@@ -122,7 +124,7 @@ def test_ring2_layout_choice():
     assert years(40).f64_mode() == 8 and years(43).f64_mode() == 8 and years(5).f64_mode() == 12
     assert years(49).f64_mode() == -1 and years(40, w=3).f64_mode() == -1        # generic kernel
     with pytest.raises(Exception):
-        years(40, ring2=13)
+        years(40, ring2=14)
 
 
 def test_bad_arguments():

@@ -95,7 +95,7 @@ def check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks, msg=""):
         npt.assert_array_equal(tr, t0, err_msg=f"{msg} round-1 ring")
         npt.assert_allclose(sr, s0, rtol=1e-12, atol=1e-300, equal_nan=True, err_msg=f"{msg} round-1 ring")
     seen = set()
-    for v in (None, 0, 7, 8, 10):
+    for v in (None, 0, 7, 8, 10, 12):
         plan = dev.Plan(doy, 5, ring2=v)
         use = plan.ring2_in_use()
         plan.destroy()
@@ -172,7 +172,7 @@ def main():
         seen = check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks,
                                 msg=f"seed {args.seed} case {i}: T={x.shape[0]} C={x.shape[1]} pct={pct} tstep={tstep} cold={cold}")
         for v in seen:
-            layouts[v] += 1
+            layouts[v] = layouts.get(v, 0) + 1
     print(f"{args.cases} random cases, runs per layout {layouts}: 0 mismatches against the generic kernel "
           f"({time.perf_counter() - t0:.0f} s)")
 

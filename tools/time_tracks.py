@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 import xmhw_amd.device as dev
 from xmhw_amd.calendar import add_doy
 h = dev.hip()
-for y0, y1, C in ((1982, 2024, 518400), (2010, 2021, 518400)):
+for y0, y1, C in ((1982, 2024, 518400), (2010, 2021, 518400), (1940, 2024, 259200)):
     doy = add_doy(np.arange(f"{y0}-01-01", f"{y1 + 1}-01-01", dtype="datetime64[D]"))
     T = doy.shape[0]
     ts = dev.DeviceBuffer(4 * T * C)

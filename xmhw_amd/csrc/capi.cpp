@@ -160,6 +160,7 @@ int32_t ring2_resolved(const xmhw_plan* p) {
     const int32_t y8 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 8);
     const int32_t y4 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 10);
     if (y4 && y4 <= 8 && (!y8 || y4 * 4 < y8 * 8)) return 10;
+    if (!y8 && xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 12) >= 4) return 12;     // 49..96 tracks: 16 lanes per cell
     return 8;
 }
 
@@ -253,7 +254,7 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
     hipError_t e;
     if (kernel == XMHW_KERNEL_RING) {
         if constexpr (sizeof(T) == 4) {
-            if (plan->yps2 && ring2_resolved(plan) >= 0)
+            if (plan->yps2 && ring2_resolved(plan) >= 0 && xmhw::ring2_f32_supported(h.w, plan->yps2, ring2_resolved(plan)))
                 e = xmhw::launch_ring2_f32(reinterpret_cast<const float*>(ts), C, ld, h.T, plan->d_table2, plan->d_sflags,
                                            h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps2, h.ntracks,
                                            ring2_resolved(plan), q, negate, thresh, seas, ldo, st, plan->d_stats);
@@ -927,7 +928,7 @@ int xmhw_plan_create(const int32_t* doy_host, int64_t T, int32_t window_half_wid
 }
 int xmhw_plan_set_ring2(xmhw_plan* plan, int32_t variant) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
-    if (variant < -2 || variant > 11) return fail(XMHW_ERR_INVALID, "ring2 variant must be -2 (auto), -1 (off) or 0..11");
+    if (variant < -2 || variant > 12) return fail(XMHW_ERR_INVALID, "ring2 variant must be -2 (auto), -1 (off) or 0..12");
     plan->ring2_variant = variant;
     return XMHW_OK;
 }
@@ -935,7 +936,8 @@ int xmhw_plan_ring2_in_use(const xmhw_plan* plan, int32_t* variant) {
     if (!plan || !variant) return fail(XMHW_ERR_INVALID, "NULL argument");
     const bool ring = resolve_kernel(plan, 4) == XMHW_KERNEL_RING;
     const int32_t v2 = ring2_resolved(plan);
-    *variant = (ring && v2 >= 0 && xmhw::ring2_pick_yps(plan->host.w, plan->host.ntracks, v2) > 0) ? v2 : -1;
+    const int32_t y2 = v2 >= 0 ? xmhw::ring2_pick_yps(plan->host.w, plan->host.ntracks, v2) : 0;
+    *variant = (ring && y2 > 0 && xmhw::ring2_f32_supported(plan->host.w, y2, v2)) ? v2 : -1;
     return XMHW_OK;
 }
 int xmhw_plan_f64_mode(const xmhw_plan* plan, int32_t* variant) {

@@ -35,6 +35,7 @@ hipError_t launch_ring2_f32_narrowing(const double* ts, int64_t C, int64_t ld, i
                                       int32_t nchunks, int32_t w, int32_t yps, int32_t ntracks, int32_t variant,
                                       double q, int negate, double* thresh, double* seas, int64_t ldo,
                                       hipStream_t stream, uint32_t* narrow_flag);
+bool ring2_f32_supported(int32_t w, int32_t yps, int32_t variant);         // float32 instantiation exists
 bool ring2_x64_supported(int32_t w, int32_t yps, int32_t variant);         // 64-bit (high / low key word) instantiation exists
 hipError_t launch_ring2_f64(const double* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
                             const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,

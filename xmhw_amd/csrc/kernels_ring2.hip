@@ -1202,6 +1202,8 @@ struct Ring2Entry { int w, yps, subs, variant; Ring2Kernel fn, fn_stats; Ring2Ke
 //   7: as 0 with 4 lanes per cell (16 cells per wave, twice the tracks per lane)
 //   8 / 9: as 0 / 7 with the lanes' J = 5 lists merged into the cell's 8 nearest keys (window of 7 ranks)
 //   10 / 11: as 9 with 7 / 6 merged keys (4 lanes per cell: a lane holds 5 of the cell's 8 nearest more often)
+//   12: 16 lanes per cell (4 cells per wave), wide merge: the 64-bit mode's layout for short records, and the
+//       float32 layout of 49..96-track records
 #define XMHW_R2V(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>, nullptr, nullptr}
 // the shipped layouts also exist for float64 input: narrowing to float32 where that is lossless, and the
 // 64-bit mode (high / low key words) for genuinely float64 samples
@@ -1234,6 +1236,8 @@ const Ring2Entry kRing2[] = {
     XMHW_R2V(5, 2, 8, 0, 0, 5, 5), XMHW_R2N(5, 2, 8, 8, 0, 5, 8), XMHW_R2V(5, 6, 8, 0, 0, 5, 5), XMHW_R2L(5, 6, 8, 8, 0, 5, 8),
     XMHW_R2V(5, 3, 4, 7, 0, 5, 5), XMHW_R2N(5, 3, 4, 10, 0, 5, 7), XMHW_R2V(5, 4, 4, 7, 0, 5, 5), XMHW_R2N(5, 4, 4, 10, 0, 5, 7),
     XMHW_R2X(5, 1, 16, 12, 0, 5, 8), XMHW_R2X(5, 2, 16, 12, 0, 5, 8), XMHW_R2X(5, 3, 16, 12, 0, 5, 8),
+    // long records (49..96 tracks: reanalyses, model runs) on 16 lanes per cell: float32 and narrowing float64
+    XMHW_R2M(5, 4, 16, 12, 0, 5, 8), XMHW_R2M(5, 5, 16, 12, 0, 5, 8), XMHW_R2M(5, 6, 16, 12, 0, 5, 8),
 };
 #undef XMHW_R2
 #undef XMHW_R2V
@@ -1276,6 +1280,11 @@ hipError_t launch_ring2_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
     hipLaunchKernelGGL(stats ? e->fn_stats : e->fn, grid, dim3(64 * kWaves2), 0, stream, ts, C, ld, Tn, table, sflags, step_min,
                        chunks, q, negate, ntracks, thresh, seas, ldo, stats, static_cast<uint32_t*>(nullptr));
     return hipGetLastError();
+}
+
+bool ring2_f32_supported(int32_t w, int32_t yps, int32_t variant) {
+    const Ring2Entry* e = find_ring2(w, yps, ring2_subs(variant), variant);
+    return e != nullptr && e->fn != nullptr;
 }
 
 bool ring2_x64_supported(int32_t w, int32_t yps, int32_t variant) {
