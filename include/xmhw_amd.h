@@ -156,7 +156,7 @@ int xmhw_plan_ring2_in_use(const xmhw_plan *plan, int32_t *variant);
 /* genuinely float64 samples (those that do not narrow to float32): the layout variant of the
  * second-generation kernel's 64-bit mode this plan will run on (8 / 10: the float32 layouts, 12: 16
  * lanes per cell), or -1 (generic kernel; the round-1 float64 ring only on an explicit
- * XMHW_KERNEL_RING request).  w = 5, up to 48 tracks.                                           */
+ * XMHW_KERNEL_RING request).  w = 5, up to 96 tracks.                                           */
 int xmhw_plan_f64_mode(const xmhw_plan *plan, int32_t *variant);
 
 /* ---- the hot path ------------------------------------------------------ *

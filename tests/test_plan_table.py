@@ -122,7 +122,8 @@ def test_ring2_layout_choice():
     # registers or in LDS -- 16 lanes for shorter records)
     assert years(30).f64_mode() == 8 and years(20).f64_mode() == 8 and years(12).f64_mode() == 8
     assert years(40).f64_mode() == 8 and years(43).f64_mode() == 8 and years(5).f64_mode() == 12
-    assert years(49).f64_mode() == -1 and years(40, w=3).f64_mode() == -1        # generic kernel
+    assert years(49).f64_mode() == 12 and years(96).f64_mode() == 12             # 16 lanes, low words in LDS
+    assert years(97).f64_mode() == -1 and years(40, w=3).f64_mode() == -1        # generic kernel
     with pytest.raises(Exception):
         years(40, ring2=14)
 

@@ -110,11 +110,11 @@ def check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks, msg=""):
     return seen
 
 
-def random_f64_case(rng):
+def random_f64_case(rng, years=(9, 49)):
     """as random_ring2_case with genuinely float64 samples: full-precision doubles, exact repeats (quantised),
     and clusters of DISTINCT doubles that share the high word of their 64-bit key (within 2^-20 relative), which
     is what the low-word pass of the 64-bit mode has to sort out"""
-    x32, doy, pct, tstep, cold, nchunks = random_ring2_case(rng)
+    x32, doy, pct, tstep, cold, nchunks = random_ring2_case(rng, years)
     x = x32.astype(np.float64)
     T, C = x.shape
     mode = rng.integers(0, 4)
@@ -161,7 +161,7 @@ def main():
     t0 = time.perf_counter()
     if args.dtype == "f64":
         for i in range(args.cases):
-            x, doy, pct, tstep, cold, nchunks = random_f64_case(rng)
+            x, doy, pct, tstep, cold, nchunks = random_f64_case(rng, (49, 121) if args.long else (9, 49))
             check_f64_case(dev, x, doy, pct, tstep, cold, nchunks,
                            msg=f"seed {args.seed} case {i}: T={x.shape[0]} C={x.shape[1]} pct={pct} tstep={tstep} cold={cold}")
         print(f"{args.cases} random float64 cases: 0 mismatches against the generic kernel ({time.perf_counter() - t0:.0f} s)")

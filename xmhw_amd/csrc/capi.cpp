@@ -114,8 +114,10 @@ X64Choice x64_choice(const xmhw_plan* p) {
     }
     // ... 16 lanes per cell for longer and for very short records (the table of the 16-lane rings)
     const int32_t y16 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 12);
+    // (its table: the 16-lane rings' one up to 3 tracks per lane, the plan's own ring2 table beyond -- there the
+    // float32 layout is the same 16 lanes)
     if (y16 > 0 && xmhw::ring2_x64_supported(p->host.w, y16, 12) &&
-        y16 == xmhw::ring64_pick_yps(p->host.w, p->host.ntracks)) {
+        (y16 <= 3 ? y16 == xmhw::ring64_pick_yps(p->host.w, p->host.ntracks) : ring2_resolved(p) == 12)) {
         c.variant = 12;
         c.yps = y16;
     }
@@ -294,7 +296,7 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
                 const X64Choice xc = x64_choice(plan);
                 if (xc.variant >= 0)
                     e = xmhw::launch_ring2_f64(reinterpret_cast<const double*>(ts), C, ld, h.T,
-                                               xc.variant == 12 ? plan->d_table64
+                                               xc.variant == 12 ? ((plan->subs2 == 16 && plan->yps2 == xc.yps) ? plan->d_table2 : plan->d_table64)
                                                : (plan->subs2 == 8 && plan->yps2 == xc.yps) ? plan->d_table2 : plan->d_tablex,
                                                plan->d_sflags,
                                                h.step_min, plan->d_chunks, plan->nchunks, h.w, xc.yps, h.ntracks, xc.variant,

@@ -1236,8 +1236,9 @@ const Ring2Entry kRing2[] = {
     XMHW_R2V(5, 2, 8, 0, 0, 5, 5), XMHW_R2N(5, 2, 8, 8, 0, 5, 8), XMHW_R2V(5, 6, 8, 0, 0, 5, 5), XMHW_R2L(5, 6, 8, 8, 0, 5, 8),
     XMHW_R2V(5, 3, 4, 7, 0, 5, 5), XMHW_R2N(5, 3, 4, 10, 0, 5, 7), XMHW_R2V(5, 4, 4, 7, 0, 5, 5), XMHW_R2N(5, 4, 4, 10, 0, 5, 7),
     XMHW_R2X(5, 1, 16, 12, 0, 5, 8), XMHW_R2X(5, 2, 16, 12, 0, 5, 8), XMHW_R2X(5, 3, 16, 12, 0, 5, 8),
-    // long records (49..96 tracks: reanalyses, model runs) on 16 lanes per cell: float32 and narrowing float64
-    XMHW_R2M(5, 4, 16, 12, 0, 5, 8), XMHW_R2M(5, 5, 16, 12, 0, 5, 8), XMHW_R2M(5, 6, 16, 12, 0, 5, 8),
+    // long records (49..96 tracks: reanalyses, model runs) on 16 lanes per cell: float32, narrowing float64 and the
+    // 64-bit mode with its low words in LDS
+    XMHW_R2L(5, 4, 16, 12, 0, 5, 8), XMHW_R2L(5, 5, 16, 12, 0, 5, 8), XMHW_R2L(5, 6, 16, 12, 0, 5, 8),
 };
 #undef XMHW_R2
 #undef XMHW_R2V
