@@ -158,8 +158,8 @@ def test_float64_narrowing(dev):
 
 
 def test_long_float64_record_narrows_onto_the_16_lane_ring(dev):
-    """61 years as float64: no float64 ring covers it; float32-representable samples still take the
-    float32 ring (16 lanes per cell), genuine float64 samples end on the generic kernel."""
+    """61 years as float64: float32-representable samples take the float32 kernel (16 lanes per cell),
+    genuine float64 samples the 64-bit mode on the same layout; both against the generic kernel."""
     from xmhw_amd.device import DeviceBuffer, Plan, clim_raw
     from xmhw_amd._lib import hip
     h = hip()
@@ -190,7 +190,9 @@ def test_long_float64_record_narrows_onto_the_16_lane_ring(dev):
     assert not narrowed
     tg, sg, _ = run(rand, kernel="generic")
     npt.assert_array_equal(tr, tg)
-    npt.assert_array_equal(sr, sg)
+    # (since round 2 such a record runs on the second-generation kernel's 64-bit mode, 16 lanes per cell: the
+    # percentile is exact, the mean a running float64 sum -- equal to the generic kernel's up to rounding)
+    npt.assert_allclose(sr, sg, rtol=1e-12, atol=1e-12)
 
 
 @pytest.mark.parametrize("seed", [61, 62])
