@@ -134,12 +134,12 @@ def random_f64_case(rng, years=(9, 49)):
     return x, doy, pct, tstep, cold, nchunks
 
 
-def check_f64_case(dev, x, doy, pct, tstep, cold, nchunks, msg=""):
+def check_f64_case(dev, x, doy, pct, tstep, cold, nchunks, msg="", kernel="auto"):
     """the float64 path as the library takes it (narrowing probe -> ring2 narrowing -> ring2 64-bit mode or the
     round-1 float64 ring) against the generic float64 kernel: raw percentile bit for bit"""
     t0, s0, _ = _raw(dev, x, doy, pct / 100.0, cold, kernel="generic")
     for narrowing in (True, False):
-        t1, s1, _ = _raw(dev, x, doy, pct / 100.0, cold, nchunks, kernel="auto", ring2=None, narrowing=narrowing)
+        t1, s1, _ = _raw(dev, x, doy, pct / 100.0, cold, nchunks, kernel=kernel, ring2=None, narrowing=narrowing)
         with np.errstate(invalid="ignore"):
             npt.assert_array_equal(t1, t0, err_msg=f"{msg} narrowing={narrowing}")
             # (float64 sums are not exact: a running sum and a direct one differ by rounding, which shows
@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--cases", type=int, default=400)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--kernel", default="auto", help="f64 mode: 'ring' with XMHW_RING2_F64=0 exercises the round-1 float64 ring")
     ap.add_argument("--long", action="store_true", help="records of 49..120 years: the 16- and 32-lane round-1 float32 rings")
     args = ap.parse_args()
     from xmhw_amd._lib import require_gpu
@@ -162,7 +163,7 @@ def main():
     if args.dtype == "f64":
         for i in range(args.cases):
             x, doy, pct, tstep, cold, nchunks = random_f64_case(rng, (49, 121) if args.long else (9, 49))
-            check_f64_case(dev, x, doy, pct, tstep, cold, nchunks,
+            check_f64_case(dev, x, doy, pct, tstep, cold, nchunks, kernel=args.kernel,
                            msg=f"seed {args.seed} case {i}: T={x.shape[0]} C={x.shape[1]} pct={pct} tstep={tstep} cold={cold}")
         print(f"{args.cases} random float64 cases: 0 mismatches against the generic kernel ({time.perf_counter() - t0:.0f} s)")
         return

@@ -211,6 +211,10 @@ __global__ __launch_bounds__(256) void clim_ring_f64(
             all_counted &= counted[y];
             double xv = x_cur[y];
             if (negate) xv = -xv;
+            // one zero only: this kernel compares samples as doubles (-0.0 == +0.0) but brackets in key space
+            // (-0.0 < +0.0); with both zeros in a pool the two disagree about counts.  -0.0 + 0.0 = +0.0.
+            // (The second-generation kernel compares keys throughout and keeps both.)
+            xv = xv + 0.0;
             xin[y] = xv;
         }
 #define XMHW_RING_CASE(K)                                                  \
