@@ -137,9 +137,11 @@ int xmhw_plan_table(const xmhw_plan *plan, int32_t years_per_lane, uint32_t *tab
 
 /* debug: ring-kernel pass counters {rows, 32-bit count passes, extractions, cold starts,
  * fast steps, 8-bit probes, code-ring rebuilds} per wave, then count passes summed over CELLS (what
- * each cell needed on its own); all summed since the last read;
- * enable != 0 allocates the counters; out8 receives 8 values                          */
-int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out8);
+ * each cell needed on its own); all summed since the last read; the third-generation kernel
+ * (variants 20, 21) reports its band-path counters in slots 5..7 (csrc/kernels_ring3.hip) and
+ * shader-clock ticks per section of its row loop in slots 8..15;
+ * enable != 0 allocates the counters; out16 receives 16 values                        */
+int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out16);
 
 /* second-generation float32 ring kernel (w = 5, 9..96 tracks; xmhw_amd/csrc/kernels_ring2.hip),
  * used by default where it is instantiated.  variant: -2 = auto (the default: 8, or 10 where the

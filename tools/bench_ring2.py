@@ -57,6 +57,20 @@ def main():
         st_raw = h.plan_debug_stats(plan.handle, 1, True)
         st = st_raw.astype(np.float64)
         hist = None
+        ring3 = None
+        if v >= 20:        # third-generation kernel: slots 5 and 6 carry the band-path counters
+            a, b = int(st_raw[5]), int(st_raw[6])
+            ring3 = {"wave_rows_band_only": (a & 0xFFFFFFFF) / max(float(st_raw[0]), 1.0),
+                     "rebuilds_per_wave_row": (a >> 32) / max(float(st_raw[0]), 1.0),
+                     "cell_rows_tried": b & 0xFFFFFFFF, "cell_rows_failed": b >> 32,
+                     "cell_fail_rate": (b >> 32) / max(b & 0xFFFFFFFF, 1),
+                     "failed_off_block": int(st_raw[7]) & 0xFFFFFFFF, "failed_band_too_big": int(st_raw[7]) >> 32,
+                     "hist_mismatch": int(st_raw[3]) >> 32,
+                     # shader-clock ticks per wave-row: push+histogram, totals, walk, compaction, sort+pick, slow path,
+                     # epilogue, rebuild
+                     "ticks_per_wave_row": [round(float(x) / max(float(st_raw[0]), 1.0), 1) for x in st_raw[8:16]]}
+            st[3] = float(int(st_raw[3]) & 0xFFFFFFFF)
+            st[5] = st[6] = st[7] = 0.0
         if v in (0, 5, 6, 7, 8, 9, 10, 11):   # no code ring: slots 5 and 6 hold the per-cell histogram of count passes
             a, b = int(st_raw[5]), int(st_raw[6])
             hist = [a & 0xFFFFFFFF, a >> 32, b & 0xFFFFFFFF, b >> 32]
@@ -81,6 +95,7 @@ def main():
                           # what a cell needs on its own (the wave runs the maximum over its 8 or 16 cells)
                           "count_passes_per_cell_row": st[7] / (float(C) * D * args.reps),
                           "cell_rows_needing_0_1_2_3plus_passes": None if hist is None else [round(x / max(sum(hist), 1), 4) for x in hist],
+                          "ring3": ring3,
                           "thresh_bit_identical_to_first": bool(np.array_equal(got, ref[0], equal_nan=True)),
                           "seas_max_rel_diff": float(np.nanmax(np.abs(got_se - ref[1]) / np.abs(ref[1])))}), flush=True)
         for b in (th, se, sub):

@@ -930,7 +930,8 @@ int xmhw_plan_create(const int32_t* doy_host, int64_t T, int32_t window_half_wid
 }
 int xmhw_plan_set_ring2(xmhw_plan* plan, int32_t variant) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
-    if (variant < -2 || variant > 12) return fail(XMHW_ERR_INVALID, "ring2 variant must be -2 (auto), -1 (off) or 0..12");
+    if (variant < -2 || (variant > 12 && variant != 20 && variant != 21))
+        return fail(XMHW_ERR_INVALID, "ring2 variant must be -2 (auto), -1 (off), 0..12, 20 or 21");
     plan->ring2_variant = variant;
     return XMHW_OK;
 }
@@ -996,14 +997,14 @@ int xmhw_plan_set_chunks(xmhw_plan* plan, int32_t nchunks) {
 int xmhw_plan_debug_stats(xmhw_plan* plan, int enable, uint64_t* out4) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
     if (enable && !plan->d_stats) {
-        HIP_TRY(hipMalloc(&plan->d_stats, 8 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(plan->d_stats, 0, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&plan->d_stats, 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(plan->d_stats, 0, 16 * sizeof(unsigned long long)));
     }
     if (out4) {
         if (!plan->d_stats) return fail(XMHW_ERR_INVALID, "stats not enabled");
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(out4, plan->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemset(plan->d_stats, 0, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemcpy(out4, plan->d_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(plan->d_stats, 0, 16 * sizeof(unsigned long long)));
     }
     return XMHW_OK;
 }

@@ -48,6 +48,16 @@ hipError_t launch_ring2_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
                             double* thresh, double* seas, int64_t ldo, hipStream_t stream,
                             unsigned long long* stats = nullptr);
 
+// third-generation float32 ring kernel (kernels_ring3.hip): per-cell histogram in LDS + band compaction;
+// 8 or 4 lanes per cell (ring2 variants 20 and 21), w = 5
+int32_t ring3_pick_yps(int32_t w, int32_t ntracks, int32_t subs);
+bool ring3_supported(int32_t w, int32_t yps, int32_t subs);
+hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
+                            const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,
+                            int32_t w, int32_t yps, int32_t subs, int32_t ntracks, double q, int negate,
+                            double* thresh, double* seas, int64_t ldo, hipStream_t stream,
+                            unsigned long long* stats = nullptr);
+
 // float64 input through the float32 ring kernel: zeroes narrow_flag, probes the series, runs the
 // kernel with samples narrowed on load; narrow_flag != 0 afterwards: some sample is not float32-
 // representable and the outputs are garbage (queue launch_ring_f64(..., run_flag = narrow_flag) behind)

@@ -1253,10 +1253,15 @@ const Ring2Entry* find_ring2(int32_t w, int32_t yps, int32_t subs, int32_t varia
 }
 }  // namespace
 
-int32_t ring2_subs(int32_t variant) { return variant == 12 ? 16 : (variant == 7 || variant >= 9) ? 4 : 8; }
+// variants 20 / 21: the third-generation kernel (kernels_ring3.hip) on 8 / 4 lanes per cell
+int32_t ring2_subs(int32_t variant) {
+    if (variant >= 20) return variant == 21 ? 4 : 8;
+    return variant == 12 ? 16 : (variant == 7 || variant >= 9) ? 4 : 8;
+}
 
 int32_t ring2_pick_yps(int32_t w, int32_t ntracks, int32_t variant) {
     const int32_t subs = ring2_subs(variant);
+    if (variant >= 20) return ring3_pick_yps(w, ntracks, subs);
     int32_t best = 0;
     for (const auto& e : kRing2)
         if (e.w == w && e.variant == (variant < 0 ? 0 : variant) && e.subs == subs && e.yps * subs >= ntracks &&
@@ -1273,6 +1278,9 @@ hipError_t launch_ring2_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
                             double* thresh, double* seas, int64_t ldo, hipStream_t stream,
                             unsigned long long* stats) {
     const int32_t subs = ring2_subs(variant);
+    if (variant >= 20)
+        return launch_ring3_f32(ts, C, ld, Tn, table, sflags, step_min, chunks, nchunks, w, yps, subs, ntracks, q, negate,
+                                thresh, seas, ldo, stream, stats);
     const Ring2Entry* e = find_ring2(w, yps, subs, variant);
     if (!e || !e->fn) return hipErrorInvalidValue;
     if (C <= 0 || nchunks <= 0) return hipSuccess;
@@ -1284,6 +1292,7 @@ hipError_t launch_ring2_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
 }
 
 bool ring2_f32_supported(int32_t w, int32_t yps, int32_t variant) {
+    if (variant >= 20) return ring3_supported(w, yps, ring2_subs(variant));
     const Ring2Entry* e = find_ring2(w, yps, ring2_subs(variant), variant);
     return e != nullptr && e->fn != nullptr;
 }

@@ -1,0 +1,1100 @@
+// kernels_ring3.hip -- third-generation float32 ring kernel (round 3): selection by BAND COMPACTION.
+//
+// The ring (R = 2w+1 samples of every owned track as order-preserving 32-bit keys in VGPRs), the step
+// table, the push logic, the running sums and the carried pivot with its exact count ("free probe")
+// are those of kernels_ring2.hip.  What changed is how the two order statistics of numpy's linear
+// quantile are found.  Round 2 closed a bracket with count passes over ALL pooled keys (2 instructions
+// per key and pass, 1.92 passes per wave-row because a wave iterates until the slowest of its cells has
+// settled) and then ran an insertion network over ALL keys (6 instructions per key): 75 % of the kernel.
+// Here, per row:
+//
+//   1. a per-cell HISTOGRAM in LDS (NB buckets of 2^shift keys around the target, one ds_add per pushed
+//      and per evicted key) mirrors the ring.  The carried pivot is the lower edge of a bucket, so the
+//      free probe gives the exact number of keys below that edge; a prefix sum over the 16 buckets next
+//      to it (one LDS read per lane, a scan over the lanes of the cell) finds the buckets B0..B1 that
+//      hold order statistics lo and lo+1, the exact count Cb of keys below B0 and the exact number m of
+//      keys inside B0..B1 -- no pass over the keys, no iteration, nothing a slow cell could hold the
+//      wave up with;
+//   2. ONE pass over the keys (v_sub, v_cmp, and under the resulting EXEC mask ds_write + v_add: three
+//      vector instructions per key) appends the m keys of the band to per-lane lists in LDS;
+//   3. the lanes of the cell read their lists back (<= CAP keys each), sort the CAP x lanes slots with a
+//      bitonic network across the lanes (DPP) and pick entries lo - Cb and lo - Cb + 1.
+//
+// Every step is exact (the histogram is an exact mirror of the ring, band edges are bucket edges in key
+// space); what can go wrong is only capacity (m > list space, more than CAP band keys in one lane: ties,
+// constant cells), the target leaving the 16 buckets looked at, or the window.  Those rows -- and rows
+// that do not pool every track (Feb 29), and the first row of a chunk -- take the round-2 selection
+// (count passes + extraction), which is kept verbatim as the slow path (a cell that overflows keeps its
+// anchor: pivot and count stay exact, so nothing has to be rebuilt for it).
+// The window is rebuilt (re-centred, bucket width re-derived) for all cells of the wave when any cell's
+// target comes near an end of its window or its band population drifts out of range.
+//
+// Lane layout: the lanes of a cell are ADJACENT (lane = cell_in_wave * SUBS + sub), so that every
+// exchange inside a cell is one quad_perm / row_half_mirror DPP operation.
+//
+// Reference semantics restated: window_roll() (identify.py:184-209),
+// calculate_thresh()/calculate_seas() without the Feb-29 step (identify.py:233-235, :263),
+// coldSpells negation (xmhw.py:153-154).
+#include "device_common.h"
+#include "kernels.h"
+#include "plan.h"
+
+namespace xmhw {
+namespace {
+
+constexpr int kWaves3 = 4;
+constexpr uint32_t kInv3 = 0xFFFFFFFFu;
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp3(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), CTRL, 0xF, 0xF, false));
+}
+// partner = lane ^ 1, ^ 2, quad mirror (^ 3), mirror inside 8 lanes (^ 7); shifts inside the 16-lane row
+constexpr int kX1 = 0xB1, kX2 = 0x4E, kX3 = 0x1B, kX7 = 0x141;
+constexpr int kShr1 = 0x111, kShr2 = 0x112, kShr4 = 0x114;
+
+template <int SUBS>
+__device__ __forceinline__ uint32_t csum(uint32_t v) {
+    v += dpp3<kX1>(v);
+    v += dpp3<kX2>(v);
+    if constexpr (SUBS == 8) v += dpp3<kX7>(v);
+    return v;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp3_f64(double v) {
+    const uint64_t b = static_cast<uint64_t>(__double_as_longlong(v));
+    const uint32_t lo = dpp3<CTRL>(static_cast<uint32_t>(b));
+    const uint32_t hi = dpp3<CTRL>(static_cast<uint32_t>(b >> 32));
+    return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
+}
+template <int SUBS>
+__device__ __forceinline__ double csum(double v) {
+    v += dpp3_f64<kX1>(v);
+    v += dpp3_f64<kX2>(v);
+    if constexpr (SUBS == 8) v += dpp3_f64<kX7>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t minu3(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t maxu3(uint32_t a, uint32_t b) { return a > b ? a : b; }
+template <int SUBS>
+__device__ __forceinline__ uint32_t cmax(uint32_t v) {
+    v = maxu3(v, dpp3<kX1>(v));
+    v = maxu3(v, dpp3<kX2>(v));
+    if constexpr (SUBS == 8) v = maxu3(v, dpp3<kX7>(v));
+    return v;
+}
+template <int SUBS>
+__device__ __forceinline__ uint32_t cmin(uint32_t v) {
+    v = minu3(v, dpp3<kX1>(v));
+    v = minu3(v, dpp3<kX2>(v));
+    if constexpr (SUBS == 8) v = minu3(v, dpp3<kX7>(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t med3u3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t ashr31_3(uint32_t v) {
+    uint32_t r;
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+// key of a non-NaN float: negmask = 0 (heat waves) or 0xFFFFFFFF (cold spells: key(-x) = ~key(x))
+__device__ __forceinline__ uint32_t key_of_bits3(uint32_t b, uint32_t negmask) {
+    return b ^ (static_cast<uint32_t>(static_cast<int32_t>(b) >> 31) | 0x80000000u) ^ negmask;
+}
+__device__ __forceinline__ uint32_t bits_of_key3(uint32_t k) { return k ^ (~ashr31_3(k) | 0x80000000u); }
+__device__ __forceinline__ double value_of_key3(uint32_t k) {   // 0 for an invalid key
+    const float f = __uint_as_float(bits_of_key3(k));
+    return k == kInv3 ? 0.0 : static_cast<double>(f);
+}
+__device__ __forceinline__ uint32_t opaque3(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ void ring_sel3(uint32_t& slot, uint32_t other, unsigned long long take_other) {
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(slot) : "v"(other), "s"(take_other));
+}
+
+// c + #{r[i] <= p}, 11 keys, hand-scheduled (see kernels_ring2.hip: count_le11)
+template <class RingT>
+__device__ __forceinline__ uint32_t count_le11_3(const RingT& r, uint32_t p, uint32_t& c, uint32_t d) {
+    unsigned long long s0, s1, s2, sd;
+    asm("v_cmp_le_u32_e64 %[s0], %[k0], %[p]\n\t"
+        "v_cmp_le_u32_e64 %[s1], %[k1], %[p]\n\t"
+        "v_cmp_le_u32_e64 %[s2], %[k2], %[p]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s0]\n\t"
+        "v_cmp_le_u32_e64 %[s0], %[k3], %[p]\n\t"
+        "v_addc_co_u32_e64 %[d], %[sd], %[d], 0, %[s1]\n\t"
+        "v_cmp_le_u32_e64 %[s1], %[k4], %[p]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s2]\n\t"
+        "v_cmp_le_u32_e64 %[s2], %[k5], %[p]\n\t"
+        "v_addc_co_u32_e64 %[d], %[sd], %[d], 0, %[s0]\n\t"
+        "v_cmp_le_u32_e64 %[s0], %[k6], %[p]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s1]\n\t"
+        "v_cmp_le_u32_e64 %[s1], %[k7], %[p]\n\t"
+        "v_addc_co_u32_e64 %[d], %[sd], %[d], 0, %[s2]\n\t"
+        "v_cmp_le_u32_e64 %[s2], %[k8], %[p]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s0]\n\t"
+        "v_cmp_le_u32_e64 %[s0], %[k9], %[p]\n\t"
+        "v_addc_co_u32_e64 %[d], %[sd], %[d], 0, %[s1]\n\t"
+        "v_cmp_le_u32_e64 %[s1], %[k10], %[p]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s2]\n\t"
+        "v_addc_co_u32_e64 %[d], %[sd], %[d], 0, %[s0]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s1]"
+        : [c] "+v"(c), [d] "+v"(d), [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [sd] "=&s"(sd)
+        : [k0] "v"(r[0]), [k1] "v"(r[1]), [k2] "v"(r[2]), [k3] "v"(r[3]), [k4] "v"(r[4]), [k5] "v"(r[5]),
+          [k6] "v"(r[6]), [k7] "v"(r[7]), [k8] "v"(r[8]), [k9] "v"(r[9]), [k10] "v"(r[10]), [p] "v"(p));
+    return d;
+}
+
+// Band compaction, 11 keys: every key k with (k - e0) < w (unsigned: e0 <= k < e0 + w) is appended to the
+// list at LDS byte address p (p += 4).  The 11 compares are issued first (their lane masks go to SGPR
+// pairs), then each mask becomes EXEC for one ds_write + v_add: 3 vector instructions, one scalar and one
+// LDS instruction per key.  EXEC is saved and restored (the call sites are wave-uniform).
+template <class RingT>
+__device__ __forceinline__ void compact11(const RingT& r, uint32_t e0, uint32_t w, uint32_t& p) {
+    unsigned long long m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, sv;
+    uint32_t t0, t1;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_sub_u32 %[t0], %[k0], %[e0]\n\t"
+        "v_sub_u32 %[t1], %[k1], %[e0]\n\t"
+        "v_cmp_lt_u32_e64 %[m0], %[t0], %[w]\n\t"
+        "v_sub_u32 %[t0], %[k2], %[e0]\n\t"
+        "v_cmp_lt_u32_e64 %[m1], %[t1], %[w]\n\t"
+        "v_sub_u32 %[t1], %[k3], %[e0]\n\t"
+        "v_cmp_lt_u32_e64 %[m2], %[t0], %[w]\n\t"
+        "v_sub_u32 %[t0], %[k4], %[e0]\n\t"
+        "v_cmp_lt_u32_e64 %[m3], %[t1], %[w]\n\t"
+        "v_sub_u32 %[t1], %[k5], %[e0]\n\t"
+        "v_cmp_lt_u32_e64 %[m4], %[t0], %[w]\n\t"
+        "v_sub_u32 %[t0], %[k6], %[e0]\n\t"
+        "v_cmp_lt_u32_e64 %[m5], %[t1], %[w]\n\t"
+        "v_sub_u32 %[t1], %[k7], %[e0]\n\t"
+        "v_cmp_lt_u32_e64 %[m6], %[t0], %[w]\n\t"
+        "v_sub_u32 %[t0], %[k8], %[e0]\n\t"
+        "v_cmp_lt_u32_e64 %[m7], %[t1], %[w]\n\t"
+        "v_sub_u32 %[t1], %[k9], %[e0]\n\t"
+        "v_cmp_lt_u32_e64 %[m8], %[t0], %[w]\n\t"
+        "v_sub_u32 %[t0], %[k10], %[e0]\n\t"
+        "v_cmp_lt_u32_e64 %[m9], %[t1], %[w]\n\t"
+        "v_cmp_lt_u32_e64 %[m10], %[t0], %[w]\n\t"
+        "s_and_b64 exec, %[sv], %[m0]\n\t"
+        "ds_write_b32 %[p], %[k0]\n\t"
+        "v_add_u32 %[p], 4, %[p]\n\t"
+        "s_and_b64 exec, %[sv], %[m1]\n\t"
+        "ds_write_b32 %[p], %[k1]\n\t"
+        "v_add_u32 %[p], 4, %[p]\n\t"
+        "s_and_b64 exec, %[sv], %[m2]\n\t"
+        "ds_write_b32 %[p], %[k2]\n\t"
+        "v_add_u32 %[p], 4, %[p]\n\t"
+        "s_and_b64 exec, %[sv], %[m3]\n\t"
+        "ds_write_b32 %[p], %[k3]\n\t"
+        "v_add_u32 %[p], 4, %[p]\n\t"
+        "s_and_b64 exec, %[sv], %[m4]\n\t"
+        "ds_write_b32 %[p], %[k4]\n\t"
+        "v_add_u32 %[p], 4, %[p]\n\t"
+        "s_and_b64 exec, %[sv], %[m5]\n\t"
+        "ds_write_b32 %[p], %[k5]\n\t"
+        "v_add_u32 %[p], 4, %[p]\n\t"
+        "s_and_b64 exec, %[sv], %[m6]\n\t"
+        "ds_write_b32 %[p], %[k6]\n\t"
+        "v_add_u32 %[p], 4, %[p]\n\t"
+        "s_and_b64 exec, %[sv], %[m7]\n\t"
+        "ds_write_b32 %[p], %[k7]\n\t"
+        "v_add_u32 %[p], 4, %[p]\n\t"
+        "s_and_b64 exec, %[sv], %[m8]\n\t"
+        "ds_write_b32 %[p], %[k8]\n\t"
+        "v_add_u32 %[p], 4, %[p]\n\t"
+        "s_and_b64 exec, %[sv], %[m9]\n\t"
+        "ds_write_b32 %[p], %[k9]\n\t"
+        "v_add_u32 %[p], 4, %[p]\n\t"
+        "s_and_b64 exec, %[sv], %[m10]\n\t"
+        "ds_write_b32 %[p], %[k10]\n\t"
+        "v_add_u32 %[p], 4, %[p]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [p] "+v"(p), [t0] "=&v"(t0), [t1] "=&v"(t1), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2),
+          [m3] "=&s"(m3), [m4] "=&s"(m4), [m5] "=&s"(m5), [m6] "=&s"(m6), [m7] "=&s"(m7), [m8] "=&s"(m8),
+          [m9] "=&s"(m9), [m10] "=&s"(m10), [sv] "=&s"(sv)
+        : [k0] "v"(r[0]), [k1] "v"(r[1]), [k2] "v"(r[2]), [k3] "v"(r[3]), [k4] "v"(r[4]), [k5] "v"(r[5]),
+          [k6] "v"(r[6]), [k7] "v"(r[7]), [k8] "v"(r[8]), [k9] "v"(r[9]), [k10] "v"(r[10]), [e0] "v"(e0),
+          [w] "v"(w)
+        : "memory");
+}
+
+// ---- slow path: the round-2 extraction list (kernels_ring2.hip: Top2), on the adjacent lane layout ----
+template <int J, int JM>
+struct Top3 {
+    static_assert(JM >= J && JM <= 8, "merged width: J..8");
+    uint32_t m[JM];
+    __device__ __forceinline__ void reset() {
+#pragma unroll
+        for (int i = 0; i < JM; ++i) m[i] = 0xFFFFFFFFu;
+    }
+    __device__ __forceinline__ void insert(uint32_t d) {
+#pragma unroll
+        for (int i = J - 1; i >= 1; --i) m[i] = med3u3(m[i - 1], m[i], d);
+        m[0] = minu3(m[0], d);
+    }
+    template <int SUBS>
+    __device__ __forceinline__ uint32_t horizon() const { return cmin<SUBS>(m[J - 1]); }
+    template <int CTRL, bool FIRST = false>
+    __device__ __forceinline__ void merge() {
+        constexpr int N = FIRST ? J : JM;
+        uint32_t b[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) b[i] = dpp3<CTRL>(m[i]);
+#pragma unroll
+        for (int i = 0; i < JM; ++i) {
+            const int k = JM - 1 - i;
+            if (i < N && k < N) m[i] = minu3(m[i], b[k]);
+            else if (k < N) m[i] = b[k];
+        }
+        constexpr int OFF = 8 - JM;
+#pragma unroll
+        for (int d = 4; d >= 1; d >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if ((k & d) == 0 && k >= OFF && k + d < 8) {
+                    const uint32_t lo_ = minu3(m[k - OFF], m[k - OFF + d]);
+                    const uint32_t hi_ = maxu3(m[k - OFF], m[k - OFF + d]);
+                    m[k - OFF] = lo_;
+                    m[k - OFF + d] = hi_;
+                }
+            }
+        }
+    }
+    template <int SUBS>
+    __device__ __forceinline__ void merge_cell() {
+        merge<kX1, true>();
+        merge<kX2>();
+        if constexpr (SUBS == 8) merge<kX7>();
+    }
+    __device__ __forceinline__ void at2(uint32_t j, uint32_t& a, uint32_t& b) const {
+        a = m[0];
+        b = m[1];
+#pragma unroll
+        for (int i = 1; i < JM; ++i) {
+            const bool hit = j == static_cast<uint32_t>(i);
+            a = hit ? m[i] : a;
+            b = hit ? m[i + 1 < JM ? i + 1 : i] : b;
+            asm volatile("" : "+v"(a), "+v"(b));
+        }
+    }
+    __device__ __forceinline__ uint32_t count_below(uint32_t d) const {
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < JM; ++i) c += (m[i] < d) ? 1u : 0u;
+        return c;
+    }
+};
+
+// ---- fast path: sort the CAP x SUBS slots of a cell ascending in lane-major order ----------------
+// in-lane: optimal networks (5 comparators for 4, 19 for 8); across lanes: bitonic merges whose first
+// step pairs slot r of a lane with slot CAP-1-r of its mirror lane, so that every comparator is
+// ascending; the lower lane keeps the minimum (v_med3 with a bound of 0), the upper one the maximum
+// (bound 0xFFFFFFFF)
+__device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b) {
+    const uint32_t lo = minu3(a, b), hi = maxu3(a, b);
+    a = lo;
+    b = hi;
+}
+template <int CAP>
+__device__ __forceinline__ void sort_lane(uint32_t (&c)[CAP]) {
+    if constexpr (CAP == 4) {
+        cswap(c[0], c[1]); cswap(c[2], c[3]); cswap(c[0], c[2]); cswap(c[1], c[3]); cswap(c[1], c[2]);
+    } else {
+        static_assert(CAP == 8, "4 or 8 slots per lane");
+        cswap(c[0], c[1]); cswap(c[2], c[3]); cswap(c[4], c[5]); cswap(c[6], c[7]);
+        cswap(c[0], c[2]); cswap(c[1], c[3]); cswap(c[4], c[6]); cswap(c[5], c[7]);
+        cswap(c[1], c[2]); cswap(c[5], c[6]); cswap(c[0], c[4]); cswap(c[3], c[7]);
+        cswap(c[1], c[5]); cswap(c[2], c[6]);
+        cswap(c[1], c[4]); cswap(c[3], c[6]);
+        cswap(c[2], c[4]); cswap(c[3], c[5]);
+        cswap(c[3], c[4]);
+    }
+}
+template <int CAP>
+__device__ __forceinline__ void clean_lane(uint32_t (&c)[CAP]) {      // bitonic -> sorted, in-lane
+#pragma unroll
+    for (int d = CAP / 2; d >= 1; d >>= 1)
+#pragma unroll
+        for (int r = 0; r < CAP; ++r)
+            if ((r & d) == 0) cswap(c[r], c[r + d]);
+}
+template <int CAP, int CTRL, bool MIRROR>
+__device__ __forceinline__ void cross_step(uint32_t (&c)[CAP], uint32_t bound) {
+    uint32_t b[CAP];
+#pragma unroll
+    for (int r = 0; r < CAP; ++r) b[r] = dpp3<CTRL>(c[MIRROR ? CAP - 1 - r : r]);
+#pragma unroll
+    for (int r = 0; r < CAP; ++r) c[r] = med3u3(c[r], b[r], bound);
+}
+template <int SUBS, int CAP>
+__device__ __forceinline__ void sort_cell(uint32_t (&c)[CAP], uint32_t bnd1, uint32_t bnd2, uint32_t bnd4) {
+    sort_lane<CAP>(c);
+    cross_step<CAP, kX1, true>(c, bnd1);                   // groups of 2 lanes
+    clean_lane<CAP>(c);
+    cross_step<CAP, kX3, true>(c, bnd2);                   // groups of 4 lanes
+    cross_step<CAP, kX1, false>(c, bnd1);
+    clean_lane<CAP>(c);
+    if constexpr (SUBS == 8) {
+        cross_step<CAP, kX7, true>(c, bnd4);               // groups of 8 lanes
+        cross_step<CAP, kX2, false>(c, bnd2);
+        cross_step<CAP, kX1, false>(c, bnd1);
+        clean_lane<CAP>(c);
+    }
+}
+template <int CAP>
+__device__ __forceinline__ uint32_t pick_reg(const uint32_t (&c)[CAP], uint32_t r) {
+    uint32_t v = c[0];
+#pragma unroll
+    for (int i = 1; i < CAP; ++i) {
+        v = (r == static_cast<uint32_t>(i)) ? c[i] : v;
+        asm volatile("" : "+v"(v));
+    }
+    return v;
+}
+
+constexpr int kBudget3 = 6;
+
+template <int SUBS> struct Cfg3;
+template <> struct Cfg3<4> {   // 16 cells per wave
+    static constexpr int NB = 224, CAP = 8, LW = 16, JM = 7;
+};
+template <> struct Cfg3<8> {   // 8 cells per wave
+    static constexpr int NB = 128, CAP = 4, LW = 16, JM = 8;
+};
+// buckets are sized to hold about this many pooled keys near the target
+constexpr float kBucketRanks = 4.0f;
+
+}  // namespace
+
+// sflags[step]: bit 0 = SIMPLE, bit 1 = CONSEC (plan.h).  ntracks = real tracks (tracks >= ntracks are padding).
+// stats (STATS builds): [0] wave-rows, [1] count passes, [2] extractions, [3] cold passes, [4] fast steps,
+// [5] low word: wave-rows settled by the band path alone, high word: window rebuilds (wave level),
+// [6] low word: cell-rows that tried the band path, high word: cell-rows it failed on, [7] low word: of those,
+// target off the block / window, high word: band larger than a list ([3] high word: histogram mismatches, must be 0).
+template <int YPS, int SUBS, bool STATS>
+__global__ __launch_bounds__(256, 2) void clim_ring3_f32(
+    const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
+    const uint32_t* __restrict__ sflags, int32_t step_min, const DevChunk* __restrict__ chunks, double q,
+    int negate, int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
+    unsigned long long* __restrict__ stats) {
+    constexpr int W = 5;
+    constexpr int R = 2 * W + 1;
+    static_assert(SUBS == 8 || SUBS == 4, "8 or 4 lanes per cell");
+    constexpr int NTP = SUBS * YPS;
+    constexpr int CPWAVE = 64 / SUBS;
+    constexpr int NB = Cfg3<SUBS>::NB;           // buckets per cell
+    constexpr int HS = NB + 4;                   // words per cell histogram (bank skew, keeps 16-byte alignment)
+    constexpr int CAP = Cfg3<SUBS>::CAP;         // list slots per lane that are sorted
+    constexpr int LW = Cfg3<SUBS>::LW;           // words per lane list = most keys a band may hold (MCAP)
+    constexpr int Q = 16 / SUBS;                 // buckets per lane of the 16 the walk looks at
+    constexpr int J = 5;
+    constexpr int JM = Cfg3<SUBS>::JM;
+    constexpr uint32_t SLACK = JM - 2;
+    constexpr uint32_t ALLC = (1u << YPS) - 1u;
+    constexpr int EDGE_LO = 20, EDGE_HI = 36;    // rebuild when the target bucket is this close to an end
+    // band population x 16 (running mean): a rebuild is asked for outside [LO_TRIG, HI_TRIG]; whenever the wave
+    // rebuilds, every cell outside [LO_ADJ, HI_ADJ] changes its bucket width too (so that it does not ask for
+    // a rebuild of its own a few rows later)
+    constexpr int32_t M16_TARGET = 16 * 6, M16_HI_TRIG = 16 * 14, M16_LO_TRIG = 16 * 7 / 2, M16_HI_ADJ = 16 * 10,
+                      M16_LO_ADJ = 16 * 9 / 2;
+
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kWaves3 * CPWAVE * HS + 64 * kWaves3 * LW];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int sub = lane & (SUBS - 1);
+    const int cw = lane / SUBS;
+    const int64_t cell = (static_cast<int64_t>(blockIdx.x) * kWaves3 + wave) * CPWAVE + cw;
+    const bool cell_ok = cell < C;
+    const DevChunk ch = chunks[blockIdx.y];
+    const uint32_t* tab = table + sub;           // y-major: entry of slot y at tab[step * NTP + y * SUBS]
+    const float* col = ts + (cell_ok ? cell : C - 1);
+    const uint32_t negmask = negate ? 0xFFFFFFFFu : 0u;
+    const uint32_t tmax = static_cast<uint32_t>(Tn - 1);
+    const bool padded_last = (YPS - 1) * SUBS + sub >= ntracks;
+    const uint32_t padmask = padded_last ? 0xFFFFFFFFu : 0u;
+    const uint32_t full_valid = static_cast<uint32_t>((padded_last ? YPS - 1 : YPS) * R);
+
+    uint32_t* const hist = lds + (wave * CPWAVE + cw) * HS;
+    uint32_t* const list = lds + kWaves3 * CPWAVE * HS + threadIdx.x * LW;
+    // LDS byte address of this lane's list (the low 32 bits of a generic LDS pointer are the LDS offset)
+    const uint32_t list_addr =
+        static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t*)list));
+    // lane constants of the sort (lower / upper lane of a pair) and of the scan over the lanes of a cell
+    const uint32_t bnd1 = (sub & 1) ? 0xFFFFFFFFu : 0u, bnd2 = (sub & 2) ? 0xFFFFFFFFu : 0u,
+                   bnd4 = (sub & 4) ? 0xFFFFFFFFu : 0u;
+    const uint32_t mk1 = sub >= 1 ? 0xFFFFFFFFu : 0u, mk2 = sub >= 2 ? 0xFFFFFFFFu : 0u,
+                   mk4 = sub >= 4 ? 0xFFFFFFFFu : 0u;
+    const uint32_t mk12 = sub <= 12 / Q - 1 ? 0xFFFFFFFFu : 0u;       // lanes that hold buckets 0..11 of a block
+
+    typedef uint32_t RingT __attribute__((ext_vector_type(R)));
+    RingT ring[YPS];
+#pragma unroll
+    for (int y = 0; y < YPS; ++y) ring[y] = kInv3;
+    double lsum = 0.0;
+    uint32_t nval = 0;
+
+    uint32_t tix[YPS];
+    const uint32_t last_step = padded_last ? 0u : 1u;
+    auto entries_of = [&](int32_t step, uint32_t (&e)[YPS]) {
+        const uint32_t* p = tab + static_cast<int64_t>(step - step_min) * NTP;
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) e[y] = p[y * SUBS];
+    };
+    auto point_at = [&](int32_t step) {
+        uint32_t e[YPS];
+        entries_of(step, e);
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) tix[y] = minu3((e[y] >> 1) - 2u, tmax);
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) tix[y] += (y == YPS - 1) ? last_step : 1u;
+    };
+    auto request = [&](float (&x)[YPS]) {
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) x[y] = col[static_cast<int64_t>(tix[y]) * ld];
+    };
+
+    float x_raw[YPS];
+    point_at(ch.warm_start);
+    request(x_raw);
+
+    int m = (ch.warm_start - step_min) % R;
+    // carried across rows, uniform over the lanes of a cell
+    uint32_t pc = 0, Fc = 0;  // pivot with its exact count #{keys <= pc}; with a valid window: pc = edge(A) - 1
+    uint32_t have_c = 0;
+    float kpr = 8192.0f;      // keys per rank near the target
+    bool kpr_seen = false;
+    bool clean = false;
+    // histogram window of the cell: keys [hbase, hbase + (NB << hshift)), bucket = (key - hbase) >> hshift
+    // clamped to 0 (everything below) .. NB-1 (everything above, the invalid keys included)
+    uint32_t hbase = 0, hshift = 0, hvalid = 0;
+    uint32_t A = 0;           // anchor bucket: pc + 1 is its lower edge
+    int32_t m16 = M16_TARGET; // running mean of the band population, x 16
+    uint32_t hbuilt = 0;      // the cell has had a window before (its bucket width is then adjusted, not re-derived)
+    uint32_t st_count = 0, st_extract = 0, st_rows = 0, st_cold = 0, st_fast = 0, st_cell = 0;
+    uint32_t st_band = 0, st_rebuild = 0, st_try = 0, st_fail = 0, st_lost = 0, st_cap = 0, st_mm = 0;
+
+    // STATS builds: shader-clock ticks per section of the row loop (a tick waits for the LDS queue to drain, so a
+    // section is charged with the LDS work it issued)
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = 0;
+    if constexpr (STATS) tlast = __builtin_amdgcn_s_memtime();
+    auto tick = [&](int idx) {
+        if constexpr (STATS) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tacc[idx] += now - tlast;
+            tlast = now;
+        }
+    };
+
+    auto tag_of = [&](uint32_t key) -> uint32_t {
+        return minu3(__builtin_elementwise_sub_sat(key, hbase) >> hshift, static_cast<uint32_t>(NB - 1));
+    };
+
+    uint32_t hmask = 0;
+    int32_t s = ch.warm_start;
+    uint32_t sf_cur = __builtin_amdgcn_readfirstlane(sflags[s - step_min]);
+    uint32_t sf_nxt = s + 1 < ch.end ? __builtin_amdgcn_readfirstlane(sflags[s + 1 - step_min]) : 0u;
+    while (s < ch.end) {
+    bool rotate = false;
+    for (; s < ch.end && !rotate; ++s) {
+        // ---- prefetch: the samples of step s+1 (consumed one row later) ------------------
+        float x_nxt[YPS];
+        const uint32_t sf_nn = s + 2 < ch.end ? __builtin_amdgcn_readfirstlane(sflags[s + 2 - step_min]) : 0u;
+        if (s + 1 < ch.end) {
+            if (sf_nxt & 2u) advance();
+            else point_at(s + 1);
+            request(x_nxt);
+        } else {
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) x_nxt[y] = 0.0f;
+        }
+        const uint32_t sf = sf_cur;
+
+        // ---- what this step pushes ------------------------------------------------------
+        uint32_t kin[YPS], kout[YPS];
+        uint32_t cmask = ALLC;
+        hmask = 0;
+        bool wave_hold = false;
+        float xs = x_raw[0];
+#pragma unroll
+        for (int y = 1; y < YPS; ++y) xs += x_raw[y];
+        const bool row_nan = xs != xs;
+        const bool fast = (sf & 1u) && clean && !__any(row_nan);
+        auto key_in = [&](int y) -> uint32_t { return key_of_bits3(__float_as_uint(x_raw[y]), negmask); };
+        auto is_nan = [&](int y) -> bool { return x_raw[y] != x_raw[y]; };
+        if (fast) {
+            if constexpr (STATS) ++st_fast;
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) kin[y] = key_in(y);
+            kin[YPS - 1] |= padmask;
+        } else if (sf & 1u) {
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) kin[y] = !is_nan(y) ? key_in(y) : kInv3;
+            kin[YPS - 1] |= padmask;
+        } else {
+            uint32_t e_cur[YPS];
+            entries_of(s, e_cur);
+            cmask = 0;
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) {
+                const uint32_t code = e_cur[y] >> 1;
+                cmask |= (e_cur[y] & 1u) << y;
+                hmask |= (code == kCodeHold ? 1u : 0u) << y;
+                const bool ok = code >= 2u && !is_nan(y);
+                kin[y] = ok ? key_in(y) : kInv3;
+            }
+            wave_hold = __any(hmask != 0);
+        }
+        // ---- the one place where the rings are written (slot m of every track) ------------
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) kout[y] = ring[y][m];
+        if (wave_hold) {
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) kin[y] = ((hmask >> y) & 1u) ? kout[y] : kin[y];
+        }
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) ring[y][m] = kin[y];
+        // ---- the histogram mirrors the ring (a held track adds and removes the same key) ------
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) {
+            __hip_atomic_fetch_add(&hist[tag_of(kin[y])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&hist[tag_of(kout[y])], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        uint32_t dF = 0;
+        if (fast) {
+            double din, dout;
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) {
+                uint32_t bi = __float_as_uint(x_raw[y]) ^ (negmask & 0x80000000u);
+                uint32_t bo = bits_of_key3(kout[y]);
+                if (y == YPS - 1) {
+                    bi &= ~padmask;
+                    bo &= ~padmask;
+                }
+                const double di = static_cast<double>(__uint_as_float(bi));
+                const double dq = static_cast<double>(__uint_as_float(bo));
+                din = y == 0 ? di : din + di;
+                dout = y == 0 ? dq : dout + dq;
+                dF += (kin[y] <= pc ? 1u : 0u) - (kout[y] <= pc ? 1u : 0u);
+            }
+            lsum += din - dout;
+        } else {
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) {
+                lsum += value_of_key3(kin[y]);
+                lsum -= value_of_key3(kout[y]);
+                nval += (kin[y] != kInv3 ? 1u : 0u) - (kout[y] != kInv3 ? 1u : 0u);
+                dF += (kin[y] <= pc ? 1u : 0u) - (kout[y] <= pc ? 1u : 0u);
+            }
+            rotate = wave_hold;
+            clean = !__any(nval != full_valid);
+        }
+        m = (m + 1 == R) ? 0 : m + 1;
+        tick(0);
+
+        // ---- select + output (not during warm-up) ---------------------------------
+        if (s >= ch.begin) {
+            const bool wallc = __all(cmask == ALLC);
+            uint32_t n;
+            double total;
+            if (wallc) {
+                n = csum<SUBS>(nval);
+                total = csum<SUBS>(lsum);
+            } else {
+                uint32_t nl = 0;
+                double tl = 0.0;
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) {
+                    uint32_t cy = 0;
+                    double ty = 0.0;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const uint32_t key = opaque3(ring[y][k]);
+                        cy += key != kInv3 ? 1u : 0u;
+                        ty += value_of_key3(key);
+                    }
+                    const bool cnt = (cmask >> y) & 1u;
+                    nl += cnt ? cy : 0u;
+                    tl += cnt ? ty : 0.0;
+                }
+                n = csum<SUBS>(nl);
+                total = csum<SUBS>(tl);
+            }
+            if (__any(!(fabs(total) <= 1.7976931348623157e308))) {
+                double t = 0.0, tl = 0.0;
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) {
+                    double ty = 0.0;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) ty += value_of_key3(opaque3(ring[y][k]));
+                    t += ty;
+                    tl += ((cmask >> y) & 1u) ? ty : 0.0;
+                }
+                lsum = t;
+                total = csum<SUBS>(tl);
+            }
+            Fc += csum<SUBS>(dF);
+
+            const uint32_t nn = n ? n : 1u;
+            const double vi = static_cast<double>(nn - 1) * q;
+            const double fl = floor(vi);
+            const double g = vi - fl;
+            const uint32_t lo = static_cast<uint32_t>(fl);
+            const bool need2 = lo + 1 < nn;
+
+            auto count_le = [&](uint32_t p) -> uint32_t {
+                uint32_t c = 0;
+                if (wallc) {
+                    uint32_t c2 = 0;
+#pragma unroll
+                    for (int y = 0; y < YPS; ++y) c2 = count_le11_3(ring[y], p, c, c2);
+                    c += c2;
+                } else {
+#pragma unroll
+                    for (int y = 0; y < YPS; ++y) {
+                        uint32_t cy = 0;
+#pragma unroll
+                        for (int k = 0; k < R; ++k) cy += (opaque3(ring[y][k]) <= p) ? 1u : 0u;
+                        c += ((cmask >> y) & 1u) ? cy : 0u;
+                    }
+                }
+                return csum<SUBS>(c);
+            };
+
+            bool resolved = (n == 0);
+            uint32_t alo = 0, ahi = 0, pe = 0, Fe = 0;
+            bool band_done = false;       // this cell was settled by the band path
+            bool lost = false;            // this cell's window must be rebuilt (anchor lost, target off the block)
+
+            tick(1);
+            // ================= band path =====================================================
+            const bool btry = wallc && hvalid != 0 && have_c != 0 && n != 0;
+            if (__any(btry)) {
+                // ---- 1. walk: the 16 buckets next to the anchor -------------------------
+                const bool up = Fc <= lo;                      // target at or above the anchor's lower edge
+                bool bok = btry && (up || A >= 12u);
+                const uint32_t S = bok ? (up ? A : A - 12u) : 0u;       // first bucket of the block
+                bok = bok && S >= 1u && S + 16u <= static_cast<uint32_t>(NB - 1);
+                const uint32_t* hp = hist + (bok ? S : 0u) + sub * Q;
+                uint32_t pf[Q];
+                pf[0] = hp[0];
+#pragma unroll
+                for (int i = 1; i < Q; ++i) pf[i] = pf[i - 1] + hp[i];
+                const uint32_t T = pf[Q - 1];
+                uint32_t incl = T;
+                incl += dpp3<kShr1>(incl) & mk1;
+                incl += dpp3<kShr2>(incl) & mk2;
+                if constexpr (SUBS == 8) incl += dpp3<kShr4>(incl) & mk4;
+                const uint32_t excl = incl - T;
+                const uint32_t tot = cmax<SUBS>(incl);                    // keys in the 16 buckets
+                const uint32_t p12 = cmax<SUBS>(incl & mk12);             // keys in buckets 0..11 of the block
+                const uint32_t CS = up ? Fc : Fc - p12;                   // keys below the block
+                bok = bok && CS <= lo && lo + (need2 ? 1u : 0u) < CS + tot;
+                const uint32_t t0 = lo - CS, t1 = t0 + (need2 ? 1u : 0u);
+                uint32_t kk = 0, PB = 0, PU = 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 0; i < Q; ++i) {
+                    const uint32_t P = excl + pf[i];
+                    const bool le0 = P <= t0;
+                    kk += le0 ? 1u : 0u;
+                    kk += (P <= t1) ? 0x10000u : 0u;
+                    PB = le0 ? P : PB;
+                }
+#pragma unroll
+                for (int i = Q - 1; i >= 0; --i) {
+                    const uint32_t P = excl + pf[i];
+                    PU = (P > t1) ? P : PU;
+                }
+                kk = csum<SUBS>(kk);
+                PB = cmax<SUBS>(PB);
+                PU = cmin<SUBS>(PU);
+                const uint32_t k0 = kk & 0xFFFFu, k1 = kk >> 16;
+                const uint32_t Cb = CS + PB;               // keys below bucket B0
+                const uint32_t mb = PU - PB;               // keys in buckets B0..B1
+                const uint32_t B0 = S + k0;
+                lost = btry && !bok;                       // off the block or at an end of the window
+                const bool capf = bok && mb > static_cast<uint32_t>(LW);
+                bok = bok && mb <= static_cast<uint32_t>(LW);
+                const uint32_t E0 = hbase + (B0 << hshift);
+                const uint32_t width = bok ? ((k1 - k0 + 1u) << hshift) : 0u;
+                tick(2);
+                // ---- 2. compaction: the keys of the band, appended to this lane's list ----------
+#pragma unroll
+                for (int i = 0; i < CAP; i += 4)
+                    *reinterpret_cast<uint4*>(list + i) = make_uint4(kInv3, kInv3, kInv3, kInv3);
+                uint32_t ptr = list_addr;
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) compact11(ring[y], E0, width, ptr);
+                const uint32_t cntl = (ptr - list_addr) >> 2;
+                tick(3);
+                uint32_t c[CAP];
+#pragma unroll
+                for (int i = 0; i < CAP; i += 4) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(list + i);
+                    c[i] = v.x; c[i + 1] = v.y; c[i + 2] = v.z; c[i + 3] = v.w;
+                }
+                // (mm == mb always: the histogram mirrors the ring; the check costs one reduction and turns a
+                // bookkeeping error into a slow row instead of a wrong one)
+                const uint32_t mm = csum<SUBS>(cntl);
+                const uint32_t lmax = cmax<SUBS>(cntl);
+                const bool mmf = bok && mm != mb;
+                bok = bok && mm == mb && lmax <= static_cast<uint32_t>(CAP);
+                // ---- 3. sort the cell's slots, pick entries j and j + 1 ------------------
+                sort_cell<SUBS, CAP>(c, bnd1, bnd2, bnd4);
+                const uint32_t j = lo - Cb, j1 = j + 1u;
+                const uint32_t va = pick_reg<CAP>(c, j & (CAP - 1)), vb = pick_reg<CAP>(c, j1 & (CAP - 1));
+                const uint32_t xa = cmax<SUBS>((static_cast<uint32_t>(sub) == j / CAP) ? va : 0u);
+                const uint32_t xb = cmax<SUBS>((static_cast<uint32_t>(sub) == j1 / CAP) ? vb : 0u);
+                if constexpr (STATS) {
+                    st_try += btry ? 1u : 0u;
+                    st_fail += (btry && !bok) ? 1u : 0u;
+                    st_lost += lost ? 1u : 0u;
+                    st_cap += capf ? 1u : 0u;
+                    st_mm += mmf ? 1u : 0u;
+                }
+                if (bok) {
+                    alo = xa;
+                    ahi = need2 ? xb : xa;
+                    pe = E0 - 1u;
+                    Fe = Cb;
+                    A = B0;
+                    resolved = true;
+                    band_done = true;
+                    m16 += (static_cast<int32_t>(mb << 4) - m16) >> 2;
+                } else if (capf) {
+                    m16 += (static_cast<int32_t>(minu3(mb, 64u) << 4) - m16) >> 2;      // overfull buckets: narrow them
+                }
+                // (a cell the band path could not settle for lack of list space keeps its anchor: the pivot and
+                // its count stay exact, the slow path settles this row; a cell whose target left the block is
+                // given a new window below)
+            }
+            if constexpr (STATS) st_band += __all(resolved) ? 1u : 0u;
+            tick(4);
+
+            // ================= slow path: the round-2 selection ==================================
+            uint32_t top_span = 0;
+            if (!__all(resolved)) {
+                uint32_t pl = 0, Fl = 0, ph = 0xFFFFFFFFu, Fh = nn;
+                uint32_t lreal = 0, hreal = 0;
+                float grow = 1.0f;
+                uint32_t p_first = 0;
+                int32_t rank_gap = 0;
+                {
+                    const bool use_c = have_c != 0 && wallc;
+                    uint32_t p0 = pc, F0 = 0;
+                    if (use_c) F0 = Fc;
+                    if (!__all(use_c || n == 0)) {
+                        uint32_t pm = key_of_bits3(__float_as_uint(static_cast<float>(total / static_cast<double>(nn))), 0u);
+                        if (!use_c) p0 = have_c != 0 ? pc : pm;
+                        const uint32_t Fr = count_le(minu3(p0, 0xFFFFFFFEu));
+                        if (!use_c) F0 = Fr;
+                        if constexpr (STATS) ++st_cold;
+                    }
+                    if (p0 != 0 && p0 < 0xFFFFFFFEu) {
+                        if (F0 <= lo) { pl = p0; Fl = F0; lreal = 1; }
+                        else { ph = p0; Fh = F0; hreal = 1; }
+                    }
+                    p_first = p0;
+                    rank_gap = static_cast<int32_t>(lo) - static_cast<int32_t>(F0);
+                }
+                const float aim = static_cast<float>(lo) - 0.5f * static_cast<float>(SLACK);
+                uint32_t slack = SLACK;
+                int budget = kBudget3;
+                uint32_t s_alo = 0, s_ahi = 0, s_pe = 0, s_Fe = 0;
+                bool sres = resolved;         // settled (by the band path, or n == 0)
+                for (;;) {
+                    for (int it = 0;; ++it) {
+                        const bool settle = sres || (lo - Fl <= slack) || (ph - pl <= 1u);
+                        if (__all(settle) || it >= budget) break;
+                        const uint32_t room = ph - pl;
+                        const bool both = lreal != 0 && hreal != 0;
+                        const bool from_l = lreal != 0 || hreal == 0;
+                        const float roomf = static_cast<float>(room);
+                        const float slope = both ? roomf * __builtin_amdgcn_rcpf(static_cast<float>(Fh - Fl))
+                                                 : kpr * grow;
+                        const float ranks = from_l ? aim - static_cast<float>(Fl) : static_cast<float>(Fh) - aim;
+                        float stf = fminf(fmaxf(ranks * slope, 1.0f), 2.0e9f);
+                        stf = from_l ? stf : roomf - stf;
+                        stf = fminf(fmaxf(stf, 1.0f), 4.0e9f);
+                        uint32_t off = (it < 5) ? static_cast<uint32_t>(stf) : (room >> 1);
+                        grow = both ? grow : grow * 2.0f;
+                        off = maxu3(1u, minu3(off, room - 1u));
+                        const uint32_t p = settle ? pl : pl + off;
+                        const uint32_t F = count_le(p);
+                        if constexpr (STATS) {
+                            ++st_count;
+                            st_cell += settle ? 0u : 1u;
+                        }
+                        if (!settle) {
+                            if (F <= lo) { pl = p; Fl = F; lreal = 1; }
+                            else { ph = p; Fh = F; hreal = 1; }
+                        }
+                    }
+                    const bool window = (lo - Fl <= slack);
+                    const bool adjacent = !window && (ph - pl <= 1u);
+                    const uint32_t px = adjacent ? ph : pl;
+                    const uint32_t base = px + 1u;
+                    Top3<J, JM> top;
+                    top.reset();
+                    if (wallc) {
+#pragma unroll
+                        for (int y = 0; y < YPS; ++y)
+#pragma unroll
+                            for (int k = 0; k < R; ++k) top.insert(ring[y][k] - base);
+                    } else {
+#pragma unroll
+                        for (int y = 0; y < YPS; ++y)
+#pragma unroll
+                            for (int k = 0; k < R; ++k) {
+                                const uint32_t d = opaque3(ring[y][k]) - base;
+                                top.insert(((cmask >> y) & 1u) ? d : 0xFFFFFFFFu);
+                            }
+                    }
+                    const uint32_t horizon = JM > J ? top.template horizon<SUBS>() : 0xFFFFFFFFu;
+                    top.template merge_cell<SUBS>();
+                    if constexpr (STATS) ++st_extract;
+                    if (!sres) {
+                        const uint32_t j = window ? lo - Fl : 0u;
+                        uint32_t d_lo, d_nx;
+                        top.at2(j, d_lo, d_nx);
+                        const uint32_t d_hi = need2 ? d_nx : d_lo;
+                        const bool exact = d_hi <= horizon || j + (need2 ? 1u : 0u) < static_cast<uint32_t>(J);
+                        if (window && !exact) slack = J - 2;
+                        if (window && exact) {
+                            s_alo = base + d_lo;
+                            s_ahi = base + d_hi;
+                            s_pe = pl; s_Fe = Fl;
+                            top_span = top.m[J - 1] - top.m[0];
+                            sres = true;
+                        } else if (adjacent && !window) {
+                            s_alo = ph;
+                            s_ahi = (need2 && lo + 1u >= Fh) ? base + top.m[0] : ph;
+                            s_pe = ph; s_Fe = Fh;
+                            sres = true;
+                        }
+                    }
+                    if (__all(sres)) break;
+                    const uint32_t dj = minu3(top.m[JM - 1], horizon);
+                    const uint32_t pj = base + dj;
+                    const uint32_t Fj = count_le(sres ? pl : pj);
+                    if constexpr (STATS) ++st_count;
+                    if (!sres) {
+                        if (Fj <= lo) {
+                            pl = pj; Fl = Fj; lreal = 1;
+                        } else {
+                            ph = pj; Fh = Fj; hreal = 1;
+                            Fl = Fl + top.count_below(dj);
+                            pl = pj - 1u;
+                            lreal = 1;
+                        }
+                    }
+                    budget = 2;
+                }
+                if (!resolved) {
+                    alo = s_alo; ahi = s_ahi; pe = s_pe; Fe = s_Fe;
+                    resolved = true;
+                    if (n > 0) {
+                        if (rank_gap > 1 || rank_gap < -1) {
+                            const float obs = (static_cast<float>(alo) - static_cast<float>(p_first)) *
+                                              __builtin_amdgcn_rcpf(static_cast<float>(rank_gap));
+                            if (obs >= 1.0f && obs < 1.0e8f) kpr = 0.75f * kpr + 0.25f * obs;
+                        }
+                        if (top_span != 0) {
+                            // local spacing of the keys just above the pivot: what sizes the buckets
+                            const float obs = static_cast<float>(top_span) * (1.0f / static_cast<float>(J - 1));
+                            if (obs >= 1.0f && obs < 1.0e8f) {
+                                kpr = kpr_seen ? 0.5f * kpr + 0.5f * obs : obs;
+                                kpr_seen = true;
+                            }
+                        }
+                    }
+                }
+            }
+
+            tick(5);
+            if constexpr (STATS) ++st_rows;
+            double th = make_nan(), se = make_nan();
+            if (n > 0) {
+                const double v_lo = static_cast<double>(__uint_as_float(bits_of_key3(alo)));
+                const double v_hi = static_cast<double>(__uint_as_float(bits_of_key3(ahi)));
+                th = numpy_lerp(v_lo, v_hi, g);
+                se = total / static_cast<double>(n);
+            }
+            if (wallc) {
+                // (rows that do not pool every track leave the carried pivot and the window alone: both count
+                // ALL keys of the ring and stay exact)
+                if (n > 0) {
+                    if (band_done || hvalid == 0 || lost) {
+                        pc = pe;
+                        Fc = Fe;
+                        if (!band_done) hvalid = 0;    // the pivot is no longer a bucket edge: new window below
+                    }
+                    have_c = 1;
+                } else {
+                    have_c = 0;
+                    pc = 0;
+                    Fc = 0;
+                    hvalid = 0;
+                }
+            }
+            if (sub == 0 && cell_ok) {
+                thresh[static_cast<int64_t>(s) * ldo + cell] = th;
+                seas[static_cast<int64_t>(s) * ldo + cell] = se;
+            }
+
+            tick(6);
+            // ================= window (re)build ==================================================
+            const bool can = wallc && n > 0;
+            const bool want = can && (hvalid == 0 || A < static_cast<uint32_t>(EDGE_LO) ||
+                                      A > static_cast<uint32_t>(NB - EDGE_HI) || m16 > M16_HI_TRIG || m16 < M16_LO_TRIG);
+            if (__any(want)) {
+                if constexpr (STATS) ++st_rebuild;
+                if (can) {
+                    // bucket width: from the key spacing on a first build, one step at a time afterwards
+                    uint32_t sh;
+                    if (hbuilt == 0) {
+                        const float bw = fminf(fmaxf(kpr * kBucketRanks, 1.0f), 8.0e6f);
+                        sh = 31u - static_cast<uint32_t>(__builtin_clz(static_cast<uint32_t>(bw)));
+                        m16 = M16_TARGET;
+                    } else {
+                        sh = hshift;
+#pragma unroll
+                        for (int it = 0; it < 3; ++it) {
+                            const bool dn = m16 > M16_HI_ADJ && sh > 0u, upw = m16 < M16_LO_ADJ && sh < 23u;
+                            sh = dn ? sh - 1u : upw ? sh + 1u : sh;
+                            m16 = dn ? m16 >> 1 : upw ? m16 << 1 : m16;
+                        }
+                    }
+                    sh = minu3(sh, 23u);
+                    hshift = sh;
+                    const uint32_t half = static_cast<uint32_t>(NB / 2) << sh;
+                    uint32_t nb = alo > half ? alo - half : 0u;
+                    nb = minu3(nb, 0u - (static_cast<uint32_t>(NB) << sh));     // window inside the key space
+                    hbase = nb;
+                    hbuilt = 1;
+                }
+                // every lane clears its share of the cell's histogram, then adds its keys
+#pragma unroll
+                for (int i = 0; i < NB / SUBS; i += 4)
+                    *reinterpret_cast<uint4*>(hist + sub * (NB / SUBS) + i) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int y = 0; y < YPS; ++y)
+#pragma unroll
+                    for (int k = 0; k < R; ++k)
+                        __hip_atomic_fetch_add(&hist[tag_of(ring[y][k])], 1u, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                // anchor: the bucket of this row's answer; its lower edge becomes the carried pivot
+                const uint32_t An = can ? tag_of(alo) : 0u;
+                const uint32_t pn = hbase + (An << hshift) - 1u;
+                const bool okA = can && An >= 1u && An + 16u < static_cast<uint32_t>(NB);
+                const uint32_t Fn = count_le(okA ? pn : 0u);
+                if constexpr (STATS) ++st_count;
+                if (okA) {
+                    A = An;
+                    pc = pn;
+                    Fc = Fn;
+                    hvalid = 1;
+                } else if (can) {
+                    hvalid = 0;
+                }
+            }
+        }
+
+        tick(7);
+        if ((s & 31) == 31) __syncthreads();
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) x_raw[y] = x_nxt[y];
+        sf_cur = sf_nxt;
+        sf_nxt = sf_nn;
+    }
+    if (rotate) {
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) {
+            const unsigned long long hy = __builtin_amdgcn_ballot_w64(((hmask >> y) & 1u) != 0);
+            const uint32_t last = opaque3(ring[y][R - 1]);
+            asm volatile("s_nop 1");
+#pragma unroll
+            for (int k = R - 1; k >= 1; --k) {
+                uint32_t e = ring[y][k];
+                ring_sel3(e, ring[y][k - 1], hy);
+                ring[y][k] = e;
+            }
+            uint32_t e0 = ring[y][0];
+            ring_sel3(e0, last, hy);
+            ring[y][0] = e0;
+        }
+    }
+    }
+    if (STATS && stats != nullptr && lane == 0) {
+        atomicAdd(&stats[0], static_cast<unsigned long long>(st_rows));
+        atomicAdd(&stats[1], static_cast<unsigned long long>(st_count));
+        atomicAdd(&stats[2], static_cast<unsigned long long>(st_extract));
+        atomicAdd(&stats[3], static_cast<unsigned long long>(st_cold));
+        atomicAdd(&stats[4], static_cast<unsigned long long>(st_fast));
+        atomicAdd(&stats[5], static_cast<unsigned long long>(st_band) | (static_cast<unsigned long long>(st_rebuild) << 32));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&stats[8 + i], tacc[i]);
+    }
+    if (STATS && stats != nullptr && sub == 0 && cell_ok) {
+        atomicAdd(&stats[6], static_cast<unsigned long long>(st_try) | (static_cast<unsigned long long>(st_fail) << 32));
+        // (slot 7: low word: cells whose target left the block or the window, high word: bands with more keys than
+        // a list holds; the rest of the failures are lanes with more than CAP band keys)
+        atomicAdd(&stats[7], static_cast<unsigned long long>(st_lost) | (static_cast<unsigned long long>(st_cap) << 32));
+        if (st_mm) atomicAdd(&stats[3], static_cast<unsigned long long>(st_mm) << 32);
+    }
+}
+
+// ---------------------------------------------------------------------------
+namespace {
+typedef void (*Ring3Kernel)(const float*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*, int32_t,
+                            const DevChunk*, double, int, int32_t, double*, double*, int64_t, unsigned long long*);
+struct Ring3Entry { int yps, subs; Ring3Kernel fn, fn_stats; };
+#define XMHW_R3(Y, S) {Y, S, clim_ring3_f32<Y, S, false>, clim_ring3_f32<Y, S, true>}
+const Ring3Entry kRing3[] = {
+    XMHW_R3(3, 8), XMHW_R3(4, 8), XMHW_R3(5, 8), XMHW_R3(6, 8),
+    XMHW_R3(5, 4), XMHW_R3(8, 4), XMHW_R3(10, 4),
+};
+#undef XMHW_R3
+const Ring3Entry* find_ring3(int32_t yps, int32_t subs) {
+    for (const auto& e : kRing3)
+        if (e.yps == yps && e.subs == subs) return &e;
+    return nullptr;
+}
+}  // namespace
+
+int32_t ring3_pick_yps(int32_t w, int32_t ntracks, int32_t subs) {
+    if (w != 5) return 0;
+    int32_t best = 0;
+    for (const auto& e : kRing3)
+        if (e.subs == subs && e.yps * subs >= ntracks && (best == 0 || e.yps < best)) best = e.yps;
+    if (best && (best - 1) * subs >= ntracks) return 0;      // padding may only sit in the last slot of a lane
+    return best;
+}
+
+bool ring3_supported(int32_t w, int32_t yps, int32_t subs) { return w == 5 && find_ring3(yps, subs) != nullptr; }
+
+hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
+                            const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,
+                            int32_t w, int32_t yps, int32_t subs, int32_t ntracks, double q, int negate,
+                            double* thresh, double* seas, int64_t ldo, hipStream_t stream,
+                            unsigned long long* stats) {
+    const Ring3Entry* e = w == 5 ? find_ring3(yps, subs) : nullptr;
+    if (!e) return hipErrorInvalidValue;
+    if (C <= 0 || nchunks <= 0) return hipSuccess;
+    const int64_t cells_per_block = (64 / subs) * kWaves3;
+    dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
+    hipLaunchKernelGGL(stats ? e->fn_stats : e->fn, grid, dim3(64 * kWaves3), 0, stream, ts, C, ld, Tn, table, sflags,
+                       step_min, chunks, q, negate, ntracks, thresh, seas, ldo, stats);
+    return hipGetLastError();
+}
+
+}  // namespace xmhw

@@ -135,7 +135,7 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     });
 
     m.def("plan_debug_stats", [](uintptr_t p, int enable, bool read) {
-        py::array_t<uint64_t> out(8);
+        py::array_t<uint64_t> out(16);
         check(xmhw_plan_debug_stats(pp(p), enable, read ? out.mutable_data() : nullptr));
         return out;
     });
