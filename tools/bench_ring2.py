@@ -69,7 +69,9 @@ def main():
                      # shader-clock ticks per wave-row: push+histogram, totals, walk, compaction, sort+pick, slow path,
                      # epilogue, rebuild
                      "ticks_per_wave_row": [round(float(x) / max(float(st_raw[0]), 1.0), 1) for x in st_raw[8:16]]}
-            st[3] = float(int(st_raw[3]) & 0xFFFFFFFF)
+            ring3["rebuild_asked_no_window_edge_population"] = [int(st_raw[1]) >> 32, int(st_raw[2]) >> 32, int(st_raw[4]) >> 32]
+            for i in (1, 2, 3, 4):
+                st[i] = float(int(st_raw[i]) & 0xFFFFFFFF)
             st[5] = st[6] = st[7] = 0.0
         if v in (0, 5, 6, 7, 8, 9, 10, 11):   # no code ring: slots 5 and 6 hold the per-cell histogram of count passes
             a, b = int(st_raw[5]), int(st_raw[6])

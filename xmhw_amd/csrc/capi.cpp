@@ -159,6 +159,9 @@ int32_t auto_chunks(const xmhw_plan* p, int64_t C) {
 // the plain 0 and 7)
 int32_t ring2_resolved(const xmhw_plan* p) {
     if (p->ring2_variant != -2) return p->ring2_variant;
+    // the third-generation kernel (kernels_ring3.hip) on 4 lanes per cell wherever it is instantiated (w = 5,
+    // 9..48 tracks): 68 ms against 80 ms on the 0.25 degree / 40 year grid (profiles/r3_*)
+    if (xmhw::ring3_pick_yps(p->host.w, p->host.ntracks, 4) > 0) return 21;
     const int32_t y8 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 8);
     const int32_t y4 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 10);
     if (y4 && y4 <= 8 && (!y8 || y4 * 4 < y8 * 8)) return 10;

@@ -152,7 +152,10 @@ __device__ __forceinline__ uint32_t count_le11_3(const RingT& r, uint32_t p, uin
 // Band compaction, 11 keys: every key k with (k - e0) < w (unsigned: e0 <= k < e0 + w) is appended to the
 // list at LDS byte address p (p += 4).  The 11 compares are issued first (their lane masks go to SGPR
 // pairs), then each mask becomes EXEC for one ds_write + v_add: 3 vector instructions, one scalar and one
-// LDS instruction per key.  EXEC is saved and restored (the call sites are wave-uniform).
+// LDS instruction per key.  (Branching over the ds_write and the v_add where no lane of the wave has a band key
+// at that ring position -- about half of the positions -- made the pass slower: 5,290 against 3,930 cycles per
+// wave-row; tools/ubench_lds.hip: a taken s_cbranch behind an EXEC write costs as much as the masked write.)
+// EXEC is saved and restored (the call sites are wave-uniform).
 template <class RingT>
 __device__ __forceinline__ void compact11(const RingT& r, uint32_t e0, uint32_t w, uint32_t& p) {
     unsigned long long m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, sv;
@@ -221,7 +224,7 @@ __device__ __forceinline__ void compact11(const RingT& r, uint32_t e0, uint32_t 
         : [k0] "v"(r[0]), [k1] "v"(r[1]), [k2] "v"(r[2]), [k3] "v"(r[3]), [k4] "v"(r[4]), [k5] "v"(r[5]),
           [k6] "v"(r[6]), [k7] "v"(r[7]), [k8] "v"(r[8]), [k9] "v"(r[9]), [k10] "v"(r[10]), [e0] "v"(e0),
           [w] "v"(w)
-        : "memory");
+        : "memory", "scc");
 }
 
 // ---- slow path: the round-2 extraction list (kernels_ring2.hip: Top2), on the adjacent lane layout ----
@@ -368,7 +371,7 @@ template <> struct Cfg3<8> {   // 8 cells per wave
     static constexpr int NB = 128, CAP = 4, LW = 16, JM = 8;
 };
 // buckets are sized to hold about this many pooled keys near the target
-constexpr float kBucketRanks = 4.0f;
+constexpr float kBucketRanks = 3.5f;
 
 }  // namespace
 
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
     constexpr int NTP = SUBS * YPS;
     constexpr int CPWAVE = 64 / SUBS;
     constexpr int NB = Cfg3<SUBS>::NB;           // buckets per cell
-    constexpr int HS = NB + 4;                   // words per cell histogram (bank skew, keeps 16-byte alignment)
+    constexpr int HS = NB + 1;                   // words per cell histogram (one bank of skew per cell)
     constexpr int CAP = Cfg3<SUBS>::CAP;         // list slots per lane that are sorted
     constexpr int LW = Cfg3<SUBS>::LW;           // words per lane list = most keys a band may hold (MCAP)
     constexpr int Q = 16 / SUBS;                 // buckets per lane of the 16 the walk looks at
@@ -401,8 +404,8 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
     // band population x 16 (running mean): a rebuild is asked for outside [LO_TRIG, HI_TRIG]; whenever the wave
     // rebuilds, every cell outside [LO_ADJ, HI_ADJ] changes its bucket width too (so that it does not ask for
     // a rebuild of its own a few rows later)
-    constexpr int32_t M16_TARGET = 16 * 6, M16_HI_TRIG = 16 * 14, M16_LO_TRIG = 16 * 7 / 2, M16_HI_ADJ = 16 * 10,
-                      M16_LO_ADJ = 16 * 9 / 2;
+    constexpr int32_t M16_TARGET = 16 * 5, M16_HI_TRIG = 16 * 11, M16_LO_TRIG = 16 * 5 / 2, M16_HI_ADJ = 16 * 15 / 2,
+                      M16_LO_ADJ = 16 * 7 / 2;
 
     __shared__ __attribute__((aligned(16))) uint32_t lds[kWaves3 * CPWAVE * HS + 64 * kWaves3 * LW];
 
@@ -481,6 +484,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
     uint32_t hbuilt = 0;      // the cell has had a window before (its bucket width is then adjusted, not re-derived)
     uint32_t st_count = 0, st_extract = 0, st_rows = 0, st_cold = 0, st_fast = 0, st_cell = 0;
     uint32_t st_band = 0, st_rebuild = 0, st_try = 0, st_fail = 0, st_lost = 0, st_cap = 0, st_mm = 0;
+    uint32_t st_rb_inv = 0, st_rb_edge = 0, st_rb_m = 0;
 
     // STATS builds: shader-clock ticks per section of the row loop (a tick waits for the LDS queue to drain, so a
     // section is charged with the LDS work it issued)
@@ -749,11 +753,22 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
                 const bool mmf = bok && mm != mb;
                 bok = bok && mm == mb && lmax <= static_cast<uint32_t>(CAP);
                 // ---- 3. sort the cell's slots, pick entries j and j + 1 ------------------
-                sort_cell<SUBS, CAP>(c, bnd1, bnd2, bnd4);
+                // (most rows no lane holds more than four band keys: the slots 4..7 are then all empty and the
+                // network over four slots per lane does)
                 const uint32_t j = lo - Cb, j1 = j + 1u;
-                const uint32_t va = pick_reg<CAP>(c, j & (CAP - 1)), vb = pick_reg<CAP>(c, j1 & (CAP - 1));
-                const uint32_t xa = cmax<SUBS>((static_cast<uint32_t>(sub) == j / CAP) ? va : 0u);
-                const uint32_t xb = cmax<SUBS>((static_cast<uint32_t>(sub) == j1 / CAP) ? vb : 0u);
+                uint32_t xa, xb;
+                if (CAP == 4 || __all(lmax <= 4u)) {
+                    uint32_t c4[4] = {c[0], c[1], c[2], c[3]};
+                    sort_cell<SUBS, 4>(c4, bnd1, bnd2, bnd4);
+                    const uint32_t va = pick_reg<4>(c4, j & 3u), vb = pick_reg<4>(c4, j1 & 3u);
+                    xa = cmax<SUBS>((static_cast<uint32_t>(sub) == (j >> 2)) ? va : 0u);
+                    xb = cmax<SUBS>((static_cast<uint32_t>(sub) == (j1 >> 2)) ? vb : 0u);
+                } else {
+                    sort_cell<SUBS, CAP>(c, bnd1, bnd2, bnd4);
+                    const uint32_t va = pick_reg<CAP>(c, j & (CAP - 1)), vb = pick_reg<CAP>(c, j1 & (CAP - 1));
+                    xa = cmax<SUBS>((static_cast<uint32_t>(sub) == j / CAP) ? va : 0u);
+                    xb = cmax<SUBS>((static_cast<uint32_t>(sub) == j1 / CAP) ? vb : 0u);
+                }
                 if constexpr (STATS) {
                     st_try += btry ? 1u : 0u;
                     st_fail += (btry && !bok) ? 1u : 0u;
@@ -957,7 +972,12 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
             const bool want = can && (hvalid == 0 || A < static_cast<uint32_t>(EDGE_LO) ||
                                       A > static_cast<uint32_t>(NB - EDGE_HI) || m16 > M16_HI_TRIG || m16 < M16_LO_TRIG);
             if (__any(want)) {
-                if constexpr (STATS) ++st_rebuild;
+                if constexpr (STATS) {
+                    ++st_rebuild;
+                    st_rb_inv += (can && hvalid == 0) ? 1u : 0u;
+                    st_rb_edge += (can && hvalid != 0 && (A < static_cast<uint32_t>(EDGE_LO) || A > static_cast<uint32_t>(NB - EDGE_HI))) ? 1u : 0u;
+                    st_rb_m += (can && hvalid != 0 && (m16 > M16_HI_TRIG || m16 < M16_LO_TRIG)) ? 1u : 0u;
+                }
                 if (can) {
                     // bucket width: from the key spacing on a first build, one step at a time afterwards
                     uint32_t sh;
@@ -983,9 +1003,8 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
                     hbuilt = 1;
                 }
                 // every lane clears its share of the cell's histogram, then adds its keys
-#pragma unroll
-                for (int i = 0; i < NB / SUBS; i += 4)
-                    *reinterpret_cast<uint4*>(hist + sub * (NB / SUBS) + i) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 8
+                for (int i = 0; i < NB / SUBS; ++i) hist[sub * (NB / SUBS) + i] = 0u;
 #pragma unroll
                 for (int y = 0; y < YPS; ++y)
 #pragma unroll
@@ -1050,6 +1069,10 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
         // a list holds; the rest of the failures are lanes with more than CAP band keys)
         atomicAdd(&stats[7], static_cast<unsigned long long>(st_lost) | (static_cast<unsigned long long>(st_cap) << 32));
         if (st_mm) atomicAdd(&stats[3], static_cast<unsigned long long>(st_mm) << 32);
+        // (cells asking for a rebuild, by reason: no window / target near an end / band population out of range)
+        atomicAdd(&stats[1], static_cast<unsigned long long>(st_rb_inv) << 32);
+        atomicAdd(&stats[2], static_cast<unsigned long long>(st_rb_edge) << 32);
+        atomicAdd(&stats[4], static_cast<unsigned long long>(st_rb_m) << 32);
     }
 }
 
@@ -1060,8 +1083,9 @@ typedef void (*Ring3Kernel)(const float*, int64_t, int64_t, int64_t, const uint3
 struct Ring3Entry { int yps, subs; Ring3Kernel fn, fn_stats; };
 #define XMHW_R3(Y, S) {Y, S, clim_ring3_f32<Y, S, false>, clim_ring3_f32<Y, S, true>}
 const Ring3Entry kRing3[] = {
-    XMHW_R3(3, 8), XMHW_R3(4, 8), XMHW_R3(5, 8), XMHW_R3(6, 8),
-    XMHW_R3(5, 4), XMHW_R3(8, 4), XMHW_R3(10, 4),
+    XMHW_R3(2, 8), XMHW_R3(3, 8), XMHW_R3(4, 8), XMHW_R3(5, 8), XMHW_R3(6, 8),
+    XMHW_R3(3, 4), XMHW_R3(4, 4), XMHW_R3(5, 4), XMHW_R3(6, 4), XMHW_R3(7, 4), XMHW_R3(8, 4), XMHW_R3(9, 4),
+    XMHW_R3(10, 4), XMHW_R3(11, 4), XMHW_R3(12, 4),
 };
 #undef XMHW_R3
 const Ring3Entry* find_ring3(int32_t yps, int32_t subs) {
