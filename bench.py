@@ -78,6 +78,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 traffic measurement")
     ap.add_argument("--force-dist", action="store_true", help="build the RCCL communicator and gather even with one rank")
+    ap.add_argument("--no-other", action="store_true", help="skip the other_configs leg (N = 1: float64 configs[2], float32 configs[1], [3], [4] share)")
+    ap.add_argument("--other-cells", type=int, default=0, help="cells of each other_configs run (0: the preset's own grid)")
     ap.add_argument("--cpu-cells", type=int, default=16384)
     ap.add_argument("--parity-cells", type=int, default=512)
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
@@ -111,9 +113,28 @@ def launch_workers(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         running.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--worker"], env=env,
                                         stdout=None if r == 0 else sys.stderr))
+    # poll all workers: the first one that fails takes the others with it (a rank that died early would leave the
+    # rest waiting in the bootstrap accept or inside a collective)
     rc = 0
-    for p in running:
-        rc = max(rc, abs(p.wait()))
+    alive = list(running)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0:
+                rc = max(rc, abs(r))
+                for o in alive:
+                    o.terminate()
+                for o in alive:
+                    try:
+                        o.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        o.kill()
+                alive = []
+                break
     return rc
 
 
@@ -154,6 +175,73 @@ def live_traffic(argv):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"], "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, this run's box and workload"
+
+
+def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, clim_finish, steps=3, parity_cells=24):
+    """One more BASELINE config on this GPU: kernel + finish, `steps` timed steps (HIP events around the ring
+    kernel), parity of a few cells against the oracle.  Same synthetic generator, seeds and shapes as the
+    headline leg."""
+    from xmhw_amd.calendar import add_doy
+    ps = PRESETS[cfg]
+    tstep = ps["tstep"]
+    if tstep:
+        doy = np.tile(np.arange(1, 1461, dtype=np.int64), ps["years"][1] - ps["years"][0] + 1)
+    else:
+        doy = add_doy(np.arange(f"{ps['years'][0]}-01-01", f"{ps['years'][1] + 1}-01-01", dtype="datetime64[D]"))
+    T, C = int(doy.shape[0]), int(args.other_cells) or ps["cells"]
+    isz = 4 if dtype == "f32" else 8
+    w, pctile, width = 5, 90, 31
+    plan = Plan(doy, w, kernel=args.kernel, nchunks=args.chunks, ring2=args.ring2 if isz == 4 else None)
+    D = plan.D
+    bufs = []
+    try:
+        ts = DeviceBuffer(isz * T * C); bufs.append(ts)
+        h.synth_sst(ts.ptr, isz, T, C, C, 0, 20260101 + ps["index"], ps["nan"], 0)
+        th, se = DeviceBuffer(8 * D * C), DeviceBuffer(8 * D * C)
+        out = DeviceBuffer(8 * 2 * D * C)
+        bufs += [th, se, out]
+        e0, e1 = h.event_create(), h.event_create()
+        ring_ms = []
+
+        def step():
+            h.event_record(e0, 0)
+            clim_raw(plan, ts, isz, C, pctile / 100.0, False, th, se)
+            h.event_record(e1, 0)
+            clim_finish(plan, th, se, C, not tstep, True, width, out.ptr, out.ptr + 8 * D * C)
+            h.stream_sync(0)
+            return h.event_elapsed_ms(e0, e1)
+        step()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ring_ms.append(step())
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        idx = np.unique(np.linspace(0, C - 1, parity_cells).astype(np.int64))
+        d_idx = DeviceBuffer.from_array(idx); bufs.append(d_idx)
+        d_s = DeviceBuffer(isz * T * idx.size); bufs.append(d_s)
+        h.gather_cells(ts.ptr, isz, T, C, d_idx.ptr, idx.size, d_s.ptr, idx.size)
+        d_o = DeviceBuffer(8 * 2 * D * idx.size); bufs.append(d_o)
+        h.gather_cells(out.ptr, 8, 2 * D, C, d_idx.ptr, idx.size, d_o.ptr, idx.size)
+        h.stream_sync(0)
+        sample = d_s.to_array((T, idx.size), np.float32 if isz == 4 else np.float64)
+        got = d_o.to_array((2 * D, idx.size), np.float64)
+        _, th0, se0 = fast.threshold_cells_fast(sample, doy, pctile=pctile, windowHalfWidth=w, smoothPercentileWidth=width,
+                                                tstep=tstep)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            err = max(float(np.nanmax(np.abs(got[:D] - th0) / np.abs(th0))), float(np.nanmax(np.abs(got[D:] - se0) / np.abs(se0))))
+        v2 = plan.ring2_in_use() if isz == 4 and plan.kernel == "ring" else -1
+        x64 = plan.f64_mode() if isz == 8 and plan.kernel == "ring" else -1
+        kname = (f"clim_ring2_f32 (variant {v2})" if v2 >= 0 else
+                 f"clim_ring2_f32<double, 64-bit keys> (layout {x64})" if x64 >= 0 else "clim_generic")
+        bpc = T * isz + 2 * D * 8
+        ring_avg = float(np.mean(ring_ms))
+        return {"workload": f"{ps['name']}: {C} cells, T={T}, D={D}, nan_frac={ps['nan']}", "dtype": f"{dtype} in / f64 out",
+                "ms_per_step": ms, "cells_per_s": C / (ms * 1e-3), "kernel": kname, "kernel_avg_launch_ms": ring_avg,
+                "algorithmic_bytes_per_cell": bpc, "roofline_frac": C * bpc / (ring_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "parity_cells": int(idx.size), "parity_max_rel_err": err, "parity_ok": bool(err < 1e-6)}
+    finally:
+        for b in bufs:
+            b.free()
+        plan.destroy()
 
 
 def run(args):
@@ -290,7 +378,7 @@ def run(args):
     x64 = plan.f64_mode() if isz == 8 and plan.kernel == "ring" else -1
     kname = (f"clim_ring2_f32 (variant {v2})" if v2 >= 0 else
              f"clim_ring2_f32<double, 64-bit keys> (layout {x64})" if x64 >= 0 else
-             ("clim_ring_f64" if args.kernel == "ring" else "clim_generic") if isz == 8 else
+             "clim_generic" if isz == 8 else
              ("clim_ring_" + args.dtype if plan.kernel == "ring" else "clim_generic"))
 
     result = {
@@ -333,6 +421,32 @@ def run(args):
                                "kernel_only_cells_per_s": cells_per_step / (kernels_ms * 1e-3),
                                "gathered_bytes_per_step_at_root": float(2 * D * 8 * (cells_per_step - C))}
 
+    # ---- N > 1: the SAME workload on rank 0 alone (the N = 1 default line measures configs[2], a clean grid;
+    # the sharded run measures configs[3]: a speed-up must divide like by like) --------------------------------
+    if rank == 0 and world > 1 and strong and not args.pmc_child:
+        try:
+            f_ts = DeviceBuffer(isz * T * C_total)
+            h.synth_sst(f_ts.ptr, isz, T, C_total, C_total, 0, seed, ps["nan"], 0)
+            f_th, f_se = DeviceBuffer(8 * D * C_total), DeviceBuffer(8 * D * C_total)
+            f_out = DeviceBuffer(8 * 2 * D * C_total)
+
+            def one_step():
+                clim_raw(plan, f_ts, isz, C_total, q, False, f_th, f_se)
+                clim_finish(plan, f_th, f_se, C_total, not tstep, True, width, f_out.ptr, f_out.ptr + 8 * D * C_total)
+                h.stream_sync(0)
+            one_step()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                one_step()
+            single_ms = 1e3 * (time.perf_counter() - t1) / 2
+            result["multi_gpu"]["single_rank_ms_same_workload"] = single_ms
+            result["multi_gpu"]["speedup_vs_single_rank"] = single_ms / ms_per_step
+            for b_ in (f_ts, f_th, f_se, f_out):
+                b_.free()
+        except Exception as e:      # noqa: BLE001 -- e.g. not enough HBM next to the shard: reported, not fatal
+            result["multi_gpu"]["single_rank_ms_same_workload"] = None
+            result["multi_gpu"]["single_rank_error"] = f"{type(e).__name__}: {e}"
+
     # ---- parity (rank 0) ----------------------------------------------------------------------
     def gather_cols(buf, itemsize, rows, ld, idx, dtype, base=0):
         d_idx = DeviceBuffer.from_array(idx.astype(np.int64))
@@ -367,40 +481,48 @@ def run(args):
         err_se = float(np.nanmax(np.abs(got_se - se0) / np.abs(se0)))
         result["parity"] = {"cells": int(idx.size), "max_rel_err_thresh": err_th, "max_rel_err_seas": err_se,
                             "tolerance": 1e-6, "ok": bool(err_th < 1e-6 and err_se < 1e-6)}
-    if rank == 0 and strong and args.parity_cells > 0:
-        # N-rank == 1-rank: 32 columns of EVERY rank's block recomputed on rank 0 alone (the synthetic
-        # input is a function of the global cell index) and compared bit for bit with what arrived
+    if rank == 0 and use_dist and args.parity_cells > 0:
+        # N-rank == 1-rank: for EVERY rank two probes of k columns each -- the first columns of its first slab and
+        # the last columns of its last slab, i.e. always inside one slab -- recomputed on rank 0 alone (the
+        # synthetic input is a function of the global cell index) and compared bit for bit with what arrived in
+        # the gathered buffers.  The number of columns actually compared is reported and must not be 0.
         k = 32
-        bounds = slab_bounds(C_total, world)
-        mini = DeviceBuffer(isz * T * k * world)
+        bounds = slab_bounds(C_total, world) if strong else [(r * C_total, (r + 1) * C_total) for r in range(world)]
+        L = len(slabs) - 1
+        probes = []          # (rank, slab, first column inside the slab, columns, global cell index of the first)
         for r, (a, b) in enumerate(bounds):
-            h.synth_sst(mini.ptr + isz * k * r, isz, T, min(k, b - a), k * world, a + (b - a) // 2 - min(k, b - a) // 2,
-                        seed, ps["nan"], 0)
-        m_th, m_se = DeviceBuffer(8 * D * k * world), DeviceBuffer(8 * D * k * world)
-        m_out = DeviceBuffer(8 * 2 * D * k * world)
-        clim_raw(plan, mini, isz, k * world, q, False, m_th, m_se)
-        clim_finish(plan, m_th, m_se, k * world, not tstep, True, width, m_out.ptr, m_out.ptr + 8 * D * k * world)
-        h.stream_sync(0)
-        one = m_out.to_array((2 * D, k * world), np.float64)
-        same = True
-        for r, (a, b) in enumerate(bounds):
-            kk = min(k, b - a)
-            c0 = (b - a) // 2 - kk // 2                     # column inside rank r's block
-            for i in range(len(slabs)):
-                # rank r's slab i covers its columns [e_i, e_{i+1}); find the slab holding c0..c0+kk
+            w0, wL = int(cols_of_rank[0][r]), int(cols_of_rank[L][r])
+            if w0 > 0:
+                probes.append((r, 0, 0, min(k, w0), a))
+            if wL > 0:
+                kk = min(k, wL)
+                probes.append((r, L, wL - kk, kk, b - kk))
+        ncol = sum(p[3] for p in probes)
+        compared, same = 0, True
+        if ncol:
+            mini = DeviceBuffer(isz * T * ncol)
+            c = 0
+            for (_, _, _, kk, g0) in probes:
+                h.synth_sst(mini.ptr + isz * c, isz, T, kk, ncol, g0, seed, ps["nan"], 0)
+                c += kk
+            m_th, m_se = DeviceBuffer(8 * D * ncol), DeviceBuffer(8 * D * ncol)
+            m_out = DeviceBuffer(8 * 2 * D * ncol)
+            clim_raw(plan, mini, isz, ncol, q, False, m_th, m_se)
+            clim_finish(plan, m_th, m_se, ncol, not tstep, True, width, m_out.ptr, m_out.ptr + 8 * D * ncol)
+            h.stream_sync(0)
+            one = m_out.to_array((2 * D, ncol), np.float64)
+            c = 0
+            for (r, i, c0, kk, _) in probes:
                 cr = cols_of_rank[i]
-                e0 = (b - a) * i // nslab
-                if not (e0 <= c0 and c0 + kk <= e0 + int(cr[r])):
-                    continue
                 off = 2 * D * int(cr[:r].sum()) * 8
-                got = gather_cols(recv[i], 8, 2 * D, int(cr[r]), np.arange(c0 - e0, c0 - e0 + kk), np.float64, base=off)
-                same = same and np.array_equal(got, one[:, k * r:k * r + kk], equal_nan=True)
-                break
-            else:
-                same = same and True                          # block straddles two slabs: skipped
-        result["multi_gpu"]["n_rank_equals_1_rank_bitwise"] = bool(same)
-        for b_ in (mini, m_th, m_se, m_out):
-            b_.free()
+                got = gather_cols(recv[i], 8, 2 * D, int(cr[r]), np.arange(c0, c0 + kk), np.float64, base=off)
+                same = same and bool(np.array_equal(got, one[:, c:c + kk], equal_nan=True))
+                compared += kk
+                c += kk
+            for b_ in (mini, m_th, m_se, m_out):
+                b_.free()
+        result["multi_gpu"]["compared_columns"] = int(compared)
+        result["multi_gpu"]["n_rank_equals_1_rank_bitwise"] = bool(same and compared > 0)
 
     # ---- CPU baseline (rank 0, N = 1) ----------------------------------------------------------
     if pool is not None:
@@ -423,6 +545,22 @@ def run(args):
             "max_rel_diff_vs_gpu": float(np.nanmax(np.abs(g_th - r["thresh"]) / np.abs(r["thresh"]))),
         }
         pool.close()
+    # ---- the other BASELINE configs and float64 (N = 1): 3 steps each, same contract, a small parity sample ---
+    if rank == 0 and world == 1 and not args.no_other and not args.pmc_child and not args.force_dist:
+        for b_ in [ts] + raw_th + raw_se + out:
+            b_.free()
+        release_device_cache()
+        import oracle_fast as fast
+        others = []
+        for ocfg, odt in (("0.25deg", "f64"), ("1deg", "f32"), ("0.25deg_nan", "f32"), ("0.05deg_tstep", "f32")):
+            if ocfg == cfg and odt == args.dtype:
+                continue
+            try:
+                others.append(_other_config(h, np, fast, ocfg, odt, args, DeviceBuffer, Plan, clim_raw, clim_finish))
+            except Exception as e:      # noqa: BLE001 -- reported in the line, the headline number stands
+                others.append({"workload": PRESETS[ocfg]["name"], "dtype": odt, "error": f"{type(e).__name__}: {e}"})
+            release_device_cache()
+        result["other_configs"] = others
     if rank == 0:
         json_out.write(json.dumps(result) + "\n")
         json_out.flush()

@@ -62,6 +62,9 @@ int xmhw_memcpy2d_h2d(void *dev_dst, size_t dpitch, const void *host_src, size_t
 /* the inverse for results: a dense device array into a block of columns of a row-major host array */
 int xmhw_memcpy2d_d2h(void *host_dst, size_t dpitch, const void *dev_src, size_t spitch,
                       size_t width_bytes, size_t height, void *stream);
+/* the same without the wait (one per rank of a gathered buffer, then ONE xmhw_stream_sync)   */
+int xmhw_memcpy2d_d2h_async(void *dst, size_t dpitch, const void *src_dev, size_t spitch, size_t width,
+                            size_t height, void *stream);
 int xmhw_memset(void *dev_dst, int value, size_t bytes, void *stream);
 /* ---- ingest: file bytes -> samples on the device ------------------------ *
  * The reference leaves reading and CF decoding to xarray (docs/gettingstarted.rst:30-33).  Here the
@@ -398,6 +401,10 @@ int xmhw_comm_info(const xmhw_comm *comm, int *rank, int *nranks);
 /* metadata: every rank contributes one int64 (cell counts, table sizes, error flags) and gets
  * all of them back on the host; synchronises `stream`                                           */
 int xmhw_comm_allgather_i64(xmhw_comm *comm, int64_t value, int64_t *out_host, void *stream);
+/* the same in two halves: begin() queues copy-in, collective and copy-out (pinned on both ends) and
+ * returns; end() waits for that work only.  One all-gather in flight per communicator.        */
+int xmhw_comm_allgather_i64_begin(xmhw_comm *comm, int64_t value, void *stream);
+int xmhw_comm_allgather_i64_end(xmhw_comm *comm, int64_t *out_host);
 /* equal-sized byte blocks (land-mask slabs): recv_dev holds nranks * bytes_per_rank; asynchronous */
 int xmhw_comm_allgather_bytes(xmhw_comm *comm, const void *send_dev, void *recv_dev,
                               size_t bytes_per_rank, void *stream);

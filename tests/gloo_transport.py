@@ -16,12 +16,14 @@ class GlooTransport:
         self.size = dist.get_world_size(group)
 
     def allgather_i64(self, value):
+        self.int_collectives = getattr(self, "int_collectives", 0) + 1
         mine = torch.tensor([int(value)], dtype=torch.int64)
         parts = [torch.zeros_like(mine) for _ in range(self.size)]
         dist.all_gather(parts, mine, group=self.group)
         return np.array([int(p.item()) for p in parts], dtype=np.int64)
 
     def allgather_u8(self, arr):
+        self.mask_collectives = getattr(self, "mask_collectives", 0) + 1
         arr = np.ascontiguousarray(arr, dtype=np.uint8)
         counts = self.allgather_i64(arr.shape[0])
         width = int(max(int(counts.max()), 1))
@@ -31,19 +33,24 @@ class GlooTransport:
         dist.all_gather(parts, mine, group=self.group)
         return [parts[r][: int(counts[r])].numpy().copy() for r in range(self.size)]
 
-    def agree(self, error=None):
-        flags = self.allgather_i64(0 if error is None else 1)
-        if flags.any():
+    def agree(self, error=None, value=0):
+        vals = self.allgather_i64(-1 if error is not None else int(value))
+        if (vals < 0).any():
             if error is not None:
                 raise error
-            raise XmhwException(f"sharded run aborted: rank(s) {[int(r) for r in np.nonzero(flags)[0]]} failed")
+            raise XmhwException(f"sharded run aborted: rank(s) {[int(r) for r in np.nonzero(vals < 0)[0]]} failed")
+        return vals
 
-    def gather_columns(self, block, rows, dst=0):
+    def gather_columns(self, block, rows, dst=0, counts=None):
+        self.bulk_collectives = getattr(self, "bulk_collectives", 0) + 1
         if hasattr(block, "to_array"):           # a DeviceBuffer from the HIP stage
-            cols = block.nbytes // (8 * rows) if rows else 0
+            cols = (block.nbytes // (8 * rows) if rows else 0) if counts is None else int(counts[self.rank])
             block = block.to_array((rows, cols), np.float64)
         block = np.ascontiguousarray(block, dtype=np.float64).reshape(rows, -1)
-        counts = self.allgather_i64(block.shape[1])
+        if counts is None:
+            counts = self.allgather_i64(block.shape[1])
+        counts = np.asarray(counts, dtype=np.int64)
+        assert int(counts[self.rank]) == block.shape[1]
         width = int(max(int(counts.max()), 1))
         pad = torch.zeros((rows, width), dtype=torch.float64)
         pad[:, : block.shape[1]] = torch.from_numpy(block)

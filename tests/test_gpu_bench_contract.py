@@ -13,15 +13,20 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                          "--cells", "20000", "--cpu-cells", "16", "--parity-cells", "16"],
+                          "--cells", "20000", "--cpu-cells", "16", "--parity-cells", "16", "--other-cells", "6000"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "other_configs"):
         assert k in d, k
+    # SURVEY 8(d) "report both f32 and f64" + the other BASELINE configs ride the same line
+    oc = d["other_configs"]
+    assert len(oc) == 4 and all("error" not in o for o in oc), oc
+    assert sum(o["dtype"].startswith("f64") for o in oc) == 1
+    assert all(o["parity_ok"] and o["roofline_frac"] > 0 and o["ms_per_step"] > 0 for o in oc), oc
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["unit"] == "cells/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["data"] == "synthetic"
@@ -52,6 +57,8 @@ def test_bench_gather_path_with_one_rank():
     d = json.loads(lines[0])
     assert d["ranks"] == 1 and d["config"]["slabs"] == 4 and "xmhw_gather_blocks" in d["config"]["gather"]
     assert d["multi_gpu"]["step_ms"] > 0 and d["parity"]["ok"] is True
+    # the N-rank == 1-rank check really compares columns (first columns of the first slab, last of the last)
+    assert d["multi_gpu"]["compared_columns"] == 64 and d["multi_gpu"]["n_rank_equals_1_rank_bitwise"] is True
 
 
 @pytest.mark.gpu
@@ -70,3 +77,5 @@ def test_bench_starts_its_own_ranks():
     d = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
     assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["scaling"] == "strong"
     assert d["multi_gpu"]["n_rank_equals_1_rank_bitwise"] is True and d["parity"]["ok"] is True
+    assert d["multi_gpu"]["compared_columns"] == 2 * 2 * 32
+    assert d["multi_gpu"]["single_rank_ms_same_workload"] > 0 and d["multi_gpu"]["speedup_vs_single_rank"] > 0

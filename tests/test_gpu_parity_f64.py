@@ -1,5 +1,7 @@
-"""Parity of the float64 ring kernel (kernels_ring64.hip) against the oracle and
-against the generic kernel, on the same families of inputs as the float32 tests."""
+"""Parity of the float64 paths (the second-generation ring kernel's 64-bit mode where it is instantiated: w = 5;
+the generic kernel elsewhere) against the oracle and against each other, on the same families of inputs as the
+float32 tests.  The round-1 float64 ring kernel is gone (round 3): an explicit ring request on a plan the 64-bit
+mode does not cover is refused, see test_explicit_ring_request_on_an_uncovered_float64_plan_is_refused."""
 import numpy as np
 import numpy.testing as npt
 import pytest
@@ -25,7 +27,8 @@ def _check(dev, x, doy, nchunks=0, rtol=1e-12, **kw):
             kw.get("smoothPercentileWidth", 31), kw.get("tstep", False), kw.get("coldSpells", False))
     # narrowing off: the float64 ring kernel itself (quantised test data is float32-representable
     # and would otherwise take the float32 kernel, which test_float64_narrowing covers)
-    d1, t1, s1 = dev.calc_clim_device(x, doy, *args, kernel="ring", nchunks=nchunks, narrowing=False)
+    kernel = "ring" if kw.get("windowHalfWidth", 5) == 5 else "auto"      # (other windows: the generic kernel)
+    d1, t1, s1 = dev.calc_clim_device(x, doy, *args, kernel=kernel, nchunks=nchunks, narrowing=False)
     d0, t0, s0 = fast.threshold_cells_fast(x, doy, **kw)
     npt.assert_array_equal(d1, d0)
     npt.assert_array_equal(np.isnan(t1), np.isnan(t0))
@@ -205,3 +208,76 @@ def test_float64_random_cases_equal_generic_kernel(dev, seed):
     for i in range(16):
         x, doy, pct, tstep, cold, nchunks = random_f64_case(rng)
         check_f64_case(dev, x, doy, pct, tstep, cold, nchunks, msg=f"seed {seed} case {i}")
+
+
+def _clustered(T, C, seed):
+    """doubles that defeat anything working on a prefix of the key: a few levels per cell, each sample a distinct
+    double within 1e-9 of its level, exact repeats mixed in, and both zeros"""
+    rng = np.random.default_rng(seed)
+    lev = np.round(rng.normal(size=(T, C)) * 2.0) / 2.0 + 10.0
+    x = lev * (1.0 + rng.integers(0, 9, size=(T, C)) * 1e-9)
+    x[rng.random((T, C)) < 0.2] = 10.5                    # exact repeats
+    x[:, 1] = np.where(rng.random(T) < 0.5, 0.0, -0.0)    # a cell of zeros of both signs
+    x[:, 2] = rng.integers(-2, 3, size=T) * 1e-9          # clustered around zero, both signs, with repeats
+    x[rng.random((T, C)) < 0.01] = np.nan
+    return x
+
+
+@pytest.mark.parametrize("years", [(1982, 2021), (2001, 2012), (1960, 2020)])
+@pytest.mark.parametrize("w", [2, 5])
+def test_clustered_doubles_through_every_dispatchable_float64_kernel(dev, years, w):
+    """every float64 kernel the C ABI can dispatch for the plan -- auto and explicit ring (w = 5: the 64-bit mode on
+    8 lanes with the low words in registers or LDS, or on 16 lanes), generic, each with and without the narrowing
+    launches in front -- against the oracle, raw percentile bit for bit (verdict round 2: the withdrawn
+    float64 ring failed exactly this kind of input)"""
+    from xmhw_amd.device import DeviceBuffer, Plan, clim_raw
+    from xmhw_amd._lib import hip
+    h = hip()
+    time, doy = _daily(*years)
+    T, C = time.shape[0], 24
+    x = _clustered(T, C, 7 + w + years[0])
+    _, t0, s0 = fast.raw_clim(x, doy, 0.9, w)
+    D = t0.shape[0]
+    ran = []
+    for kernel in ("auto", "ring", "generic"):
+        for narrowing in (True, False):
+            plan = Plan(doy, w, kernel=kernel, narrowing=narrowing)
+            d_ts = DeviceBuffer.from_array(np.ascontiguousarray(x))
+            th, se = DeviceBuffer(8 * D * C), DeviceBuffer(8 * D * C)
+            try:
+                if kernel == "ring" and plan.f64_mode() < 0:
+                    with pytest.raises(Exception):
+                        clim_raw(plan, d_ts, 8, C, 0.9, False, th, se)
+                    continue
+                clim_raw(plan, d_ts, 8, C, 0.9, False, th, se)
+                h.stream_sync(0)
+                t1, s1 = th.to_array((D, C), np.float64), se.to_array((D, C), np.float64)
+                ran.append((kernel, narrowing, plan.f64_mode()))
+            finally:
+                for b in (d_ts, th, se):
+                    b.free()
+                plan.destroy()
+            npt.assert_array_equal(t1, t0, err_msg=f"{kernel} narrowing={narrowing} w={w}")
+            npt.assert_allclose(s1, s0, rtol=1e-12, atol=1e-12, equal_nan=True)
+    assert any(k == "generic" for k, _, _ in ran)
+    if w == 5:
+        assert any(k == "ring" and m >= 0 for k, _, m in ran), ran
+
+
+def test_explicit_ring_request_on_an_uncovered_float64_plan_is_refused(dev):
+    """w = 2 has no float64 ring kernel any more: XMHW_KERNEL_RING must fail loudly (XMHW_ERR_UNSUPPORTED), auto
+    takes the generic kernel"""
+    from xmhw_amd.device import DeviceBuffer, Plan, clim_raw
+    time, doy = _daily(2001, 2012)
+    x = _series(time.shape[0], 8, 3, dtype=np.float64) + 1e-9
+    plan = Plan(doy, 2, kernel="ring", narrowing=False)
+    d_ts = DeviceBuffer.from_array(x)
+    th, se = DeviceBuffer(8 * 366 * 8), DeviceBuffer(8 * 366 * 8)
+    try:
+        assert plan.f64_mode() < 0
+        with pytest.raises(Exception, match="(?i)unsupported|not available"):
+            clim_raw(plan, d_ts, 8, 8, 0.9, False, th, se)
+    finally:
+        for b in (d_ts, th, se):
+            b.free()
+        plan.destroy()

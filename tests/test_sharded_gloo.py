@@ -175,13 +175,18 @@ def _grid_worker(rank, world, port, outdir):
     g = np.load(os.path.join(ROOT, "tests", "golden", "oisst_2003_2004.npz"))
     time = np.datetime64("2003-01-01") + g["time"].astype("timedelta64[D]")
     temp = GridSeries(g["sst"], ("time", "lat", "lon"), {"time": time, "lat": g["lat"], "lon": g["lon"]})
-    ds = threshold_sharded(temp, GlooTransport(), _grid_compute=_grid_standin, smoothPercentileWidth=11)
+    tr = GlooTransport()
+    ds = threshold_sharded(temp, tr, _grid_compute=_grid_standin, smoothPercentileWidth=11)
+    # north_star's "single gather at the end": ONE bulk collective, ONE int64 exchange (the agreement that every
+    # local stage succeeded, carrying the survivor counts), no mask exchange
+    assert (tr.bulk_collectives, tr.int_collectives, getattr(tr, "mask_collectives", 0)) == (1, 1, 0), \
+        (tr.bulk_collectives, tr.int_collectives, getattr(tr, "mask_collectives", 0))
     if rank == 0:
         np.savez(os.path.join(outdir, "grid.npz"), thresh=ds["thresh"], seas=ds["seas"], lat=ds.coords["lat"],
                  lon=ds.coords["lon"])
     else:
         assert ds is None
-    # an all-land grid raises on EVERY rank (the masks are all-gathered), nobody hangs
+    # an all-land grid raises on EVERY rank (the survivor counts ride the agreement), nobody hangs
     land = GridSeries(np.full((731, 3, 2), np.nan, np.float32), ("time", "lat", "lon"),
                       {"time": time, "lat": np.arange(3), "lon": np.arange(2)})
     try:

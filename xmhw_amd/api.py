@@ -200,6 +200,8 @@ def _threshold(temp, compute, tdim="time", climatologyPeriod=[None, None], pctil
     finally:
         if pad is not None:
             pad.free()
+    if th is None:        # a rank of a sharded run that is not the root: nothing to assemble (xmhw_amd/sharded.py)
+        return None
 
     D = doys.shape[0]
     yrs = cal.years_of(time)

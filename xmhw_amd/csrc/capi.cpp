@@ -67,8 +67,8 @@ struct xmhw_plan {
     int32_t ring2_variant = -2;   // -2: auto (0 or 7, whichever pads fewer tracks); -1: off (round-1 kernel); 0..7: see kernels_ring2.hip
     uint32_t* d_table2 = nullptr;
     uint32_t* d_sflags = nullptr;
-    int32_t yps64 = 0;        // float64 ring kernel tracks-per-lane (16 lanes per cell)
-    uint32_t* d_table64 = nullptr;
+    int32_t yps64 = 0;        // 64-bit mode on 16 lanes per cell, short records: tracks per lane (1..3), 0: none
+    uint32_t* d_table64 = nullptr;   // ... and its step table
     xmhw::DevChunk* d_chunks = nullptr;
     int32_t* d_row_ptr = nullptr;
     int32_t* d_centres = nullptr;
@@ -95,6 +95,7 @@ struct xmhw_plan {
 namespace {
 
 int32_t ring2_resolved(const xmhw_plan* p);
+int32_t ring2_legacy(const xmhw_plan* p);
 
 // float64 samples on the second-generation kernel's 64-bit mode: which layout, if any.  The float32 layout of
 // the plan (8 or 4 lanes per cell) as long as a lane holds at most 4 tracks (44 keys and their low words fit the
@@ -117,7 +118,7 @@ X64Choice x64_choice(const xmhw_plan* p) {
     // (its table: the 16-lane rings' one up to 3 tracks per lane, the plan's own ring2 table beyond -- there the
     // float32 layout is the same 16 lanes)
     if (y16 > 0 && xmhw::ring2_x64_supported(p->host.w, y16, 12) &&
-        (y16 <= 3 ? y16 == xmhw::ring64_pick_yps(p->host.w, p->host.ntracks) : ring2_resolved(p) == 12)) {
+        (y16 <= 3 || ring2_resolved(p) == 12)) {
         c.variant = 12;
         c.yps = y16;
     }
@@ -128,14 +129,13 @@ bool x64_usable(const xmhw_plan* p) { return x64_choice(p).variant >= 0; }
 int32_t resolve_kernel(const xmhw_plan* p, int elem_bytes) {
     if (p->host.kernel_choice == XMHW_KERNEL_GENERIC) return XMHW_KERNEL_GENERIC;
     if (elem_bytes == 8) {
-        // float64: the second-generation kernel's 64-bit mode where it is instantiated.  The round-1 float64
-        // ring (kernels_ring64.hip) is no longer chosen automatically: the randomised cross-check of round 2
-        // (tools/fuzz_ring2.py --dtype f64) found it returning wrong rows on clustered doubles (distinct
-        // values within 1e-9 of each other mixed with repeats); it answers only to an explicit
-        // XMHW_KERNEL_RING request on plans the 64-bit mode does not cover.  Everything else is generic.
+        // float64: the second-generation kernel's 64-bit mode where it is instantiated (w = 5, up to 96 tracks),
+        // the generic kernel otherwise.  The round-1 float64 ring (kernels_ring64.hip) is gone: round 2's
+        // randomised cross-check found it returning wrong rows on clustered doubles and it was never repaired;
+        // an explicit XMHW_KERNEL_RING request on a plan the 64-bit mode does not cover is refused
+        // (XMHW_ERR_UNSUPPORTED) instead of being served by a kernel known to be wrong.
         const bool x64 = x64_usable(p);
-        if (p->host.kernel_choice == XMHW_KERNEL_RING)
-            return (x64 || xmhw::ring64_pick_yps(p->host.w, p->host.ntracks)) ? XMHW_KERNEL_RING : -1;
+        if (p->host.kernel_choice == XMHW_KERNEL_RING) return x64 ? XMHW_KERNEL_RING : -1;
         return x64 ? XMHW_KERNEL_RING : XMHW_KERNEL_GENERIC;
     }
     const int32_t yps = xmhw::ring_pick(p->host.w, p->host.ntracks, elem_bytes, nullptr);
@@ -157,16 +157,43 @@ int32_t auto_chunks(const xmhw_plan* p, int64_t C) {
 // 4-lane layout pads fewer tracks (20 tracks: 4 x 5 exactly against 8 x 3 = 24) and does not spill;
 // both with the lanes' lists merged into a wider window (variants 8 and 10: measured 3-4 % faster than
 // the plain 0 and 7)
+int32_t ring2_legacy(const xmhw_plan* p) {
+    const int32_t y8 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 8);
+    const int32_t y4 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 10);
+    if (y4 && y4 <= 8 && (!y8 || y4 * 4 < y8 * 8)) return 10;
+    if (!y8 && xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 12) >= 4) return 12;
+    return 8;
+}
+
 int32_t ring2_resolved(const xmhw_plan* p) {
     if (p->ring2_variant != -2) return p->ring2_variant;
     // the third-generation kernel (kernels_ring3.hip) on 4 lanes per cell wherever it is instantiated (w = 5,
     // 9..48 tracks): 68 ms against 80 ms on the 0.25 degree / 40 year grid (profiles/r3_*)
     if (xmhw::ring3_pick_yps(p->host.w, p->host.ntracks, 4) > 0) return 21;
-    const int32_t y8 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 8);
-    const int32_t y4 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 10);
-    if (y4 && y4 <= 8 && (!y8 || y4 * 4 < y8 * 8)) return 10;
-    if (!y8 && xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 12) >= 4) return 12;     // 49..96 tracks: 16 lanes per cell
-    return 8;
+    return ring2_legacy(p);
+}
+
+// float64 input that is really float32 (decoded archives): which ring2 variant narrows it, and on which of the
+// plan's tables.  The third-generation kernel has no double instantiation, so a plan whose float32 layout is
+// variant 20 / 21 narrows on the second-generation kernel: its table is the plan's own when the lane layout is
+// the same (4 lanes: variant 10), the 64-bit mode's 8-lane table otherwise.
+struct NarrowChoice { int32_t variant = -1, yps = 0; const uint32_t* table = nullptr; };
+NarrowChoice narrow_choice(const xmhw_plan* p) {
+    NarrowChoice c;
+    int32_t v = ring2_resolved(p);
+    if (v < 0) return c;
+    if (v >= 20) v = ring2_legacy(p);
+    const int32_t subs = xmhw::ring2_subs(v);
+    const int32_t yps = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, v);
+    if (!yps || !xmhw::ring2_narrowing_supported(p->host.w, yps, v)) return c;
+    const uint32_t* t = nullptr;
+    if (p->subs2 == subs && p->yps2 == yps) t = p->d_table2;
+    else if (subs == 8 && p->ypsx == yps) t = p->d_tablex;
+    if (!t) return c;
+    c.variant = v;
+    c.yps = yps;
+    c.table = t;
+    return c;
 }
 
 int upload(xmhw_plan* p, int64_t C) {
@@ -195,7 +222,10 @@ int upload(xmhw_plan* p, int64_t C) {
         p->yps = xmhw::ring_pick(h.w, h.ntracks, 4, &p->subs);
         if (p->yps) HIP_TRY(put(&p->d_table, h.ring_table(p->subs, p->yps)));
         HIP_TRY(put(&p->d_sflags, h.step_flags()));
-        p->yps64 = xmhw::ring64_pick_yps(h.w, h.ntracks);
+        {
+            const int32_t y16 = xmhw::ring2_pick_yps(h.w, h.ntracks, 12);
+            p->yps64 = (y16 >= 1 && y16 <= 3) ? y16 : 0;
+        }
         if (p->yps64) HIP_TRY(put(&p->d_table64, h.ring_table(16, p->yps64)));
     }
     // the second-generation ring kernel's table depends on the variant's lanes per cell
@@ -274,15 +304,15 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
             // kernel (stops at the first lossy sample) -> float64 kernel (runs only if flagged).
             const uint32_t* run_flag = nullptr;
             e = hipSuccess;
-            const int32_t v2 = ring2_resolved(plan);
-            if (plan->narrowing && plan->yps2 && v2 >= 0 && xmhw::ring2_narrowing_supported(h.w, plan->yps2, v2)) {
+            const NarrowChoice nc = narrow_choice(plan);
+            if (plan->narrowing && nc.variant >= 0) {
                 // the second-generation kernel narrows too (the shipped layouts)
                 if (!plan->d_narrow_flag) HIP_TRY(hipMalloc(&plan->d_narrow_flag, sizeof(uint32_t)));
                 e = xmhw::launch_narrow_probe(reinterpret_cast<const double*>(ts), h.T, C, ld, plan->d_narrow_flag, st);
                 if (e == hipSuccess)
-                    e = xmhw::launch_ring2_f32_narrowing(reinterpret_cast<const double*>(ts), C, ld, h.T, plan->d_table2,
+                    e = xmhw::launch_ring2_f32_narrowing(reinterpret_cast<const double*>(ts), C, ld, h.T, nc.table,
                                                          plan->d_sflags, h.step_min, plan->d_chunks, plan->nchunks, h.w,
-                                                         plan->yps2, h.ntracks, v2, q, negate, thresh, seas, ldo, st,
+                                                         nc.yps, h.ntracks, nc.variant, q, negate, thresh, seas, ldo, st,
                                                          plan->d_narrow_flag);
                 run_flag = plan->d_narrow_flag;
             } else if (plan->narrowing && plan->yps) {
@@ -293,8 +323,8 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
                                                     plan->d_narrow_flag);
                 run_flag = plan->d_narrow_flag;
             }
-            // genuinely float64 samples: the second-generation kernel's 64-bit mode where it is instantiated
-            // (XMHW_RING2_F64=0 keeps the round-1 float64 kernel), the round-1 float64 ring otherwise
+            // genuinely float64 samples: the second-generation kernel's 64-bit mode (resolve_kernel() returned
+            // XMHW_KERNEL_RING only because it is instantiated for this plan)
             if (e == hipSuccess) {
                 const X64Choice xc = x64_choice(plan);
                 if (xc.variant >= 0)
@@ -305,9 +335,7 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
                                                h.step_min, plan->d_chunks, plan->nchunks, h.w, xc.yps, h.ntracks, xc.variant,
                                                q, negate, thresh, seas, ldo, st, run_flag);
                 else
-                    e = xmhw::launch_ring_f64(reinterpret_cast<const double*>(ts), C, ld, plan->d_table64,
-                                              h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps64, q,
-                                              negate, thresh, seas, ldo, st, plan->d_stats, run_flag);
+                    return fail(XMHW_ERR_UNSUPPORTED, "no float64 ring kernel for this plan");
             }
         }
     } else {
@@ -317,15 +345,14 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
             // no float64 ring for this plan (e.g. a record of more than 48 tracks), but the float32 ring
             // covers it: float32-representable data still takes the fast kernel, the generic one
             // runs only if the narrowing gave up
-            const int32_t v2 = ring2_resolved(plan);
-            if (plan->narrowing && plan->yps2 && v2 >= 0 && xmhw::ring2_narrowing_supported(h.w, plan->yps2, v2) &&
-                plan->host.kernel_choice == XMHW_KERNEL_AUTO) {
+            const NarrowChoice nc = narrow_choice(plan);
+            if (plan->narrowing && nc.variant >= 0 && plan->host.kernel_choice == XMHW_KERNEL_AUTO) {
                 if (!plan->d_narrow_flag) HIP_TRY(hipMalloc(&plan->d_narrow_flag, sizeof(uint32_t)));
                 e = xmhw::launch_narrow_probe(reinterpret_cast<const double*>(ts), h.T, C, ld, plan->d_narrow_flag, st);
                 if (e == hipSuccess)
-                    e = xmhw::launch_ring2_f32_narrowing(reinterpret_cast<const double*>(ts), C, ld, h.T, plan->d_table2,
+                    e = xmhw::launch_ring2_f32_narrowing(reinterpret_cast<const double*>(ts), C, ld, h.T, nc.table,
                                                          plan->d_sflags, h.step_min, plan->d_chunks, plan->nchunks, h.w,
-                                                         plan->yps2, h.ntracks, v2, q, negate, thresh, seas, ldo, st,
+                                                         nc.yps, h.ntracks, nc.variant, q, negate, thresh, seas, ldo, st,
                                                          plan->d_narrow_flag);
                 run_flag = plan->d_narrow_flag;
             } else if (plan->narrowing && plan->yps && plan->host.kernel_choice == XMHW_KERNEL_AUTO) {

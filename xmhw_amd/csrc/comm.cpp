@@ -96,7 +96,10 @@ int rccl_fail(ncclResult_ e, const char* what) {
 struct xmhw_comm {
     ncclComm_ comm = nullptr;
     int rank = 0, nranks = 1, device = 0;
-    int64_t* d_scratch = nullptr;     // nranks int64 for the metadata all-gather
+    int64_t* d_scratch = nullptr;     // nranks int64 for the metadata all-gather (+ 1: this rank's value)
+    int64_t* h_pinned = nullptr;      // pinned mirror of d_scratch for the begin / end form
+    hipEvent_t ev = nullptr;          // completion of a begun all-gather
+    bool pending = false;
 };
 
 extern "C" {
@@ -131,6 +134,15 @@ int xmhw_comm_create(int rank, int nranks, const void* id, xmhw_comm** comm) {
         delete c;
         return xmhw_set_error_(XMHW_ERR_NOMEM, "hipMalloc of the communicator scratch failed");
     }
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), sizeof(int64_t) * static_cast<size_t>(nranks + 1),
+                      hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) {
+        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+        (void)hipFree(c->d_scratch);
+        r->CommDestroy(c->comm);
+        delete c;
+        return xmhw_set_error_(XMHW_ERR_NOMEM, "pinned scratch / event of the communicator failed");
+    }
     *comm = c;
     return XMHW_OK;
 }
@@ -138,6 +150,8 @@ int xmhw_comm_create(int rank, int nranks, const void* id, xmhw_comm** comm) {
 int xmhw_comm_destroy(xmhw_comm* comm) {
     if (!comm) return XMHW_OK;
     Rccl* r = rccl();
+    if (comm->ev) (void)hipEventDestroy(comm->ev);
+    if (comm->h_pinned) (void)hipHostFree(comm->h_pinned);
     if (comm->d_scratch) (void)hipFree(comm->d_scratch);
     if (comm->comm && r->CommDestroy) (void)r->CommDestroy(comm->comm);
     delete comm;
@@ -161,6 +175,34 @@ int xmhw_comm_allgather_i64(xmhw_comm* comm, int64_t value, int64_t* out_host, v
     HIPC_TRY(hipMemcpyAsync(out_host, comm->d_scratch, sizeof(int64_t) * static_cast<size_t>(comm->nranks),
                             hipMemcpyDeviceToHost, st));
     HIPC_TRY(hipStreamSynchronize(st));
+    return XMHW_OK;
+}
+
+// the same all-gather in two halves: begin() queues the copy in, the collective and the copy out (pinned memory on
+// both ends, nothing waits) and returns; end() waits for that work only and hands the values over.  Host work --
+// or kernels on other streams -- can sit between the two.
+int xmhw_comm_allgather_i64_begin(xmhw_comm* comm, int64_t value, void* stream) {
+    if (!comm) return xmhw_set_error_(XMHW_ERR_INVALID, "comm is NULL");
+    if (comm->pending) return xmhw_set_error_(XMHW_ERR_INVALID, "an all-gather is already in flight on this communicator");
+    Rccl* r = rccl();
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int64_t* mine = comm->d_scratch + comm->nranks;
+    comm->h_pinned[comm->nranks] = value;
+    HIPC_TRY(hipMemcpyAsync(mine, comm->h_pinned + comm->nranks, sizeof(int64_t), hipMemcpyHostToDevice, st));
+    RCCL_TRY(r->AllGather(mine, comm->d_scratch, 1, kNcclInt64, comm->comm, st));
+    HIPC_TRY(hipMemcpyAsync(comm->h_pinned, comm->d_scratch, sizeof(int64_t) * static_cast<size_t>(comm->nranks),
+                            hipMemcpyDeviceToHost, st));
+    HIPC_TRY(hipEventRecord(comm->ev, st));
+    comm->pending = true;
+    return XMHW_OK;
+}
+
+int xmhw_comm_allgather_i64_end(xmhw_comm* comm, int64_t* out_host) {
+    if (!comm || !out_host) return xmhw_set_error_(XMHW_ERR_INVALID, "NULL argument");
+    if (!comm->pending) return xmhw_set_error_(XMHW_ERR_INVALID, "no all-gather in flight on this communicator");
+    HIPC_TRY(hipEventSynchronize(comm->ev));
+    comm->pending = false;
+    std::memcpy(out_host, comm->h_pinned, sizeof(int64_t) * static_cast<size_t>(comm->nranks));
     return XMHW_OK;
 }
 
@@ -223,6 +265,16 @@ int xmhw_memcpy2d_d2h(void* dst, size_t dpitch, const void* src_dev, size_t spit
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPC_TRY(hipMemcpy2DAsync(dst, dpitch, src_dev, spitch, width, height, hipMemcpyDeviceToHost, st));
     HIPC_TRY(hipStreamSynchronize(st));
+    return XMHW_OK;
+}
+
+// the same copy without the wait: the root drains a gathered buffer with one of these per rank and ONE
+// xmhw_stream_sync at the end (dst should be pinned for the copies to overlap each other)
+int xmhw_memcpy2d_d2h_async(void* dst, size_t dpitch, const void* src_dev, size_t spitch, size_t width, size_t height,
+                            void* stream) {
+    if (width == 0 || height == 0) return XMHW_OK;
+    if (!dst || !src_dev || dpitch < width || spitch < width) return xmhw_set_error_(XMHW_ERR_INVALID, "bad pointer/pitch");
+    HIPC_TRY(hipMemcpy2DAsync(dst, dpitch, src_dev, spitch, width, height, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
     return XMHW_OK;
 }
 

@@ -60,21 +60,12 @@ hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
 
 // float64 input through the float32 ring kernel: zeroes narrow_flag, probes the series, runs the
 // kernel with samples narrowed on load; narrow_flag != 0 afterwards: some sample is not float32-
-// representable and the outputs are garbage (queue launch_ring_f64(..., run_flag = narrow_flag) behind)
+// representable and the outputs are garbage (queue launch_ring2_f64(..., run_flag = narrow_flag) behind)
 hipError_t launch_ring_f32_narrowing(const double* ts, int64_t Tn, int64_t C, int64_t ld, const uint32_t* table,
                                      int32_t step_min, const DevChunk* chunks, int32_t nchunks, int32_t w,
                                      int32_t yps, int32_t subs, double q, int negate, double* thresh, double* seas,
                                      int64_t ldo, hipStream_t stream, unsigned long long* stats,
                                      uint32_t* narrow_flag);
-
-// float64 ring kernel: 16 lanes per cell, yps tracks per lane (kernels_ring64.hip); with run_flag
-// the kernel returns at once unless *run_flag != 0
-int32_t ring64_pick_yps(int32_t w, int32_t ntracks);  // 0 if none
-hipError_t launch_ring_f64(const double* ts, int64_t C, int64_t ld, const uint32_t* table,
-                           int32_t step_min, const DevChunk* chunks, int32_t nchunks,
-                           int32_t w, int32_t yps, double q, int negate, double* thresh,
-                           double* seas, int64_t ldo, hipStream_t stream,
-                           unsigned long long* stats = nullptr, const uint32_t* run_flag = nullptr);
 
 // Feb-29 substitution + circular running mean, per cell over present groups
 hipError_t launch_finish(const double* th_in, const double* se_in, int64_t C, int64_t ldo, int32_t D,

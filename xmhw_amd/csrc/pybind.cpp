@@ -361,6 +361,21 @@ PYBIND11_MODULE(_xmhw_hip, m) {
         return reinterpret_cast<uintptr_t>(c);
     });
     m.def("comm_destroy", [](uintptr_t c) { check(xmhw_comm_destroy(reinterpret_cast<xmhw_comm*>(c))); });
+    m.def("comm_allgather_i64_begin", [](uintptr_t c, int64_t value, uintptr_t stream) {
+        check(xmhw_comm_allgather_i64_begin(reinterpret_cast<xmhw_comm*>(c), value, vp(stream)));
+    }, py::arg("comm"), py::arg("value"), py::arg("stream") = 0);
+    m.def("comm_allgather_i64_end", [](uintptr_t c) {
+        int rank = 0, n = 1;
+        check(xmhw_comm_info(reinterpret_cast<xmhw_comm*>(c), &rank, &n));
+        py::array_t<int64_t> out(n);
+        {
+            py::gil_scoped_release r;
+            int rc = xmhw_comm_allgather_i64_end(reinterpret_cast<xmhw_comm*>(c), out.mutable_data());
+            py::gil_scoped_acquire a;
+            check(rc);
+        }
+        return out;
+    });
     m.def("comm_allgather_i64", [](uintptr_t c, int64_t value, uintptr_t stream) {
         xmhw_comm* cc = reinterpret_cast<xmhw_comm*>(c);
         int rank = 0, n = 0;
@@ -392,6 +407,18 @@ PYBIND11_MODULE(_xmhw_hip, m) {
         const size_t isz = static_cast<size_t>(bi.itemsize);
         py::gil_scoped_release r;
         check(xmhw_memcpy2d_d2h(static_cast<char*>(bi.ptr) + isz * col0, isz * static_cast<size_t>(bi.shape[1]), vp(src),
+                                isz * static_cast<size_t>(ncols), isz * static_cast<size_t>(ncols),
+                                static_cast<size_t>(bi.shape[0]), vp(stream)));
+    }, py::arg("dst"), py::arg("col0"), py::arg("ncols"), py::arg("src"), py::arg("stream") = 0);
+    m.def("memcpy2d_d2h_async", [](py::buffer dst, int64_t col0, int64_t ncols, uintptr_t src, uintptr_t stream) {
+        // dense (rows, ncols) device array -> columns [col0, col0 + ncols) of a C-contiguous 2-D host array
+        py::buffer_info bi = dst.request(true);
+        if (bi.ndim != 2 || bi.strides[1] != bi.itemsize || bi.strides[0] != bi.itemsize * bi.shape[1])
+            throw InvalidError("memcpy2d_d2h_async needs a C-contiguous 2-D array");
+        if (col0 < 0 || ncols < 0 || col0 + ncols > bi.shape[1]) throw InvalidError("column range outside the array");
+        const size_t isz = static_cast<size_t>(bi.itemsize);
+        py::gil_scoped_release r;
+        check(xmhw_memcpy2d_d2h_async(static_cast<char*>(bi.ptr) + isz * col0, isz * static_cast<size_t>(bi.shape[1]), vp(src),
                                 isz * static_cast<size_t>(ncols), isz * static_cast<size_t>(ncols),
                                 static_cast<size_t>(bi.shape[0]), vp(stream)));
     }, py::arg("dst"), py::arg("col0"), py::arg("ncols"), py::arg("src"), py::arg("stream") = 0);

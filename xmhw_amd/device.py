@@ -64,7 +64,10 @@ def native_float(a):
 # that runs out of device memory calls it and retries once (xmhw_amd._lib).
 import os as _os
 
+import threading as _threading
+
 _POOL = []
+_POOL_LOCK = _threading.Lock()      # the upload thread of the slab pipeline allocates while the main thread frees
 _POOL_SLOTS = 4
 _POOL_MIN = 1 << 30
 _POOL_MAX_BYTES = int(float(_os.environ.get("XMHW_AMD_POOL_GB", "96")) * (1 << 30))
@@ -75,16 +78,19 @@ def release_device_cache():
     """Return the cached large device buffers (see DeviceBuffer) to the driver; the number of
     bytes released."""
     h = hip()
+    with _POOL_LOCK:
+        entries = list(_POOL)
+        del _POOL[:]
     freed = 0
-    while _POOL:
-        cap, ptr, _ = _POOL.pop()
+    for cap, ptr, _ in entries:
         h.free(ptr)
         freed += cap
     return freed
 
 
 def device_cache_bytes():
-    return sum(cap for cap, _, _ in _POOL)
+    with _POOL_LOCK:
+        return sum(cap for cap, _, _ in _POOL)
 
 
 class DeviceBuffer:
@@ -100,13 +106,17 @@ class DeviceBuffer:
         if not self.nbytes:
             return
         self.device = self._h.get_device()      # the device this buffer lives on, recorded at allocation
-        if self.nbytes >= _POOL_MIN and _POOL:
-            fit = [i for i, (cap, _, d) in enumerate(_POOL)
-                   if d == self.device and self.nbytes <= cap <= 2 * self.nbytes]
-            if fit:
-                i = min(fit, key=lambda k: _POOL[k][0])
-                self.capacity, self.ptr, _ = _POOL.pop(i)
-                return
+        if self.nbytes >= _POOL_MIN:
+            with _POOL_LOCK:          # look-up and removal are one step: another thread may be in here too
+                fit = [i for i, (cap, _, d) in enumerate(_POOL)
+                       if d == self.device and self.nbytes <= cap <= 2 * self.nbytes]
+                if fit:
+                    i = min(fit, key=lambda k: _POOL[k][0])
+                    cap, ptr, dev = _POOL.pop(i)
+                    if cap >= self.nbytes and dev == self.device:
+                        self.capacity, self.ptr = cap, ptr
+                        return
+                    _POOL.append((cap, ptr, dev))
         if _TRACE and self.nbytes >= _POOL_MIN:
             import time as _time
             _t0 = _time.perf_counter()
@@ -133,9 +143,15 @@ class DeviceBuffer:
 
     def free(self):
         if self.ptr:
-            if (self.capacity >= _POOL_MIN and len(_POOL) < _POOL_SLOTS
-                    and device_cache_bytes() + self.capacity <= _POOL_MAX_BYTES):
-                _POOL.append((self.capacity, self.ptr, self.device))
+            kept = False
+            if self.capacity >= _POOL_MIN:
+                with _POOL_LOCK:
+                    if (len(_POOL) < _POOL_SLOTS
+                            and sum(c for c, _, _ in _POOL) + self.capacity <= _POOL_MAX_BYTES):
+                        _POOL.append((self.capacity, self.ptr, self.device))
+                        kept = True
+            if kept:
+                pass
             elif _TRACE and self.capacity >= _POOL_MIN:
                 import time as _time
                 _t0 = _time.perf_counter()
@@ -619,12 +635,12 @@ def _grid_block_on_device(plan, stacked, c0, c1, anynans, pctile, coldSpells, fe
     results stay on the device as a dense (2D, w) block.  Returns (keep, doys, DeviceBuffer, None)."""
     h = hip()
     D, w = plan.D, c1 - c0
-    isz = stacked.dtype.itemsize
-    block = DeviceBuffer(8 * 2 * D * max(w, 1))
+    isz = device_itemsize(stacked)     # the DECODED item size (an int16 CF-packed archive arrives as float32)
+    if w == 0:                         # more ranks than columns: a zero-byte block, nothing to send
+        return np.zeros(0, dtype=bool), plan.doys.copy(), DeviceBuffer(0), None
+    block = DeviceBuffer(8 * 2 * D * w)
     bufs = []
     try:
-        if w == 0:
-            return np.zeros(0, dtype=bool), plan.doys.copy(), block, None
         d_ts, keep = compact_columns(stacked, c0, c1, anynans)
         n = int(keep.sum())
         if d_ts is None:

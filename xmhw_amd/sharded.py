@@ -84,47 +84,56 @@ class RcclTransport:
             recv.free()
         return [flat[r, : int(counts[r])].copy() for r in range(self.size)]
 
-    def agree(self, error=None):
-        """Collective: raise XmhwException on every rank if any rank reports an error."""
-        flags = self.allgather_i64(0 if error is None else 1)
-        if flags.any():
-            bad = [int(r) for r in np.nonzero(flags)[0]]
+    def agree(self, error=None, value=0):
+        """Collective: raise XmhwException on every rank if any rank reports an error; otherwise every rank gets
+        every rank's ``value`` (a non-negative int64: a survivor count, say) from the same exchange."""
+        vals = self.allgather_i64(-1 if error is not None else int(value))
+        if (vals < 0).any():
+            bad = [int(r) for r in np.nonzero(vals < 0)[0]]
             if error is not None:
                 raise error
             raise XmhwException(f"sharded run aborted: rank(s) {bad} failed in their local stage")
+        return vals
 
     # -- bulk -------------------------------------------------------------------------------
-    def gather_columns(self, block, rows, dst=0):
+    def gather_columns(self, block, rows, dst=0, counts=None):
         """Per-rank dense (rows, cols_r) float64 blocks -> (rows, sum cols_r) host array on ``dst``
         (blocks side by side in rank order), None elsewhere.  ``block`` is a DeviceBuffer holding
-        the dense block (the kernels' output, nothing is copied before it travels) or a host array."""
+        the dense block (the kernels' output, nothing is copied before it travels) or a host array.
+        ``counts``: every rank's block width when all ranks already know them (slab_bounds); without it the
+        widths are all-gathered first."""
         own = None
         if isinstance(block, DeviceBuffer):
-            cols = block.nbytes // (8 * rows) if rows else 0
+            cols = (block.nbytes // (8 * rows) if rows else 0) if counts is None else int(counts[self.rank])
             dev = block
         else:
             a = np.ascontiguousarray(block, dtype=np.float64)
             cols = a.shape[1] if a.ndim == 2 else 0
-            dev = own = DeviceBuffer.from_array(a)
-        counts = self.allgather_i64(cols)
+            dev = own = DeviceBuffer.from_array(a) if a.size else None
+        counts = self.allgather_i64(cols) if counts is None else np.asarray(counts, dtype=np.int64)
+        if int(counts[self.rank]) != cols:
+            raise XmhwException(f"rank {self.rank}: block of {cols} columns, {int(counts[self.rank])} announced")
         total = int(counts.sum())
         recv = None
         try:
             if self.rank == dst:
                 recv = DeviceBuffer(8 * rows * max(total, 1))
-            self._h.gather_blocks(self._comm, dev.ptr, rows, cols, recv.ptr if recv else 0,
+            self._h.gather_blocks(self._comm, dev.ptr if dev is not None else 0, rows, cols, recv.ptr if recv else 0,
                                   counts if self.rank == dst else np.zeros(0, dtype=np.int64), dst, self.stream)
-            self._h.stream_sync(self.stream)
             if self.rank != dst:
+                self._h.stream_sync(self.stream)
                 return None
+            # the blocks leave the device behind the collective on the same stream: one 2-D copy per rank (block r
+            # goes straight into columns [c0_r, c0_r + cols_r) of the result), ONE wait at the end
             out = np.empty((rows, total), dtype=np.float64)
             off_bytes, c0 = 0, 0
             for r in range(self.size):
                 n = int(counts[r])
                 if n and rows:
-                    self._h.memcpy2d_d2h(out, c0, n, recv.ptr + off_bytes, self.stream)
+                    self._h.memcpy2d_d2h_async(out, c0, n, recv.ptr + off_bytes, self.stream)
                 off_bytes += 8 * rows * n
                 c0 += n
+            self._h.stream_sync(self.stream)
             return out
         finally:
             if own is not None:
@@ -154,16 +163,35 @@ def init_rccl(rank=None, size=None, local_rank=None, addr=None, port=None):
     return RcclTransport(rank, size, uid)
 
 
-def _stage(transport, fn):
-    """Run a rank-local stage; if it raises on any rank, all ranks raise together."""
+def _stage(transport, fn, value=None):
+    """Run a rank-local stage; if it raises on any rank, all ranks raise together.  ``value`` (a function of
+    the stage's result giving a non-negative int) rides the same exchange: returns (result, every rank's value)."""
     err = None
     out = None
+    v = 0
     try:
         out = fn()
+        if value is not None:
+            v = int(value(out))
     except Exception as e:      # noqa: BLE001 -- reported to every rank, then re-raised
         err = e if isinstance(e, XmhwException) else XmhwException(f"rank {transport.rank}: {type(e).__name__}: {e}")
-    transport.agree(err)
-    return out
+    try:
+        vals = transport.agree(err, v)
+    except Exception:
+        _free_buffers(out)          # another rank failed: what this rank's stage left on the device goes too
+        raise
+    return out if value is None else (out, vals)
+
+
+def _free_buffers(obj):
+    if isinstance(obj, DeviceBuffer):
+        obj.free()
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _free_buffers(v)
+    elif isinstance(obj, (tuple, list)):
+        for v in obj:
+            _free_buffers(v)
 
 
 def make_sharded_compute(transport, dst=0, compute=None):
@@ -199,37 +227,44 @@ def make_sharded_compute(transport, dst=0, compute=None):
 def make_sharded_grid_compute(transport, dst=0, grid_compute=None):
     """A drop-in for device.calc_clim_grid_device: every rank takes a contiguous block of the
     UNCOMPACTED stacked columns, masks / compacts / computes it on its own GPU (no rank runs
-    land_check() over the whole grid, no rank touches another rank's columns of ``stacked``), the
-    keep masks are all-gathered (N bytes: every rank needs the surviving cells for the output grid,
-    and an all-land grid raises on every rank alike), then ONE gather of the (2D, block) results."""
+    land_check() over the whole grid, no rank touches another rank's columns of ``stacked``).  What is
+    exchanged: ONE int64 per rank (the agreement that every local stage succeeded, carrying the rank's number of
+    surviving cells, so that an all-land grid raises on every rank alike) and ONE gather of the (2D, block)
+    results -- the reference's single collect (xmhw/xmhw.py:197, :210-211).  The block widths are slab_bounds(),
+    known to everybody; the surviving cells are read off the gathered block on the root (a dropped cell is an
+    all-NaN column, a kept one has at least one pooled sample and therefore a value).  The other ranks get
+    ``None`` for the arrays: they have nothing to assemble."""
     inner = grid_compute or calc_clim_grid_device
 
     def sharded(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile, smoothPercentileWidth,
                 tstep, coldSpells=False, **extra):
         N = stacked.shape[1]
-        lo, hi = slab_bounds(N, transport.size)[transport.rank]
+        bounds = slab_bounds(N, transport.size)
+        lo, hi = bounds[transport.rank]
 
         def local():
             return inner(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile,
                          smoothPercentileWidth, tstep, coldSpells, columns=(lo, hi), **extra)
 
-        keep_r, doys, th_r, se_r = _stage(transport, local)
-        D = doys.shape[0]
-        keep = np.concatenate(transport.allgather_u8(keep_r.astype(np.uint8))) != 0
-        if not keep.any():
-            raise XmhwException("All points of grid are either land or NaN")     # on every rank alike
-        # the blocks come back on the grid (NaN at dropped cells): each has its slab's width
-        if isinstance(th_r, DeviceBuffer):
-            block = th_r              # device-resident (2D, w) block from the HIP stage
-        else:
-            block = np.concatenate([th_r, se_r], axis=0)
-        both = transport.gather_columns(block, 2 * D, dst)
-        if isinstance(th_r, DeviceBuffer):
-            th_r.free()
+        th_r = None
+        try:
+            (keep_r, doys, th_r, se_r), kept = _stage(transport, local, value=lambda res: int(np.count_nonzero(res[0])))
+            D = doys.shape[0]
+            if int(kept.sum()) == 0:
+                raise XmhwException("All points of grid are either land or NaN")     # on every rank alike
+            # the blocks come back on the grid (NaN at dropped cells): each has its slab's width
+            if isinstance(th_r, DeviceBuffer):
+                block = th_r              # device-resident (2D, w) block from the HIP stage
+            else:
+                block = np.concatenate([th_r, se_r], axis=0)
+            both = transport.gather_columns(block, 2 * D, dst, counts=[b - a for a, b in bounds])
+        finally:
+            if isinstance(th_r, DeviceBuffer):
+                th_r.free()
         if transport.rank != dst:
-            th = se = np.full((D, N), np.nan)
-        else:
-            th, se = both[:D], both[D:]
+            return None, doys, None, None
+        th, se = both[:D], both[D:]
+        keep = ~np.isnan(th).all(axis=0)
         return keep, doys, th, se
 
     return sharded
