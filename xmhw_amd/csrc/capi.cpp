@@ -167,9 +167,11 @@ int32_t ring2_legacy(const xmhw_plan* p) {
 
 int32_t ring2_resolved(const xmhw_plan* p) {
     if (p->ring2_variant != -2) return p->ring2_variant;
-    // the third-generation kernel (kernels_ring3.hip) on 4 lanes per cell wherever it is instantiated (w = 5,
-    // 9..48 tracks): 68 ms against 80 ms on the 0.25 degree / 40 year grid (profiles/r3_*)
-    if (xmhw::ring3_pick_yps(p->host.w, p->host.ntracks, 4) > 0) return 21;
+    // the third-generation kernel (kernels_ring3.hip) on 4 lanes per cell where a lane holds at least 7 tracks
+    // (w = 5, 25..48 tracks): 65 ms against 80 ms on the 0.25 degree / 40 year grid, 4.1 against 4.9 ms on the
+    // 1 degree / 30 year one; with fewer keys per lane its per-row overheads (histogram, walk, sort) outweigh the
+    // cheaper selection (20 tracks, 6-hourly share: 130.6 ms against 121.5 ms for variant 10) -- profiles/r3_*
+    if (xmhw::ring3_pick_yps(p->host.w, p->host.ntracks, 4) >= 7) return 21;
     return ring2_legacy(p);
 }
 
@@ -1074,9 +1076,15 @@ int xmhw_clim_finish(const xmhw_plan* plan, const double* thresh_in, const doubl
     if (thresh_in == thresh_out || seas_in == seas_out)
         return fail(XMHW_ERR_INVALID, "in and out may not alias");
     const xmhw::Plan& h = plan->host;
+    void* flags = nullptr;      // per-column "has an absent group" flags of the one-pass finish kernel
+    if (smooth && smooth_width == 31) {
+        hipError_t se = scratch_get(static_cast<hipStream_t>(stream), static_cast<size_t>(C), &flags);
+        if (se != hipSuccess) return hip_fail(se, "scratch allocation");
+    }
     hipError_t e = xmhw::launch_finish(thresh_in, seas_in, C, ldo, h.D, row_index(h, 59), row_index(h, 60),
                                        row_index(h, 61), feb29_fix, smooth, smooth ? smooth_width : 1,
-                                       thresh_out, seas_out, static_cast<hipStream_t>(stream));
+                                       thresh_out, seas_out, static_cast<hipStream_t>(stream),
+                                       static_cast<uint8_t*>(flags));
     if (e != hipSuccess) return hip_fail(e, "clim_finish launch");
     return XMHW_OK;
 }

@@ -70,7 +70,8 @@ hipError_t launch_ring_f32_narrowing(const double* ts, int64_t Tn, int64_t C, in
 // Feb-29 substitution + circular running mean, per cell over present groups
 hipError_t launch_finish(const double* th_in, const double* se_in, int64_t C, int64_t ldo, int32_t D,
                          int32_t i59, int32_t i60, int32_t i61, int feb29_fix, int smooth,
-                         int32_t width, double* th_out, double* se_out, hipStream_t stream);
+                         int32_t width, double* th_out, double* se_out, hipStream_t stream,
+                         uint8_t* flags = nullptr);      // C bytes of scratch: enables the one-pass kernel (width 31)
 
 template <typename T>
 hipError_t launch_land_mask(const T* ts, int64_t Tn, int64_t C, int64_t ld, int anynans,

@@ -255,12 +255,12 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
     all-land block).  ``resident`` (device.ResidentSeries filled by calc_clim_grid_device for the same host
     array and mask rule): its compacted device slabs are used instead of a second upload."""
     import time as _time
-    from .device import ResidentSeries, _grid_batch, _trace, compact_columns, decode_on_host, device_itemsize, is_packed
+    from .device import ResidentSeries, _grid_batch, _trace, compact_columns, decode_through_device, device_itemsize, is_packed
     _t_all = _time.perf_counter()
     rkey = ResidentSeries.key_of(stacked, anynans) if resident is not None else None
     if is_packed(stacked):
         if intermediate:
-            stacked = decode_on_host(stacked)       # the per-step path compacts on the host anyway
+            stacked = decode_through_device(stacked)       # the per-step path compacts on the host anyway
     else:
         stacked = np.ascontiguousarray(native_float(stacked))
     T, N = stacked.shape

@@ -32,16 +32,17 @@ def is_packed(a):
     return isinstance(a, PackedArray) and a.decode is not None
 
 
-def decode_on_host(a):
-    """numpy restatement of the device decoding (tests, tiny inputs): xarray's CF decoding"""
-    d = a.decode
-    raw = np.asarray(a)
-    out = raw.astype(np.dtype(d["out"]))
-    if d.get("scale") is not None:
-        out = out * np.dtype(d["out"]).type(d["scale"]) + np.dtype(d["out"]).type(d.get("offset") or 0.0)
-    if d.get("fill") is not None:
-        out[raw == raw.dtype.type(d["fill"])] = np.nan
-    return out
+def decode_through_device(a):
+    """A file view (PackedArray: big-endian and / or CF-packed samples) as a decoded host array, decoded by the
+    DEVICE kernel the climatology path uses (upload of the raw bytes, xmhw_decode, download) -- for the per-step
+    detect() outputs, which compact on the host.  (The numpy restatement of the decoding the tests compare the
+    kernel with lives in oracle/ingest_oracle.py; the product has no host decoder.)"""
+    T, N = a.shape
+    buf, isz = upload_columns(a, 0, N)
+    try:
+        return buf.to_array((T, N), np.float32 if isz == 4 else np.float64)
+    finally:
+        buf.free()
 
 
 def native_float(a):

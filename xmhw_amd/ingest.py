@@ -72,9 +72,35 @@ def decode_time(values, units, calendar=""):
     return out
 
 
+def cf_recipe(what, dtype, at):
+    """The device decoder's recipe for a stored variable: xarray's CF decoding rules (float32 for int16 data with
+    float32 packing attributes, float64 otherwise; ``_FillValue`` / ``missing_value`` -> NaN)."""
+    dtype = np.dtype(dtype)
+    kind, isz = dtype.kind, dtype.itemsize
+    scale, offset, fill = at.get("scale_factor"), at.get("add_offset"), at.get("_FillValue", at.get("missing_value"))
+    if kind == "i" and isz == 2:
+        f64 = any(isinstance(x, (float, np.float64)) and not isinstance(x, np.float32) for x in (scale, offset) if x is not None)
+        out = np.float64 if f64 else np.float32
+        if scale is None and offset is not None:
+            scale = 1.0
+    elif kind == "f" and isz in (4, 8):
+        out = np.float32 if isz == 4 else np.float64
+        if scale is not None or offset is not None:
+            scale = 1.0 if scale is None else scale
+    else:
+        raise XmhwException(f"{what} is stored as {dtype}; the device decoder takes int16, float32, float64")
+    return dict(scale=None if scale is None else float(scale), offset=None if offset is None else float(offset),
+                fill=None if fill is None else float(fill), out=np.dtype(out).name)
+
+
 def open_series(path, varname=None, tdim=None):
-    """A (time, y, x) variable of a netCDF classic file as a GridSeries whose values are a zero-copy
+    """A (time, y, x) variable of a netCDF classic file, or of a zarr v2 directory store (a directory holding
+    ``.zgroup`` / ``.zarray``: xmhw_amd/zarr2.py), as a GridSeries whose values are a zero-copy
     PackedArray over the mapped file: nothing is read or decoded on the host."""
+    import os
+    if os.path.isdir(path):
+        from . import zarr2
+        return zarr2.open_series(path, varname, tdim)
     f = netcdf3.File(path)
     cands = [v for v in f.variables.values() if len(v.dims) >= 2 and v.name not in f.dimensions]
     if varname is None:
@@ -92,24 +118,9 @@ def open_series(path, varname=None, tdim=None):
     if var.shape[0] and not np.asarray(inner).flags.c_contiguous:
         raise XmhwException(f"{path}: {var.name}: the non-time dimensions must be contiguous in the file")
     at = var.attrs
-    kind, isz = var.dtype.kind, var.dtype.itemsize
-    scale, offset, fill = at.get("scale_factor"), at.get("add_offset"), at.get("_FillValue", at.get("missing_value"))
-    if kind == "i" and isz == 2:
-        # xarray's CF decoding: float32 for float32 attributes, float64 otherwise
-        f64 = any(isinstance(x, (float, np.float64)) and not isinstance(x, np.float32) for x in (scale, offset) if x is not None)
-        out = np.float64 if f64 else np.float32
-        if scale is None and offset is not None:
-            scale = 1.0
-    elif kind == "f" and isz in (4, 8):
-        out = np.float32 if isz == 4 else np.float64
-        if scale is not None or offset is not None:
-            scale = 1.0 if scale is None else scale
-    else:
-        raise XmhwException(f"{path}: {var.name} is stored as {var.dtype}; the device decoder takes int16, float32, float64")
-    decode = dict(scale=None if scale is None else float(scale), offset=None if offset is None else float(offset),
-                  fill=None if fill is None else float(fill), out=np.dtype(out).name,
-                  # where the bytes live, for uploads that pread() instead of faulting the mapping in
-                  file=dict(fd=f.fileno(), address=f.map_address, length=f.map_length))
+    decode = cf_recipe(f"{path}: {var.name}", var.dtype, at)
+    # where the bytes live, for uploads that pread() instead of faulting the mapping in
+    decode["file"] = dict(fd=f.fileno(), address=f.map_address, length=f.map_length)
     coords, coord_attrs = {}, {}
     for d in var.dims:
         if d in f.variables and f.variables[d].dims == (d,):
