@@ -177,3 +177,38 @@ def test_threshold_from_a_zarr_store_equals_host_decoded(tmp_path, fixture, comp
     npt.assert_array_equal(got["thresh"], ref["thresh"])
     npt.assert_array_equal(got["seas"], ref["seas"])
     npt.assert_array_equal(got.coords["lat"], ref.coords["lat"])
+
+
+def test_threshold_from_the_reference_netcdf4_fixture(fixture):
+    """netCDF-4 / HDF5 (xmhw_amd/hdf5min.py): threshold() straight from the reference's own fixture file -- chunked,
+    shuffled, deflated float32 with dense attribute storage -- equals threshold() on the array extracted from it"""
+    import xmhw_amd
+    from xmhw_amd import ingest
+    sst, lat, lon, time = fixture
+    p = os.path.join(ROOT, "tests", "golden", "ref_testdata", "oisst_2003_2004.nc")
+    got = ingest.threshold_file(p, "sst")
+    t = np.datetime64("2003-01-01T12:00:00") + time.astype("timedelta64[D]")
+    ref = xmhw_amd.threshold_array(sst, t, dims=("time", "lat", "lon"), coords={"lat": lat, "lon": lon},
+                                   calendar="proleptic_gregorian")
+    npt.assert_array_equal(got["thresh"], ref["thresh"])
+    npt.assert_array_equal(got["seas"], ref["seas"])
+    npt.assert_array_equal(got.coords["lat"], ref.coords["lat"])
+    # the all-land fixture raises like land_check() (identify.py:527-528)
+    with pytest.raises(xmhw_amd.XmhwException):
+        ingest.threshold_file(os.path.join(ROOT, "tests", "golden", "ref_testdata", "land.nc"), "sst")
+
+
+@pytest.mark.parametrize("var", ["sst_be_contig", "sst_le_chunked", "f32_chunked"])
+def test_threshold_from_h5py_written_netcdf4_layouts(var):
+    """packed int16 of both byte orders (contiguous: zero-copy window + pread upload; chunked + shuffle + deflate +
+    fletcher32: inflated once on the host), device decode, against the oracle's numpy decoder"""
+    import xmhw_amd
+    from xmhw_amd import GridSeries, ingest
+    from ingest_oracle import decode_packed
+    p = os.path.join(ROOT, "tests", "golden", "hdf5", "packed_earliest.h5")
+    temp = ingest.open_series(p, var)
+    host = decode_packed(temp.values)
+    ref = xmhw_amd.threshold(GridSeries(host, temp.dims, temp.coords, time_encoding=temp.time_encoding), smoothPercentileWidth=11)
+    got = xmhw_amd.threshold(temp, smoothPercentileWidth=11)
+    npt.assert_array_equal(got["thresh"], ref["thresh"])
+    npt.assert_array_equal(got["seas"], ref["seas"])

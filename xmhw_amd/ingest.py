@@ -1,4 +1,5 @@
-"""File -> device ingest for threshold() / detect().
+"""File -> device ingest for threshold() / detect(): netCDF classic (xmhw_amd/netcdf3.py),
+netCDF-4 / HDF5 (xmhw_amd/hdf5min.py) and zarr v2 directory stores (xmhw_amd/zarr2.py).
 
 The reference leaves reading to xarray (``xr.open_dataset(...)['sst']``, docs/gettingstarted.rst:
 30-33) and masks land by ``dropna`` on the stacked array (xmhw/identify.py:520-528).  Here a netCDF
@@ -101,6 +102,10 @@ def open_series(path, varname=None, tdim=None):
     if os.path.isdir(path):
         from . import zarr2
         return zarr2.open_series(path, varname, tdim)
+    with open(path, "rb") as fh:
+        magic = fh.read(8)
+    if magic == b"\x89HDF\r\n\x1a\n":
+        return _open_netcdf4(path, varname, tdim)
     f = netcdf3.File(path)
     cands = [v for v in f.variables.values() if len(v.dims) >= 2 and v.name not in f.dimensions]
     if varname is None:
@@ -146,6 +151,85 @@ def open_series(path, varname=None, tdim=None):
     gs.coord_attrs = coord_attrs
     gs.time_encoding = enc
     gs._file = f                     # keeps the mapping alive
+    return gs
+
+
+def _open_netcdf4(path, varname=None, tdim=None):
+    """netCDF-4 (HDF5) through xmhw_amd/hdf5min.py: a contiguous, unfiltered variable is a zero-copy window of
+    the mapped file (uploaded with pread() like a classic file); a chunked / deflated one -- what OISST and the
+    reference's own fixtures are -- is inflated once into its stored dtype on the host.  Either way byte order,
+    CF packing and the fill value are left to the device decoder."""
+    from . import hdf5min
+    f = hdf5min.File(path)
+    sets = {k: f[k] for k in f.keys()}
+    sets = {k: v for k, v in sets.items() if not v.is_group}
+    cands = [k for k, v in sets.items() if v.shape is not None and len(v.shape) >= 2]
+    if varname is None:
+        if len(cands) != 1:
+            raise XmhwException(f"{path}: name the variable, candidates {cands}")
+        varname = cands[0]
+    if varname not in sets:
+        raise XmhwException(f"{path}: no variable {varname!r}")
+    var = sets[varname]
+    # dimension names: netCDF-4 numbers its dimensions (_Netcdf4Dimid on the dimension scales) and lists a
+    # variable's dimension ids in _Netcdf4Coordinates; without that attribute the scales are matched by length
+    scales = {k: v for k, v in sets.items() if v.attrs.get("CLASS") == "DIMENSION_SCALE" and v.shape is not None and len(v.shape) == 1}
+    by_id = {int(v.attrs["_Netcdf4Dimid"]): k for k, v in scales.items() if "_Netcdf4Dimid" in v.attrs}
+    ids = var.attrs.get("_Netcdf4Coordinates")
+    dims = None
+    if ids is not None:
+        ids = [int(i) for i in np.atleast_1d(ids)]
+        if len(ids) == len(var.shape) and all(i in by_id for i in ids):
+            dims = tuple(by_id[i] for i in ids)
+    if dims is None:
+        dims = []
+        for n in var.shape:
+            m = [k for k, v in scales.items() if v.shape[0] == n and k not in dims]
+            dims.append(m[0] if len(m) == 1 else f"dim_{len(dims)}")
+        dims = tuple(dims)
+    tdim = tdim or dims[0]
+    if dims[0] != tdim:
+        raise XmhwException(f"{path}: {varname} must have {tdim!r} as its first (slowest) dimension, has {dims}")
+    at = {}
+    for k, v in var.attrs.items():
+        if k in ("DIMENSION_LIST", "_Netcdf4Coordinates", "_Netcdf4Dimid", "CLASS", "NAME", "REFERENCE_LIST") or v is None:
+            continue
+        at[k] = v[0] if isinstance(v, np.ndarray) and v.size == 1 else v
+    for k in ("_FillValue", "missing_value"):
+        if k in at and isinstance(at[k], (float, np.floating)) and np.isnan(at[k]):
+            del at[k]                                    # NaN as the fill value of float data: nothing to replace
+    decode = cf_recipe(f"{path}: {varname}", var.dtype, at)
+    off = var.contiguous_offset()
+    if off is not None:
+        data = f.window(off, var.dtype, var.shape)
+        decode["file"] = dict(fd=f.fileno(), address=f.map_address, length=f.map_length)
+    else:
+        data = var.read()
+    coords, coord_attrs = {}, {}
+    for i, d in enumerate(dims):
+        cv = sets.get(d)
+        if cv is not None and cv.shape == (var.shape[i],) and "netCDF dimension but not" not in str(cv.attrs.get("NAME", "")):
+            coords[d] = cv.read().astype(cv.dtype.newbyteorder("="))
+            coord_attrs[d] = {k: v for k, v in cv.attrs.items()
+                              if v is not None and k not in ("CLASS", "NAME", "REFERENCE_LIST", "_Netcdf4Dimid", "_FillValue")}
+        else:
+            coords[d] = np.arange(var.shape[i])
+            coord_attrs[d] = {}
+    tat = coord_attrs.get(tdim, {})
+    enc = {}
+    if "units" in tat and " since " in str(tat["units"]):
+        cal = str(tat.get("calendar", ""))
+        coords[tdim] = decode_time(coords[tdim], tat["units"], cal)
+        if cal:
+            enc["calendar"] = cal
+    gs = GridSeries.__new__(GridSeries)
+    gs.values = PackedArray(data, decode)
+    gs.dims = dims
+    gs.coords = coords
+    gs.attrs = {k: v for k, v in at.items() if k not in ("scale_factor", "add_offset", "_FillValue", "missing_value")}
+    gs.coord_attrs = coord_attrs
+    gs.time_encoding = enc
+    gs._file = f
     return gs
 
 
