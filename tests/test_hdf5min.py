@@ -38,13 +38,11 @@ def test_reference_oisst_fixture_equals_the_extracted_golden():
 def test_reference_clim_fixtures(name, npz):
     f = hdf5min.File(os.path.join(G, "ref_testdata", name))
     g = np.load(os.path.join(G, npz))
-    suffix = "_nosmooth" if "nosmooth" in name else ""
+    prefix = "nosmooth_" if "nosmooth" in name else "smooth_"
     for k in ("thresh1", "thresh2", "seas1", "seas2"):
-        key = [c for c in g.files if c.startswith(k) and c.endswith(suffix) and ("nosmooth" in c) == bool(suffix)]
         a = f[k].read()
         assert a.shape == (366,) and a.dtype == np.dtype("<f8")
-        if key:
-            npt.assert_array_equal(a, g[key[0]])
+        npt.assert_array_equal(a, g[prefix + k])
 
 
 def test_open_series_on_the_reference_fixture():

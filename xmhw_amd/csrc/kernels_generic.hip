@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void clim_finish_tiled(const double* __restric
 // clim_finish_stream<W>: Feb-29 + circular running mean of width W for columns WITHOUT absent groups, every
 // raw row read ONCE (+ W - 1 halo rows per part).  Thread = cell (512 contiguous bytes per wave and row); the
 // W rows of the current window sit in registers (the row loop is unrolled W times, so that the slot of a row
-// is static); one load per output row, issued W rows ahead.  The window sum slides (+ lead - trail) and is
+// is static); one load per output row, issued one row ahead.  The window sum slides (+ lead - trail) and is
 // re-summed from the registers, in window order, at every row that is a multiple of W: a part boundary is
 // such a row, so the result does not depend on how the doy axis is cut into parts, and parts depend on D
 // only -- N-rank and 1-rank runs stay bit-identical.  A column that holds a NaN (an absent group: the
@@ -420,18 +420,11 @@ __global__ __launch_bounds__(256) void clim_finish_stream(const double* __restri
         win[k] = load(r);
         r = (r + 1 == D) ? 0 : r + 1;
     }
-    // the rows that enter the window during the next W steps are requested W steps ahead (a second set of W
-    // registers): W loads in flight per thread, which is what keeps HBM busy at two waves per SIMD
-    double nxt[W];
-#pragma unroll
-    for (int k = 0; k < W; ++k) {
-        if (d0 + k < d1) {
-            nxt[k] = load(r);
-            r = (r + 1 == D) ? 0 : r + 1;
-        } else {
-            nxt[k] = 0.0;
-        }
-    }
+    // (requesting the rows W steps ahead instead -- a second set of W registers, W loads in flight per thread at two
+    // waves per SIMD -- measured SLOWER: 5.08 against 3.59 ms at D = 366, 15.3 against 10.0 ms at D = 1460; the walk
+    // down a column touches a new 8 MB-strided page per row, and more of them in flight did not help)
+    double pre = load(r);                          // the row after the first window, one step ahead
+    r = (r + 1 == D) ? 0 : r + 1;
     const double wd = static_cast<double>(W);
     for (int32_t base = d0; base < d1; base += W) {
         double s = win[0];
@@ -442,11 +435,9 @@ __global__ __launch_bounds__(256) void clim_finish_stream(const double* __restri
             const int32_t d = base + k;
             if (d < d1) {
                 out[static_cast<int64_t>(d) * ld] = s / wd;
-                const double nv = nxt[k];
-                if (d + W < d1) {                  // the row step d + W will slide in
-                    nxt[k] = load(r);
-                    r = (r + 1 == D) ? 0 : r + 1;
-                }
+                const double nv = pre;
+                pre = load(r);
+                r = (r + 1 == D) ? 0 : r + 1;
                 s -= win[k];
                 win[k] = nv;
                 s += nv;
