@@ -154,7 +154,9 @@ __device__ __forceinline__ uint32_t count_le11_3(const RingT& r, uint32_t p, uin
 // pairs), then each mask becomes EXEC for one ds_write + v_add: 3 vector instructions, one scalar and one
 // LDS instruction per key.  (Branching over the ds_write and the v_add where no lane of the wave has a band key
 // at that ring position -- about half of the positions -- made the pass slower: 5,290 against 3,930 cycles per
-// wave-row; tools/ubench_lds.hip: a taken s_cbranch behind an EXEC write costs as much as the masked write.)
+// wave-row; tools/ubench_lds.hip: a taken s_cbranch behind an EXEC write costs as much as the masked write.  Taking
+// the positions in PAIRS -- one v_cndmask + ONE masked ds_write per pair unless some lane matches at both -- halves
+// the LDS instructions and was slower too: 5,920 cycles, kernel 71.5 against 65.0 ms; profiles/r3_compaction_variants.txt)
 // EXEC is saved and restored (the call sites are wave-uniform).
 template <class RingT>
 __device__ __forceinline__ void compact11(const RingT& r, uint32_t e0, uint32_t w, uint32_t& p) {
