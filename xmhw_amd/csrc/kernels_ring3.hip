@@ -462,9 +462,12 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
 #pragma unroll
         for (int y = 0; y < YPS; ++y) tix[y] += (y == YPS - 1) ? last_step : 1u;
     };
+    // (the row stride as a 32-bit number -- the launcher refuses ld >= 2^32 -- so that a sample address is ONE
+    // v_mad_u64_u32 instead of the two the compiler needs for a 64-bit stride: 30 fewer 64-bit instructions per row)
+    const uint32_t ld32 = static_cast<uint32_t>(ld);
     auto request = [&](float (&x)[YPS]) {
 #pragma unroll
-        for (int y = 0; y < YPS; ++y) x[y] = col[static_cast<int64_t>(tix[y]) * ld];
+        for (int y = 0; y < YPS; ++y) x[y] = col[static_cast<uint64_t>(tix[y]) * ld32];
     };
 
     float x_raw[YPS];
@@ -1114,7 +1117,7 @@ hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
                             double* thresh, double* seas, int64_t ldo, hipStream_t stream,
                             unsigned long long* stats) {
     const Ring3Entry* e = w == 5 ? find_ring3(yps, subs) : nullptr;
-    if (!e) return hipErrorInvalidValue;
+    if (!e || ld >= (int64_t(1) << 32)) return hipErrorInvalidValue;
     if (C <= 0 || nchunks <= 0) return hipSuccess;
     const int64_t cells_per_block = (64 / subs) * kWaves3;
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
