@@ -146,15 +146,17 @@ int xmhw_plan_table(const xmhw_plan *plan, int32_t years_per_lane, uint32_t *tab
  * enable != 0 allocates the counters; out16 receives 16 values                        */
 int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out16);
 
-/* second-generation float32 ring kernel (w = 5, 9..96 tracks; xmhw_amd/csrc/kernels_ring2.hip),
- * used by default where it is instantiated.  variant: -2 = auto (the default: 8, or 10 where the
- * 4-lane layout pads fewer tracks, e.g. 20 tracks), -1 = off (round-1 kernel), 0 = 8 lanes per
- * cell with 32-bit count passes and a 5-key extraction list, 7 = the same with 4 lanes per cell,
- * 8 / 10 = 0 / 7 with the lanes' lists merged into the cell's 8 / 7 nearest keys (a wider window of
- * acceptable ranks: fewer count passes), 1..6, 9, 11 = measured alternatives kept for the record
- * (8/16-bit code rings, other list widths), 12 = 16 lanes per cell (49..96 tracks).  The environment
- * variable XMHW_RING2 sets the default
- * of new plans.  All variants return bit-identical thresh.                                       */
+/* float32 ring kernels for w = 5 (what replaces xmhw/xmhw.py:184-197 + identify.py:212-270 per cell).
+ * variant: -2 = auto (the default): 21 -- the third-generation kernel (xmhw_amd/csrc/kernels_ring3.hip:
+ * per-cell histogram in LDS, band compaction, sort across the lanes of a cell) on 4 lanes per cell -- where a
+ * lane holds at least 7 tracks (25..48 tracks), otherwise the second-generation kernel
+ * (kernels_ring2.hip, 9..96 tracks): 8, or 10 where the 4-lane layout pads fewer tracks (e.g. 20 tracks),
+ * 12 = 16 lanes per cell (49..96 tracks).  -1 = off (round-1 kernel); 0 / 7 = 8 / 4 lanes per cell with
+ * 32-bit count passes and a 5-key extraction list (8 / 10 are these with the lanes' lists merged into the
+ * cell's 8 / 7 nearest keys); 20 = the third-generation kernel on 8 lanes per cell; 1..6, 9, 11 = measured
+ * alternatives of round 2 (8/16-bit code rings, other list widths), compiled with -DXMHW_RING2_EXPERIMENTS
+ * only.  The environment variable XMHW_RING2 sets the default of new plans.  All variants return
+ * bit-identical thresh.                                                                            */
 int xmhw_plan_set_ring2(xmhw_plan *plan, int32_t variant);
 /* the variant float32 input of this plan will run on, -1 if the round-1 / generic kernel */
 int xmhw_plan_ring2_in_use(const xmhw_plan *plan, int32_t *variant);

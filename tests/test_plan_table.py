@@ -95,16 +95,20 @@ def test_too_many_tracks_falls_back_to_generic():
 
 
 def test_ring2_layout_choice():
-    """the second-generation float32 ring kernel: 8 lanes per cell unless the 4-lane layout pads fewer
-    tracks (capi.cpp: ring2_resolved); outside its instantiations the round-1 kernel runs (-1)"""
+    """which float32 ring kernel a plan runs on (capi.cpp: ring2_resolved): the third-generation kernel on 4 lanes
+    per cell (21) where a lane holds at least 7 tracks (25..48 tracks); otherwise the second-generation one -- 8
+    lanes per cell unless the 4-lane layout pads fewer tracks; outside both the round-1 kernel runs (-1)"""
     from xmhw_amd.device import Plan
 
     def years(n, w=5, ring2=None):
         t = np.arange("1982-01-01", f"{1982 + n}-01-01", dtype="datetime64[D]")
         return Plan(ora.add_doy(t), w, ring2=ring2)
 
-    assert years(40).ring2_in_use() == 8                      # 8 x 5 = 40 tracks exactly
-    assert years(30).ring2_in_use() == 8                      # 8 x 4 and 4 x 8 both pad 2: a tie goes to 8 lanes
+    assert years(40).ring2_in_use() == 21                     # 4 x 10 = 40 tracks: ring3
+    assert years(30).ring2_in_use() == 21                     # 4 x 8 (2 padded)
+    assert years(25).ring2_in_use() == 21 and years(48).ring2_in_use() == 21      # 7 .. 12 tracks per lane
+    assert years(24).ring2_in_use() == 8                      # 6 tracks per lane at 4 lanes: ring2 (8 x 3 = 24 exactly)
+    assert years(40, ring2=8).ring2_in_use() == 8 and years(40, ring2=20).ring2_in_use() == 20      # forced
     assert years(20).ring2_in_use() == 10                     # 4 x 5 = 20 exactly, 8 x 3 would pad 4
     assert Plan(np.tile(np.arange(1, 1461), 20), 5).ring2_in_use() == 10     # config 5's tstep axis
     assert years(20, ring2=0).ring2_in_use() == 0             # forced
@@ -112,7 +116,7 @@ def test_ring2_layout_choice():
     assert years(40, ring2=-1).ring2_in_use() == -1           # round-1 kernel
     assert years(10).ring2_in_use() == 10                     # 10 tracks: 4 x 3 = 12 slots against 8 x 2 = 16
     assert years(16).ring2_in_use() == 8                      # 16 tracks: 8 x 2 = 4 x 4 exactly: a tie goes to 8 lanes
-    assert years(43).ring2_in_use() == 8                      # 41..48 tracks (OISST 1982-2024): 8 x 6
+    assert years(43).ring2_in_use() == 21                     # 41..48 tracks (OISST 1982-2024): 4 x 11
     assert years(49).ring2_in_use() == 12 and years(96).ring2_in_use() == 12   # 49..96 tracks: 16 lanes per cell
     assert years(97).ring2_in_use() == -1                     # beyond: round-1 kernel (32 lanes per cell)
     assert years(40, ring2=12).ring2_in_use() == -1           # (that layout's short-record entries are float64-only)
