@@ -508,6 +508,10 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
         return minu3(__builtin_elementwise_sub_sat(key, hbase) >> hshift, static_cast<uint32_t>(NB - 1));
     };
 
+    // inputs of the epilogue of the row this lane finishes (see below)
+    uint32_t e_alo = 0, e_ahi = 0, e_n = 0;
+    double e_total = 0.0, e_g = 0.0;
+
     uint32_t hmask = 0;
     int32_t s = ch.warm_start;
     uint32_t sf_cur = __builtin_amdgcn_readfirstlane(sflags[s - step_min]);
@@ -942,12 +946,31 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
 
             tick(5);
             if constexpr (STATS) ++st_rows;
-            double th = make_nan(), se = make_nan();
-            if (n > 0) {
-                const double v_lo = static_cast<double>(__uint_as_float(bits_of_key3(alo)));
-                const double v_hi = static_cast<double>(__uint_as_float(bits_of_key3(ahi)));
-                th = numpy_lerp(v_lo, v_hi, g);
-                se = total / static_cast<double>(n);
+            // The epilogue (key -> value, numpy's lerp, the float64 division, the two stores) is the same ~50
+            // instructions for every lane of a cell: the lanes take turns -- lane `sub` keeps the inputs of the row
+            // whose number is sub modulo SUBS, and once per SUBS rows (and at the end of the chunk) every lane
+            // finishes ITS row.  Same arithmetic per cell-row, a quarter (an eighth) of the instructions.
+            const uint32_t eph = static_cast<uint32_t>(s - ch.begin) & static_cast<uint32_t>(SUBS - 1);
+            if (static_cast<uint32_t>(sub) == eph) {
+                e_alo = alo;
+                e_ahi = ahi;
+                e_n = n;
+                e_total = total;
+                e_g = g;
+            }
+            if (eph == static_cast<uint32_t>(SUBS - 1) || s + 1 == ch.end) {
+                double th = make_nan(), se = make_nan();
+                if (e_n > 0) {
+                    const double v_lo = static_cast<double>(__uint_as_float(bits_of_key3(e_alo)));
+                    const double v_hi = static_cast<double>(__uint_as_float(bits_of_key3(e_ahi)));
+                    th = numpy_lerp(v_lo, v_hi, e_g);
+                    se = e_total / static_cast<double>(e_n);
+                }
+                if (static_cast<uint32_t>(sub) <= eph && cell_ok) {
+                    const int64_t row = static_cast<int64_t>(s) - static_cast<int64_t>(eph) + sub;
+                    thresh[row * ldo + cell] = th;
+                    seas[row * ldo + cell] = se;
+                }
             }
             if (wallc) {
                 // (rows that do not pool every track leave the carried pivot and the window alone: both count
@@ -965,10 +988,6 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
                     Fc = 0;
                     hvalid = 0;
                 }
-            }
-            if (sub == 0 && cell_ok) {
-                thresh[static_cast<int64_t>(s) * ldo + cell] = th;
-                seas[static_cast<int64_t>(s) * ldo + cell] = se;
             }
 
             tick(6);
