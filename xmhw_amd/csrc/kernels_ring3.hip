@@ -519,17 +519,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
     while (s < ch.end) {
     bool rotate = false;
     for (; s < ch.end && !rotate; ++s) {
-        // ---- prefetch: the samples of step s+1 (consumed one row later) ------------------
-        float x_nxt[YPS];
         const uint32_t sf_nn = s + 2 < ch.end ? __builtin_amdgcn_readfirstlane(sflags[s + 2 - step_min]) : 0u;
-        if (s + 1 < ch.end) {
-            if (sf_nxt & 2u) advance();
-            else point_at(s + 1);
-            request(x_nxt);
-        } else {
-#pragma unroll
-            for (int y = 0; y < YPS; ++y) x_nxt[y] = 0.0f;
-        }
         const uint32_t sf = sf_cur;
 
         // ---- what this step pushes ------------------------------------------------------
@@ -612,6 +602,13 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
             clean = !__any(nval != full_valid);
         }
         m = (m + 1 == R) ? 0 : m + 1;
+        // ---- prefetch: the samples of step s+1 are requested as soon as this row's are used up, into the SAME
+        // registers (no second buffer, no copies; they have the rest of the row -- the selection -- to arrive)
+        if (s + 1 < ch.end) {
+            if (sf_nxt & 2u) advance();
+            else point_at(s + 1);
+            request(x_raw);
+        }
         tick(0);
 
         // ---- select + output (not during warm-up) ---------------------------------
@@ -1054,8 +1051,6 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
 
         tick(7);
         if ((s & 31) == 31) __syncthreads();
-#pragma unroll
-        for (int y = 0; y < YPS; ++y) x_raw[y] = x_nxt[y];
         sf_cur = sf_nxt;
         sf_nxt = sf_nn;
     }
