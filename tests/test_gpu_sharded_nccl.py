@@ -6,7 +6,8 @@
    multi-GPU node runs it).
  * two ranks SHARING one GPU, host transport (tests/gloo_transport.py), real HIP stages: every rank
    masks / compacts / computes its own column block and, in detect, addresses the climatologies at
-   a non-zero column offset (the k0 > 0 path of detect_grid).
+   a non-zero column offset (the k0 > 0 path of detect_grid); detect(intermediate=True) too, its per-step
+   planes gathered block by block.
 Results must be bit-identical to the single-process calls."""
 import os
 import socket
@@ -58,6 +59,7 @@ ds = threshold_sharded(temp, tr)
 ref = xmhw_amd.threshold(temp)
 th, se = climatology_series(ref, "thresh"), climatology_series(ref, "seas")
 m1 = detect_sharded(temp, th, se, tr)
+mi = detect_sharded(temp, th, se, tr, intermediate=True)      # the per-step planes, gathered block by block
 if rank == 0:
     np.testing.assert_array_equal(ds["thresh"], ref["thresh"])
     np.testing.assert_array_equal(ds["seas"], ref["seas"])
@@ -66,9 +68,16 @@ if rank == 0:
     np.testing.assert_array_equal(m1.offsets, m0.offsets)
     np.testing.assert_array_equal(m1.keep, m0.keep)
     assert m0.n_events > 0
+    m0i, i0 = xmhw_amd.detect(temp, th, se, intermediate=True)
+    m1i, i1 = mi
+    np.testing.assert_array_equal(m1i.table, m0i.table)
+    assert set(i1.data_vars) == set(i0.data_vars)
+    for k, v in i0.data_vars.items():
+        assert i1.data_vars[k].dtype == v.dtype, k
+        np.testing.assert_array_equal(i1.data_vars[k], v, err_msg=k)
     print("sharded ok", mode, world, m0.n_events)
 else:
-    assert ds is None and m1 is None
+    assert ds is None and m1 is None and mi is None
 if mode == "rccl":
     tr.close()
 else:

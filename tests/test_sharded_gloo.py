@@ -243,7 +243,7 @@ def _detect_grid_standin(stacked, anynans, seas, thresh, doy, doys, minDuration=
         return dict(table=np.zeros((0, 31)), offsets=np.zeros(1, dtype=np.int64), inter=None, keep=keep)
     r = oracle_detect_cells(np.ascontiguousarray(sub), np.ascontiguousarray(seas[:, k0:k0 + n]),
                             np.ascontiguousarray(thresh[:, k0:k0 + n]), doy, doys, minDuration, joinGaps, maxGap,
-                            coldSpells, False)
+                            coldSpells, intermediate)
     r["keep"] = keep
     return r
 
@@ -261,10 +261,16 @@ def _detect_grid_worker(rank, world, port, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     temp, th, se = _detect_inputs()
     out = detect_sharded(temp, th, se, GlooTransport(), _grid_compute=_detect_grid_standin, minDuration=4, maxGap=1)
+    # the same with the per-step planes (xmhw/xmhw.py:354-356): gathered block by block beside the tables
+    out_i = detect_sharded(temp, th, se, GlooTransport(), _grid_compute=_detect_grid_standin, minDuration=4, maxGap=1,
+                           intermediate=True)
     if rank == 0:
-        np.savez(os.path.join(outdir, "detect_grid.npz"), table=out.table, offsets=out.offsets, keep=out.keep)
+        mhw_i, inter = out_i
+        np.testing.assert_array_equal(mhw_i.table, out.table)
+        np.savez(os.path.join(outdir, "detect_grid.npz"), table=out.table, offsets=out.offsets, keep=out.keep,
+                 **{"inter_" + k: v for k, v in inter.data_vars.items()})
     else:
-        assert out is None
+        assert out is None and out_i is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -281,11 +287,14 @@ def test_sharded_detect_grid_path_equals_single(tmp_path, world):
     mp.spawn(_detect_grid_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "detect_grid.npz")
     temp, th, se = _detect_inputs()
-    mhw = _detect(temp, th, se, oracle_detect_cells, minDuration=4, maxGap=1)
+    mhw, inter = _detect(temp, th, se, oracle_detect_cells, minDuration=4, maxGap=1, intermediate=True)
     assert mhw.n_events > 0
     np.testing.assert_array_equal(got["keep"], mhw.keep)
     np.testing.assert_array_equal(got["offsets"], mhw.offsets)
     np.testing.assert_array_equal(got["table"], mhw.table)
+    for k, v in inter.data_vars.items():
+        assert got["inter_" + k].dtype == v.dtype, k
+        np.testing.assert_array_equal(got["inter_" + k], v, err_msg=k)
 
 
 def _failing_worker(rank, world, port, outdir):

@@ -258,12 +258,18 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
     from .device import ResidentSeries, _grid_batch, _trace, compact_columns, decode_through_device, device_itemsize, is_packed
     _t_all = _time.perf_counter()
     rkey = ResidentSeries.key_of(stacked, anynans) if resident is not None else None
-    if is_packed(stacked):
+    T, N = stacked.shape
+    block = None
+    if intermediate and columns is not None:
+        # sharded per-step path: only this rank's block of columns is read (and decoded)
+        b0, b1 = int(columns[0]), int(columns[1])
+        block = decode_through_device(stacked, b0, b1) if is_packed(stacked) else \
+            np.ascontiguousarray(native_float(np.asarray(stacked)[:, b0:b1]))
+    elif is_packed(stacked):
         if intermediate:
             stacked = decode_through_device(stacked)       # the per-step path compacts on the host anyway
     else:
         stacked = np.ascontiguousarray(native_float(stacked))
-    T, N = stacked.shape
 
     def host_compact(a):
         nan = np.isnan(a)
@@ -283,12 +289,33 @@ def detect_grid(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGa
         r["keep"] = keep
         return r
 
+    def host_block(seas_c, thresh_c):
+        # sharded: this rank's block of columns only; its survivors pair up with the climatology columns at the
+        # offset the exchange returns (an all-land block is not an error here, the grid as a whole decides)
+        sub = block
+        nan = np.isnan(sub)
+        keep = ~(nan.any(axis=0) if anynans else nan.all(axis=0))
+        n = int(keep.sum())
+        k0, total = exchange(n)
+        if total != thresh_c.shape[1] or seas_c.shape[1] != thresh_c.shape[1]:
+            raise XmhwException(f"temp, th and se do not have the same ocean cells: {total}, "
+                                f"{thresh_c.shape[1]}, {seas_c.shape[1]}")
+        if n == 0:
+            return dict(table=np.zeros((0, len(EVENT_COLUMNS))), offsets=np.zeros(1, dtype=np.int64), inter=None,
+                        keep=keep)
+        r = detect_cells(np.ascontiguousarray(sub[:, keep]), np.ascontiguousarray(seas_c[:, k0:k0 + n]),
+                         np.ascontiguousarray(thresh_c[:, k0:k0 + n]), doy, doys, minDuration, joinGaps, maxGap,
+                         coldSpells, True, max_batch_bytes if max_batch_bytes is not None else 64 << 30, pad=pad)
+        r["keep"] = keep
+        return r
+
     if intermediate:
         # the per-step columns come back to the host anyway: compact there and take the per-step kernels
+        path = host_path if columns is None else host_block
         if clim_stacked:
-            return host_path(host_compact(np.asarray(seas, dtype=np.float64))[0],
-                             host_compact(np.asarray(thresh, dtype=np.float64))[0])
-        return host_path(seas, thresh)
+            return path(host_compact(np.asarray(seas, dtype=np.float64))[0],
+                        host_compact(np.asarray(thresh, dtype=np.float64))[0])
+        return path(np.asarray(seas, dtype=np.float64), np.asarray(thresh, dtype=np.float64))
     def rows_as_they_are(a):
         # threshold() hands its climatologies over as row-pitched views when an all-land band was cut
         # from the grid (landmask.compress_axis): the pitched upload takes them as they are; only other

@@ -32,15 +32,18 @@ def is_packed(a):
     return isinstance(a, PackedArray) and a.decode is not None
 
 
-def decode_through_device(a):
+def decode_through_device(a, lo=0, hi=None):
     """A file view (PackedArray: big-endian and / or CF-packed samples) as a decoded host array, decoded by the
     DEVICE kernel the climatology path uses (upload of the raw bytes, xmhw_decode, download) -- for the per-step
-    detect() outputs, which compact on the host.  (The numpy restatement of the decoding the tests compare the
+    detect() outputs, which compact on the host; [lo, hi) restricts it to a block of columns.  (The numpy restatement of the decoding the tests compare the
     kernel with lives in oracle/ingest_oracle.py; the product has no host decoder.)"""
     T, N = a.shape
-    buf, isz = upload_columns(a, 0, N)
+    hi = N if hi is None else hi
+    if hi <= lo:
+        return np.zeros((T, 0), dtype=a.decoded_dtype)
+    buf, isz = upload_columns(a, lo, hi)
     try:
-        return buf.to_array((T, N), np.float32 if isz == 4 else np.float64)
+        return buf.to_array((T, hi - lo), np.float32 if isz == 4 else np.float64)
     finally:
         buf.free()
 

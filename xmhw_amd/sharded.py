@@ -292,15 +292,35 @@ def threshold_sharded(temp, transport, dst=0, _compute=None, _grid_compute=None,
     return ds if transport.rank == dst else None
 
 
+def _gather_planes(transport, planes, T, C, sample_dtype, dst=0):
+    """The per-step variables of detect(intermediate=True) (xmhw/identify.py:405-409, xmhw/xmhw.py:354-356): every
+    rank hands in its (T, cells of its block) planes -- None for a block without cells -- and rank ``dst`` gets the
+    (T, C) planes of the whole grid; the other ranks get zero planes of the same shapes and dtypes."""
+    from .detect_front import INTERMEDIATE_U8
+    booleans = set(INTERMEDIATE_U8) | {"bthresh"}
+    out = {}
+    for k in INTER_VARIABLES:
+        blk = planes[k] if planes is not None else np.zeros((T, 0))
+        full = transport.gather_columns(np.asarray(blk, dtype=np.float64), T, dst)
+        if transport.rank != dst:
+            out[k] = np.zeros((T, C), dtype=bool if k in booleans else np.float64)
+        elif k in booleans:
+            out[k] = full != 0
+        elif k == "ts":
+            out[k] = full.astype(sample_dtype)          # float32 values survive the float64 transport
+        else:
+            out[k] = full
+    return out
+
+
 def make_sharded_detect(transport, dst=0, compute=None):
     """A drop-in for detect_front.detect_cells that runs only this rank's slab of cells and gathers
     the event tables (variable length per rank) and, if asked for, the per-step columns.  Rank dst
     returns the full result, the others an empty one."""
-    from .detect_front import EVENT_COLUMNS, INTERMEDIATE_U8, detect_cells
+    from .detect_front import EVENT_COLUMNS, detect_cells
 
     inner = compute or detect_cells
     ncol = len(EVENT_COLUMNS)
-    BOOL_VARIABLES = set(INTERMEDIATE_U8) | {"bthresh"}
 
     def sharded(ts, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
                 intermediate=False, **extra):
@@ -318,25 +338,9 @@ def make_sharded_detect(transport, dst=0, compute=None):
         counts = np.diff(res["offsets"]).astype(np.float64)[None, :]
         all_counts = transport.gather_columns(counts, 1, dst)
         table = transport.gather_rows(res["table"], dst)
-        inter = None
-        if intermediate:
-            inter = {}
-            for k in INTER_VARIABLES:
-                blk = res["inter"][k] if hi > lo else np.zeros((T, 0))
-                full = transport.gather_columns(np.asarray(blk, dtype=np.float64), T, dst)
-                if transport.rank != dst:
-                    continue
-                if k in BOOL_VARIABLES:
-                    inter[k] = full != 0
-                elif k == "ts":
-                    inter[k] = full.astype(ts.dtype)        # float32 values survive the float64 transport
-                else:
-                    inter[k] = full
+        inter = _gather_planes(transport, res["inter"], T, C, ts.dtype, dst) if intermediate else None
         if transport.rank != dst:
-            return dict(table=np.zeros((0, ncol)), offsets=np.zeros(C + 1, dtype=np.int64),
-                        inter=None if not intermediate else
-                        {k: np.zeros((T, C), dtype=bool if k in BOOL_VARIABLES else np.float64)
-                         for k in INTER_VARIABLES})
+            return dict(table=np.zeros((0, ncol)), offsets=np.zeros(C + 1, dtype=np.int64), inter=inter)
         offsets = np.zeros(C + 1, dtype=np.int64)
         np.cumsum(all_counts[0].astype(np.int64), out=offsets[1:])
         return dict(table=table, offsets=offsets, inter=inter)
@@ -356,11 +360,8 @@ def make_sharded_detect_grid(transport, dst=0, grid_compute=None):
 
     def sharded(stacked, anynans, seas, thresh, doy, doys, minDuration=5, joinGaps=True, maxGap=2, coldSpells=False,
                 intermediate=False, clim_stacked=False, **extra):
-        N = stacked.shape[1]
+        T, N = stacked.shape
         lo, hi = slab_bounds(N, transport.size)[transport.rank]
-        if intermediate:
-            raise XmhwException("detect_sharded: intermediate=True is only available through the host "
-                                "land_check path (pass _compute)")
 
         # the positional pairing with the climatology needs every rank's survivor count in the middle
         # of the local stage: that exchange is itself a collective, so a rank that fails before it
@@ -375,7 +376,7 @@ def make_sharded_detect_grid(transport, dst=0, grid_compute=None):
         def local():
             try:
                 return inner(stacked, anynans, seas, thresh, doy, doys, minDuration, joinGaps, maxGap, coldSpells,
-                             False, clim_stacked=clim_stacked, columns=(lo, hi), exchange=exchange, **extra)
+                             intermediate, clim_stacked=clim_stacked, columns=(lo, hi), exchange=exchange, **extra)
             except Exception:
                 if not state["exchanged"]:
                     exchange(0)
@@ -388,11 +389,15 @@ def make_sharded_detect_grid(transport, dst=0, grid_compute=None):
         counts = transport.gather_columns(np.diff(res["offsets"]).astype(np.float64)[None, :], 1, dst)
         table = transport.gather_rows(res["table"], dst)
         C = int(keep.sum())
+        # (intermediate=True: the per-step planes travel as the event tables do, one gather per variable)
+        from .device import is_packed, native_float
+        sample_dtype = stacked.decoded_dtype if is_packed(stacked) else native_float(np.zeros(0, stacked.dtype)).dtype
+        inter = _gather_planes(transport, res["inter"], T, C, sample_dtype, dst) if intermediate else None
         if transport.rank != dst:
-            return dict(table=np.zeros((0, ncol)), offsets=np.zeros(C + 1, dtype=np.int64), inter=None, keep=keep)
+            return dict(table=np.zeros((0, ncol)), offsets=np.zeros(C + 1, dtype=np.int64), inter=inter, keep=keep)
         offsets = np.zeros(C + 1, dtype=np.int64)
         np.cumsum(counts[0].astype(np.int64), out=offsets[1:])
-        return dict(table=table, offsets=offsets, inter=None, keep=keep)
+        return dict(table=table, offsets=offsets, inter=inter, keep=keep)
 
     return sharded
 
@@ -401,9 +406,10 @@ def detect_sharded(temp, th, se, transport, dst=0, _compute=None, _grid_compute=
     """detect() over all ranks of ``transport``; rank ``dst`` gets what detect() returns, the others
     None.  The ranks split the uncompacted grid columns and each masks / compacts its own block on
     its GPU (survivor counts are exchanged so that every block finds its climatology columns);
-    ``_compute`` (test hook, compact-array stand-in; also needed for intermediate=True) selects the
-    older path in which every rank runs land_check() on the host and the compact cells are split."""
-    if _compute is not None or kwargs.get("intermediate"):
+    ``_compute`` (test hook, compact-array stand-in) selects the older path in which every rank runs
+    land_check() on the host and the compact cells are split.  intermediate=True (xmhw/xmhw.py:354-356,
+    :479-484): rank ``dst`` gets (mhw, intermediate Dataset), the per-step planes gathered block by block."""
+    if _compute is not None:
         out = _detect(temp, th, se, make_sharded_detect(transport, dst, _compute), **kwargs)
     else:
         out = _detect(temp, th, se, make_sharded_detect(transport, dst, None),
