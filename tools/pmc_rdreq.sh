@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/rdreq; mkdir -p $O
 C="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"
-timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/ring -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --parity-cells 8 $BENCH_ARGS > $O/ring.log 2>&1
+timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/ring -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --no-pmc --no-other --parity-cells 8 $BENCH_ARGS > $O/ring.log 2>&1
 timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/calib -- python3 $R/tools/calib_fetch.py > $O/calib.log 2>&1
 python3 - <<PY
 import csv, glob, collections

@@ -4,7 +4,7 @@
 TAG=${1:-x}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_$TAG; mkdir -p $O
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $O/p1 -- python3 $R/bench.py --cells 129600 --chunks 1 --steps 1 --warmup 0 --no-cpu --parity-cells 8 > $O/p1.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $O/p1 -- python3 $R/bench.py --cells 129600 --chunks 1 --steps 1 --warmup 0 --no-cpu --no-pmc --no-other --parity-cells 8 > $O/p1.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob('$O/p1/*/*_counter_collection.csv')[0]

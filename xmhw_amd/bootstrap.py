@@ -40,7 +40,10 @@ def share_bytes(rank, size, make_payload, addr=None, port=None, timeout=120.0):
         payload = make_payload()
         srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind(("0.0.0.0" if addr not in ("127.0.0.1", "localhost") else "127.0.0.1", port))
+        try:
+            srv.bind((addr, port))                       # the rendezvous interface only
+        except OSError:
+            srv.bind(("0.0.0.0", port))                  # (addr is a name this host does not own: any interface)
         srv.listen(size)
         srv.settimeout(timeout)
         served = 0
@@ -48,7 +51,11 @@ def share_bytes(rank, size, make_payload, addr=None, port=None, timeout=120.0):
             while served < size - 1:
                 conn, _ = srv.accept()
                 with conn:
-                    if _recv_exact(conn, 4) != _MAGIC:
+                    conn.settimeout(5.0)                 # a silent stray connection does not block the group
+                    try:
+                        if _recv_exact(conn, 4) != _MAGIC:
+                            continue
+                    except (socket.timeout, OSError):
                         continue
                     conn.sendall(struct.pack("<I", len(payload)) + payload)
                     served += 1

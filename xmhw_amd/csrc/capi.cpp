@@ -445,12 +445,15 @@ struct RowsEntry {
     }
 };
 std::mutex g_cache_mu;
-std::vector<std::unique_ptr<RowsEntry>> g_rows_cache;
+std::vector<std::shared_ptr<RowsEntry>> g_rows_cache;
 uint64_t g_stamp = 0;
 constexpr size_t kRowsCacheSlots = 8;
 
-// returns nullptr and sets *err on failure
-RowsEntry* cached_rows(const int32_t* row_of_t, int64_t Tn, hipError_t* err) {
+// returns nullptr and sets *err on failure.  The caller HOLDS the returned pointer until its launches are queued: an
+// entry another thread evicts meanwhile is destroyed (hipFree, which waits for the device) only when the last holder
+// lets go of it.
+using RowsRef = std::shared_ptr<RowsEntry>;
+RowsRef cached_rows(const int32_t* row_of_t, int64_t Tn, hipError_t* err) {
     std::lock_guard<std::mutex> lock(g_cache_mu);
     int dev = 0;
     *err = hipGetDevice(&dev);
@@ -459,9 +462,9 @@ RowsEntry* cached_rows(const int32_t* row_of_t, int64_t Tn, hipError_t* err) {
         if (e->device == dev && static_cast<int64_t>(e->host.size()) == Tn &&
             std::memcmp(e->host.data(), row_of_t, sizeof(int32_t) * static_cast<size_t>(Tn)) == 0) {
             e->stamp = ++g_stamp;
-            return e.get();
+            return e;
         }
-    auto e = std::make_unique<RowsEntry>();
+    auto e = std::make_shared<RowsEntry>();
     e->host.assign(row_of_t, row_of_t + Tn);
     e->device = dev;
     *err = hipMalloc(&e->d_rows, sizeof(int32_t) * static_cast<size_t>(Tn));
@@ -476,14 +479,17 @@ RowsEntry* cached_rows(const int32_t* row_of_t, int64_t Tn, hipError_t* err) {
         g_rows_cache.erase(g_rows_cache.begin() + static_cast<long>(oldest));
     }
     e->stamp = ++g_stamp;
-    g_rows_cache.push_back(std::move(e));
-    return g_rows_cache.back().get();
+    g_rows_cache.push_back(e);
+    return e;
 }
 
-// scratch memory per (device, stream): grows on demand (the only synchronising moment), never shrinks
-struct Scratch { void* ptr = nullptr; size_t cap = 0; };
+// scratch memory per (device, stream): grows on demand (the only synchronising moment), never shrinks.  A caller
+// keeps the ScratchRef for the length of its call: a buffer that another thread on the same stream outgrows meanwhile
+// is freed only when its last holder is done.
+using ScratchRef = std::shared_ptr<void>;
+struct Scratch { ScratchRef ptr; size_t cap = 0; };
 std::map<std::pair<int, void*>, Scratch> g_scratch;
-hipError_t scratch_get(hipStream_t st, size_t bytes, void** out) {
+hipError_t scratch_get(hipStream_t st, size_t bytes, void** out, ScratchRef* keep) {
     std::lock_guard<std::mutex> lock(g_cache_mu);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -493,23 +499,23 @@ hipError_t scratch_get(hipStream_t st, size_t bytes, void** out) {
         if (sc.ptr) {
             e = hipStreamSynchronize(st);
             if (e != hipSuccess) return e;
-            (void)hipFree(sc.ptr);
-            sc.ptr = nullptr;
+            sc.ptr.reset();
             sc.cap = 0;
         }
-        e = hipMalloc(&sc.ptr, bytes);
-        if (e != hipSuccess) { sc.ptr = nullptr; return e; }
+        void* p = nullptr;
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return e;
+        sc.ptr = ScratchRef(p, [](void* q) { (void)hipFree(q); });
         sc.cap = bytes;
     }
-    *out = sc.ptr;
+    *out = sc.ptr.get();
+    *keep = sc.ptr;
     return hipSuccess;
 }
 void release_cached_tables() {
     std::lock_guard<std::mutex> lock(g_cache_mu);
     (void)hipDeviceSynchronize();
     g_rows_cache.clear();
-    for (auto& kv : g_scratch)
-        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     g_scratch.clear();
 }
 
@@ -525,7 +531,7 @@ int detect_events(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* 
         return fail(XMHW_ERR_INVALID, "NULL buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipSuccess;
-    RowsEntry* rows = cached_rows(row_of_t, Tn, &e);
+    const RowsRef rows = cached_rows(row_of_t, Tn, &e);
     if (!rows) return hip_fail(e, "row table upload");
     e = xmhw::launch_detect<T>(ts, Tn, C, ld, thresh, ldt, rows->d_rows, min_duration, join_gaps, max_gap, negate,
                                events, start, end, bthresh, ldo, nevents, st);
@@ -543,7 +549,7 @@ int event_stats(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* se
         return fail(XMHW_ERR_INVALID, "NULL buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipSuccess;
-    RowsEntry* rows = cached_rows(row_of_t, Tn, &e);
+    const RowsRef rows = cached_rows(row_of_t, Tn, &e);
     if (!rows) return hip_fail(e, "row table upload");
     e = xmhw::launch_event_stats<T>(ts, Tn, C, ld, seas, thresh, ldc, rows->d_rows, negate, events, ldo, offsets, table, st);
     if (e != hipSuccess) return hip_fail(e, "event_stats launch");
@@ -596,7 +602,7 @@ int exceed_bits(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* th
     hipStream_t st = static_cast<hipStream_t>(stream);
     constexpr int kTile = sizeof(T) == 4 ? 64 : 32;
     hipError_t e = hipSuccess;
-    RowsEntry* rows = cached_rows(row_of_t, Tn, &e);
+    const RowsRef rows = cached_rows(row_of_t, Tn, &e);
     if (!rows) return hip_fail(e, "row table upload");
     // chunk tables of the tiled kernel: built and uploaded once per (row table, D, tile)
     ChunkTables* ct = nullptr;
@@ -631,13 +637,14 @@ int exceed_bits(const T* ts, int64_t Tn, int64_t C, int64_t ld, const double* th
     const bool tiled = mode == 2 || (mode == 0 && ct->nchunks * kTile <= 4 * Tn && C >= 131072);
     const int64_t W = (Tn + 63) / 64;
     float* thf = nullptr;
+    ScratchRef scratch_keep;
     if constexpr (sizeof(T) == 4) {
         // float32 series: compare against the float32 floor of the thresholds (same results, see
         // kernels_events.hip), 4 instead of 8 bytes per threshold.  Only the addressed (D, C) region is
         // converted: `thresh` may point into a wider array (column block k0 of a (D, ldt) climatology),
         // where D * ldt elements would overrun it.  The copy lives in this stream's scratch buffer.
         void* sp = nullptr;
-        e = scratch_get(st, sizeof(float) * static_cast<size_t>(D) * static_cast<size_t>(C), &sp);
+        e = scratch_get(st, sizeof(float) * static_cast<size_t>(D) * static_cast<size_t>(C), &sp, &scratch_keep);
         if (e != hipSuccess) return hip_fail(e, "scratch allocation");
         thf = static_cast<float*>(sp);
         e = xmhw::launch_floor_to_f32(thresh, D, C, ldt, thf, C, st);
@@ -676,7 +683,7 @@ int event_stats_sparse(const T* ts, int64_t Tn, int64_t C, int64_t ld, const dou
     if (!ts || !seas || !thresh || !row_of_t || !table) return fail(XMHW_ERR_INVALID, "NULL buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipSuccess;
-    RowsEntry* rows = cached_rows(row_of_t, Tn, &e);
+    const RowsRef rows = cached_rows(row_of_t, Tn, &e);
     if (!rows) return hip_fail(e, "row table upload");
     e = xmhw::launch_event_stats_sparse<T>(ts, Tn, ld, seas, thresh, ldc, rows->d_rows, negate, n_events, table, st);
     if (e != hipSuccess) return hip_fail(e, "event_stats_sparse launch");
@@ -693,7 +700,7 @@ int event_intermediate(const T* ts, int64_t Tn, int64_t C, int64_t ld, const dou
     if (!ts || !seas || !thresh || !row_of_t || !events || !out || !dur) return fail(XMHW_ERR_INVALID, "NULL buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipSuccess;
-    RowsEntry* rows = cached_rows(row_of_t, Tn, &e);
+    const RowsRef rows = cached_rows(row_of_t, Tn, &e);
     if (!rows) return hip_fail(e, "row table upload");
     e = xmhw::launch_event_intermediate<T>(ts, Tn, C, ld, seas, thresh, ldc, rows->d_rows, negate, events, ldo, out, ldv, dur,
                                            st);
@@ -1077,8 +1084,9 @@ int xmhw_clim_finish(const xmhw_plan* plan, const double* thresh_in, const doubl
         return fail(XMHW_ERR_INVALID, "in and out may not alias");
     const xmhw::Plan& h = plan->host;
     void* flags = nullptr;      // per-column "has an absent group" flags of the one-pass finish kernel
+    ScratchRef scratch_keep;
     if (smooth && smooth_width == 31) {
-        hipError_t se = scratch_get(static_cast<hipStream_t>(stream), static_cast<size_t>(C), &flags);
+        hipError_t se = scratch_get(static_cast<hipStream_t>(stream), static_cast<size_t>(C), &flags, &scratch_keep);
         if (se != hipSuccess) return hip_fail(se, "scratch allocation");
     }
     hipError_t e = xmhw::launch_finish(thresh_in, seas_in, C, ldo, h.D, row_index(h, 59), row_index(h, 60),
@@ -1189,8 +1197,9 @@ int xmhw_offsets_from_counts(const int32_t* counts_dev, int64_t n, int64_t* offs
     if (!offsets_dev || (n > 0 && !counts_dev)) return fail(XMHW_ERR_INVALID, "NULL buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     void* sp = nullptr;
+    ScratchRef scratch_keep;
     const int64_t nblocks = (n + 1023) / 1024;
-    hipError_t e = scratch_get(st, sizeof(int64_t) * static_cast<size_t>(nblocks + 1), &sp);
+    hipError_t e = scratch_get(st, sizeof(int64_t) * static_cast<size_t>(nblocks + 1), &sp, &scratch_keep);
     if (e != hipSuccess) return hip_fail(e, "scratch allocation");
     e = xmhw::launch_offsets_from_counts(counts_dev, n, offsets_dev, static_cast<int64_t*>(sp), st);
     if (e != hipSuccess) return hip_fail(e, "offsets_from_counts launch");
