@@ -104,6 +104,13 @@ __device__ __forceinline__ uint32_t ashr31_3(uint32_t v) {
 __device__ __forceinline__ uint32_t key_of_bits3(uint32_t b, uint32_t negmask) {
     return b ^ (static_cast<uint32_t>(static_cast<int32_t>(b) >> 31) | 0x80000000u) ^ negmask;
 }
+// the same in two instructions (v_ashrrev, v_bitop3: (sign | 0x80000000) ^ b, complemented for cold spells), for the
+// plain rows where every sample is a number; NEG is a compile-time choice, the caller branches on the launch's negate
+template <bool NEG>
+__device__ __forceinline__ uint32_t key_of_bits3_fast(uint32_t b) {
+    return static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(static_cast<int32_t>(ashr31_3(b)), static_cast<int32_t>(b),
+                                                             static_cast<int32_t>(0x80000000u), NEG ? 0xC9 : 0x36));
+}
 __device__ __forceinline__ uint32_t bits_of_key3(uint32_t k) { return k ^ (~ashr31_3(k) | 0x80000000u); }
 __device__ __forceinline__ double value_of_key3(uint32_t k) {   // 0 for an invalid key
     const float f = __uint_as_float(bits_of_key3(k));
@@ -462,12 +469,13 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
 #pragma unroll
         for (int y = 0; y < YPS; ++y) tix[y] += (y == YPS - 1) ? last_step : 1u;
     };
-    // (the row stride as a 32-bit number -- the launcher refuses ld >= 2^32 -- so that a sample address is ONE
-    // v_mad_u64_u32 instead of the two the compiler needs for a 64-bit stride: 30 fewer 64-bit instructions per row)
-    const uint32_t ld32 = static_cast<uint32_t>(ld);
+    // (the row stride in BYTES as a 32-bit number -- the launcher refuses ld >= 2^30 -- so that a sample address is ONE
+    // v_mad_u64_u32 with the column pointer as its addend)
+    const uint32_t ld4 = static_cast<uint32_t>(ld) * 4u;
     auto request = [&](float (&x)[YPS]) {
 #pragma unroll
-        for (int y = 0; y < YPS; ++y) x[y] = col[static_cast<uint64_t>(tix[y]) * ld32];
+        for (int y = 0; y < YPS; ++y)
+            x[y] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(col) + static_cast<uint64_t>(tix[y]) * ld4);
     };
 
     float x_raw[YPS];
@@ -536,8 +544,13 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
         auto is_nan = [&](int y) -> bool { return x_raw[y] != x_raw[y]; };
         if (fast) {
             if constexpr (STATS) ++st_fast;
+            if (negate) {
 #pragma unroll
-            for (int y = 0; y < YPS; ++y) kin[y] = key_in(y);
+                for (int y = 0; y < YPS; ++y) kin[y] = key_of_bits3_fast<true>(__float_as_uint(x_raw[y]));
+            } else {
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) kin[y] = key_of_bits3_fast<false>(__float_as_uint(x_raw[y]));
+            }
             kin[YPS - 1] |= padmask;
         } else if (sf & 1u) {
 #pragma unroll
@@ -572,12 +585,18 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
             __hip_atomic_fetch_add(&hist[tag_of(kin[y])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&hist[tag_of(kout[y])], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        // the free probe: how the count of keys <= the carried pivot changes (in ONE place: written into both branches
+        // below, the compiler computed the twenty compares twice on the plain rows)
         uint32_t dF = 0;
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) dF += (kin[y] <= pc ? 1u : 0u) - (kout[y] <= pc ? 1u : 0u);
         if (fast) {
+            // (the pushed samples are summed as they are, the sum changes sign for cold spells: one instruction
+            // instead of one per sample)
             double din, dout;
 #pragma unroll
             for (int y = 0; y < YPS; ++y) {
-                uint32_t bi = __float_as_uint(x_raw[y]) ^ (negmask & 0x80000000u);
+                uint32_t bi = __float_as_uint(x_raw[y]);
                 uint32_t bo = bits_of_key3(kout[y]);
                 if (y == YPS - 1) {
                     bi &= ~padmask;
@@ -587,16 +606,14 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
                 const double dq = static_cast<double>(__uint_as_float(bo));
                 din = y == 0 ? di : din + di;
                 dout = y == 0 ? dq : dout + dq;
-                dF += (kin[y] <= pc ? 1u : 0u) - (kout[y] <= pc ? 1u : 0u);
             }
-            lsum += din - dout;
+            lsum += (negate ? -din : din) - dout;
         } else {
 #pragma unroll
             for (int y = 0; y < YPS; ++y) {
                 lsum += value_of_key3(kin[y]);
                 lsum -= value_of_key3(kout[y]);
                 nval += (kin[y] != kInv3 ? 1u : 0u) - (kout[y] != kInv3 ? 1u : 0u);
-                dF += (kin[y] <= pc ? 1u : 0u) - (kout[y] <= pc ? 1u : 0u);
             }
             rotate = wave_hold;
             clean = !__any(nval != full_valid);
@@ -1131,7 +1148,7 @@ hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
                             double* thresh, double* seas, int64_t ldo, hipStream_t stream,
                             unsigned long long* stats) {
     const Ring3Entry* e = w == 5 ? find_ring3(yps, subs) : nullptr;
-    if (!e || ld >= (int64_t(1) << 32)) return hipErrorInvalidValue;
+    if (!e || ld >= (int64_t(1) << 30)) return hipErrorInvalidValue;
     if (C <= 0 || nchunks <= 0) return hipSuccess;
     const int64_t cells_per_block = (64 / subs) * kWaves3;
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
