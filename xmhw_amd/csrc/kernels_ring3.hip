@@ -42,7 +42,8 @@
 namespace xmhw {
 namespace {
 
-constexpr int kWaves3 = 4;
+// waves per workgroup: the lanes of a workgroup cover ONE 128-byte line of a sample row (32 cells)
+constexpr int waves3(int subs) { return subs == 4 ? 2 : 4; }
 constexpr uint32_t kInv3 = 0xFFFFFFFFu;
 
 template <int CTRL>
@@ -390,7 +391,7 @@ constexpr float kBucketRanks = 3.5f;
 // [6] low word: cell-rows that tried the band path, high word: cell-rows it failed on, [7] low word: of those,
 // target off the block / window, high word: band larger than a list ([3] high word: histogram mismatches, must be 0).
 template <int YPS, int SUBS, bool STATS>
-__global__ __launch_bounds__(256, 2) void clim_ring3_f32(
+__global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
     const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, int32_t step_min, const DevChunk* __restrict__ chunks, double q,
     int negate, int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
@@ -398,6 +399,7 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
     constexpr int W = 5;
     constexpr int R = 2 * W + 1;
     static_assert(SUBS == 8 || SUBS == 4, "8 or 4 lanes per cell");
+    constexpr int kWaves3 = waves3(SUBS);
     constexpr int NTP = SUBS * YPS;
     constexpr int CPWAVE = 64 / SUBS;
     constexpr int NB = Cfg3<SUBS>::NB;           // buckets per cell
@@ -1067,6 +1069,11 @@ __global__ __launch_bounds__(256, 2) void clim_ring3_f32(
         }
 
         tick(7);
+        // The waves of a workgroup read the two halves of the same 128-byte lines (a workgroup is 32 cells wide), and
+        // a line stays in L2 for about three rows: they are marched in step every 32 rows.  Measured on configs[2]
+        // (profiles/r3_rendezvous.txt): no rendezvous at all is 3 % faster (55.3 against 56.9 ms) but fetches 1.65 x
+        // the algorithmic bytes -- every line again for the wave that comes late; bounding the lead of a wave by 8..32
+        // rows through a counter in LDS does not help (1.6 x: the partner has to arrive within about three rows).
         if ((s & 31) == 31) __syncthreads();
         sf_cur = sf_nxt;
         sf_nxt = sf_nn;
@@ -1150,6 +1157,7 @@ hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
     const Ring3Entry* e = w == 5 ? find_ring3(yps, subs) : nullptr;
     if (!e || ld >= (int64_t(1) << 30)) return hipErrorInvalidValue;
     if (C <= 0 || nchunks <= 0) return hipSuccess;
+    const int kWaves3 = waves3(subs);
     const int64_t cells_per_block = (64 / subs) * kWaves3;
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
     hipLaunchKernelGGL(stats ? e->fn_stats : e->fn, grid, dim3(64 * kWaves3), 0, stream, ts, C, ld, Tn, table, sflags,
