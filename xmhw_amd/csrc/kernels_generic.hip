@@ -373,16 +373,23 @@ __global__ __launch_bounds__(256) void clim_finish_tiled(const double* __restric
 }
 
 // ---------------------------------------------------------------------------
-// clim_finish_stream<W>: Feb-29 + circular running mean of width W for columns WITHOUT absent groups, every
+// clim_finish_stream<W, A>: Feb-29 + circular running mean of width W for columns WITHOUT absent groups, every
 // raw row read ONCE (+ W - 1 halo rows per part).  Thread = cell (512 contiguous bytes per wave and row); the
-// W rows of the current window sit in registers (the row loop is unrolled W times, so that the slot of a row
-// is static); one load per output row, issued one row ahead.  The window sum slides (+ lead - trail) and is
-// re-summed from the registers, in window order, at every row that is a multiple of W: a part boundary is
-// such a row, so the result does not depend on how the doy axis is cut into parts, and parts depend on D
-// only -- N-rank and 1-rank runs stay bit-identical.  A column that holds a NaN (an absent group: the
-// reference then rolls over the PRESENT rows only) is flagged and redone by clim_finish(only = flags).
+// W rows of the current window sit in registers and the A rows after them are on their way: the row loop is
+// unrolled so that the window slot and the prefetch slot of a row are static, and a loaded value is not looked at
+// (NaN flag, Feb-29 replacement) before the row in which it enters the window -- A loads stay in flight per thread.
+// Shipped with A = W = 31 (204 VGPRs, two waves per SIMD): 2.6 ms at D = 366 x 1,036,800 cells, 8.3 ms at
+// D = 1460 x 810,000; round 3a's kernel tested every value as it was requested -- i.e. waited for it -- and took
+// 3.6 / 10.0 ms; A = 1 and A = 2 depend on where the compiler puts the loads (3.3 and 5.2 ms).
+// tools/ubench_colwalk.hip: this access pattern by itself copies at 4.5 TB/s with one load in flight per thread at
+// full occupancy and 5.1-5.5 TB/s with two to four, i.e. 2.2-2.7 ms for the bytes of D = 366.
+// The window sum slides (+ lead - trail) and is re-summed from the registers, in window order, at every row that is
+// a multiple of W: a part boundary is such a row, so the result does not depend on how the doy axis is cut into
+// parts, and parts depend on D only -- N-rank and 1-rank runs stay bit-identical.  A column that holds a NaN (an
+// absent group: the reference then rolls over the PRESENT rows only) is flagged and redone by
+// clim_finish(only = flags).
 // ---------------------------------------------------------------------------
-template <int W>
+template <int W, int A>
 __global__ __launch_bounds__(256) void clim_finish_stream(const double* __restrict__ th_in,
                                                           const double* __restrict__ se_in, int64_t C, int64_t ld,
                                                           int32_t D, int32_t i59, int32_t i60, int32_t i61,
@@ -390,6 +397,8 @@ __global__ __launch_bounds__(256) void clim_finish_stream(const double* __restri
                                                           double* __restrict__ th_out, double* __restrict__ se_out,
                                                           uint8_t* __restrict__ flags) {
     constexpr int H = (W - 1) / 2;
+    constexpr int U = (W % A == 0) ? W : W * A;        // rows per trip of the unrolled loop (A = 1, 2 or W)
+    static_assert(A >= 1 && (W % A == 0 || A == 2 || A == 4), "prefetch depth: 1, 2, 4 or a divisor of W");
     const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const double* in = (blockIdx.z == 0 ? th_in : se_in) + c;
@@ -399,10 +408,11 @@ __global__ __launch_bounds__(256) void clim_finish_stream(const double* __restri
     if (d0 >= d1) return;
     bool bad = false;
     const bool fix = feb29_fix && i60 >= 0;
-    auto load = [&](int32_t r) -> double {
-        double v = in[static_cast<int64_t>(r) * ld];
+    // a value as it enters the window: NaN -> the column is flagged; group 60 present -> the 3-point nan-mean,
+    // summed in index order (the row number is the same for every thread: a uniform branch, taken once per part)
+    auto enter = [&](double v, int32_t row) -> double {
         bad = bad || (v != v);
-        if (fix && r == i60 && v == v) {          // group 60 present: the 3-point nan-mean, summed in index order
+        if (fix && row == i60 && v == v) {
             const double v59 = i59 >= 0 ? in[static_cast<int64_t>(i59) * ld] : make_nan();
             const double v61 = i61 >= 0 ? in[static_cast<int64_t>(i61) * ld] : make_nan();
             const bool p59 = v59 == v59, p61 = v61 == v61;
@@ -412,32 +422,52 @@ __global__ __launch_bounds__(256) void clim_finish_stream(const double* __restri
         }
         return v;
     };
-    double win[W];
+    auto next = [&](int32_t r) -> int32_t { return (r + 1 == D) ? 0 : r + 1; };
+    double win[W], pre[A];
     int32_t r = d0 - H;
     if (r < 0) r += D;
+    const int32_t r_first = r;
+    // the first window and the A rows after it: W + A loads in flight
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-        win[k] = load(r);
-        r = (r + 1 == D) ? 0 : r + 1;
+        win[k] = in[static_cast<int64_t>(r) * ld];
+        r = next(r);
     }
-    // (requesting the rows W steps ahead instead -- a second set of W registers, W loads in flight per thread at two
-    // waves per SIMD -- measured SLOWER: 5.08 against 3.59 ms at D = 366, 15.3 against 10.0 ms at D = 1460; the walk
-    // down a column touches a new 8 MB-strided page per row, and more of them in flight did not help)
-    double pre = load(r);                          // the row after the first window, one step ahead
-    r = (r + 1 == D) ? 0 : r + 1;
-    const double wd = static_cast<double>(W);
-    for (int32_t base = d0; base < d1; base += W) {
-        double s = win[0];
+    int32_t r_enter = r;                           // the row of the value that enters the window next
 #pragma unroll
-        for (int k = 1; k < W; ++k) s += win[k];
+    for (int k = 0; k < A; ++k) {
+        pre[k] = in[static_cast<int64_t>(r) * ld];
+        r = next(r);
+    }
+    {
+        int32_t rw = r_first;
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-            const int32_t d = base + k;
+            win[k] = enter(win[k], rw);
+            rw = next(rw);
+        }
+    }
+    const double wd = static_cast<double>(W);
+    double s = 0.0;
+    for (int32_t base = d0; base < d1; base += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = u % W, a = u % A;
+            const int32_t d = base + u;
             if (d < d1) {
-                out[static_cast<int64_t>(d) * ld] = s / wd;
-                const double nv = pre;
-                pre = load(r);
-                r = (r + 1 == D) ? 0 : r + 1;
+                if (k == 0) {
+                    s = win[0];
+#pragma unroll
+                    for (int i = 1; i < W; ++i) s += win[i];
+                }
+                // (the load is issued BEFORE the store: loads and stores share one in-order counter, and a load behind
+                // a store cannot be waited for without waiting for the store too)
+                const double mean = s / wd;
+                const double nv = enter(pre[a], r_enter);
+                r_enter = next(r_enter);
+                if (d + A < d1 - 1) pre[a] = in[static_cast<int64_t>(r) * ld];      // (the last rows need no successors)
+                r = next(r);
+                out[static_cast<int64_t>(d) * ld] = mean;
                 s -= win[k];
                 win[k] = nv;
                 s += nv;
@@ -468,7 +498,7 @@ hipError_t launch_finish(const double* th_in, const double* se_in, int64_t C, in
         const int32_t nparts = D > 732 ? 4 : 1;
         const int32_t rpp = ((D + nparts - 1) / nparts + 30) / 31 * 31;
         dim3 grid(static_cast<unsigned>((C + 255) / 256), static_cast<unsigned>((D + rpp - 1) / rpp), 2);
-        hipLaunchKernelGGL(clim_finish_stream<31>, grid, dim3(256), 0, stream, th_in, se_in, C, ldo, D, i59, i60, i61,
+        hipLaunchKernelGGL((clim_finish_stream<31, 31>), grid, dim3(256), 0, stream, th_in, se_in, C, ldo, D, i59, i60, i61,
                            feb29_fix, rpp, th_out, se_out, flags);
         dim3 grid2(static_cast<unsigned>((C + 255) / 256), 2);
         hipLaunchKernelGGL(clim_finish, grid2, dim3(256), 0, stream, th_in, se_in, C, ldo, D, i59, i60, i61,
