@@ -174,3 +174,55 @@ def test_every_track_count_9_to_48(dev):
         doy = _daily(1975, 1975 + ny - 1)
         x = _series(doy.shape[0], 20, 100 + ny)
         _check(dev, x, doy)
+
+
+def test_float64_input_holding_float32_values_narrows_onto_the_ring3_kernel(dev):
+    """float64 input whose samples are float32-representable (a float32 archive promoted by a reader) runs on the
+    narrowing instantiation of the third-generation kernel: bit-identical to the float32 call on the same values, for
+    heat waves and cold spells, with NaN and infinite samples; one lossy sample hidden from the sparse probe makes
+    the kernel give up and the float64 kernel behind it does the work (same result as with narrowing off)."""
+    from xmhw_amd.device import DeviceBuffer, Plan, clim_raw
+    h = dev.hip()
+    doy = _daily(1982, 2021)
+    T, C = doy.shape[0], 83
+    x32 = _series(T, C, 31, 0.01)
+    x32[:, 7] = np.nan
+    x32[200:260, 9] = np.inf
+    x64 = x32.astype(np.float64)
+    hidden = x64.copy()
+    hidden[9001, 40] = 17.123456789012345            # float32 cannot hold it; off the probe's rows
+    assert 9001 % max(T // 32, 1) != 0
+    D = 366
+
+    def run(arr, narrowing, neg=False, nchunks=0):
+        plan = Plan(doy, 5, kernel="ring", narrowing=narrowing, nchunks=nchunks)
+        assert plan.ring2_in_use() == 21
+        d_ts = DeviceBuffer.from_array(np.ascontiguousarray(arr))
+        th, se = DeviceBuffer(8 * D * C), DeviceBuffer(8 * D * C)
+        try:
+            clim_raw(plan, d_ts, arr.dtype.itemsize, C, 0.9, neg, th, se)
+            h.stream_sync(0)
+            narrowed = plan.narrowed() if arr.dtype == np.float64 else None
+            return th.to_array((D, C), np.float64), se.to_array((D, C), np.float64), narrowed
+        finally:
+            for b in (d_ts, th, se):
+                b.free()
+            plan.destroy()
+
+    for neg in (False, True):
+        for nchunks in (0, 3):
+            t32, s32, _ = run(x32, True, neg, nchunks)
+            tn, sn, narrowed = run(x64, True, neg, nchunks)
+            assert narrowed
+            npt.assert_array_equal(tn, t32)
+            npt.assert_array_equal(sn, s32)
+    t64, s64, narrowed = run(x64, False)               # the float64 kernel on the same values
+    assert not narrowed
+    tn, sn, _ = run(x64, True)
+    npt.assert_array_equal(tn, t64)
+    npt.assert_allclose(sn, s64, rtol=1e-13, equal_nan=True)
+    ta, sa, narrowed = run(hidden, True)
+    assert not narrowed
+    tb, sb, _ = run(hidden, False)
+    npt.assert_array_equal(ta, tb)
+    npt.assert_array_equal(sa, sb)

@@ -176,14 +176,22 @@ int32_t ring2_resolved(const xmhw_plan* p) {
 }
 
 // float64 input that is really float32 (decoded archives): which ring2 variant narrows it, and on which of the
-// plan's tables.  The third-generation kernel has no double instantiation, so a plan whose float32 layout is
-// variant 20 / 21 narrows on the second-generation kernel: its table is the plan's own when the lane layout is
-// the same (4 lanes: variant 10), the 64-bit mode's 8-lane table otherwise.
+// plan's tables.  The third-generation kernel narrows on the layouts the automatic choice uses (7..12 tracks per lane
+// at 4 lanes per cell); any other plan whose float32 layout is variant 20 / 21 narrows on the second-generation
+// kernel: its table is the plan's own when the lane layout is the same (4 lanes: variant 10), the 64-bit mode's
+// 8-lane table otherwise.
 struct NarrowChoice { int32_t variant = -1, yps = 0; const uint32_t* table = nullptr; };
 NarrowChoice narrow_choice(const xmhw_plan* p) {
     NarrowChoice c;
     int32_t v = ring2_resolved(p);
     if (v < 0) return c;
+    if (v >= 20 && p->yps2 && p->subs2 == xmhw::ring2_subs(v) &&
+        xmhw::ring2_narrowing_supported(p->host.w, p->yps2, v)) {
+        c.variant = v;
+        c.yps = p->yps2;
+        c.table = p->d_table2;
+        return c;
+    }
     if (v >= 20) v = ring2_legacy(p);
     const int32_t subs = xmhw::ring2_subs(v);
     const int32_t yps = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, v);

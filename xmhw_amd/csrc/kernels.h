@@ -58,6 +58,14 @@ hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
                             double* thresh, double* seas, int64_t ldo, hipStream_t stream,
                             unsigned long long* stats = nullptr);
 
+// the same for float64 input whose samples are float32-representable (see launch_ring2_f32_narrowing)
+bool ring3_narrowing_supported(int32_t w, int32_t yps, int32_t subs);
+hipError_t launch_ring3_f32_narrowing(const double* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
+                                      const uint32_t* sflags, int32_t step_min, const DevChunk* chunks,
+                                      int32_t nchunks, int32_t w, int32_t yps, int32_t subs, int32_t ntracks, double q,
+                                      int negate, double* thresh, double* seas, int64_t ldo, hipStream_t stream,
+                                      uint32_t* narrow_flag);
+
 // float64 input through the float32 ring kernel: zeroes narrow_flag, probes the series, runs the
 // kernel with samples narrowed on load; narrow_flag != 0 afterwards: some sample is not float32-
 // representable and the outputs are garbage (queue launch_ring2_f64(..., run_flag = narrow_flag) behind)

@@ -1333,6 +1333,7 @@ hipError_t launch_ring2_f64(const double* ts, int64_t C, int64_t ld, int64_t Tn,
 }
 
 bool ring2_narrowing_supported(int32_t w, int32_t yps, int32_t variant) {
+    if (variant >= 20) return ring3_narrowing_supported(w, yps, ring2_subs(variant));
     const Ring2Entry* e = find_ring2(w, yps, ring2_subs(variant), variant);
     return e != nullptr && e->fn_narrow != nullptr;
 }
@@ -1345,6 +1346,9 @@ hipError_t launch_ring2_f32_narrowing(const double* ts, int64_t C, int64_t ld, i
                                       double q, int negate, double* thresh, double* seas, int64_t ldo,
                                       hipStream_t stream, uint32_t* narrow_flag) {
     const int32_t subs = ring2_subs(variant);
+    if (variant >= 20)
+        return launch_ring3_f32_narrowing(ts, C, ld, Tn, table, sflags, step_min, chunks, nchunks, w, yps, subs, ntracks, q,
+                                          negate, thresh, seas, ldo, stream, narrow_flag);
     const Ring2Entry* e = find_ring2(w, yps, subs, variant);
     if (!e || !e->fn_narrow || !narrow_flag) return hipErrorInvalidValue;
     if (C <= 0 || nchunks <= 0) return hipSuccess;

@@ -390,12 +390,21 @@ constexpr float kBucketRanks = 3.5f;
 // [5] low word: wave-rows settled by the band path alone, high word: window rebuilds (wave level),
 // [6] low word: cell-rows that tried the band path, high word: cell-rows it failed on, [7] low word: of those,
 // target off the block / window, high word: band larger than a list ([3] high word: histogram mismatches, must be 0).
-template <int YPS, int SUBS, bool STATS>
+// TI = float, or double for float64 input whose samples are float32-representable (float32 archives promoted by a
+// reader): the samples are narrowed on load, `narrow_flag` is set as soon as one does not survive the round trip, the
+// kernel gives up and the float64 kernel queued behind it (which looks at the same flag) does the work instead
+// (the protocol of kernels_ring2.hip).
+template <int YPS, int SUBS, bool STATS, typename TI = float>
 __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
-    const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
+    const TI* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, int32_t step_min, const DevChunk* __restrict__ chunks, double q,
     int negate, int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
-    unsigned long long* __restrict__ stats) {
+    unsigned long long* __restrict__ stats, uint32_t* __restrict__ narrow_flag) {
+    constexpr bool kNarrow = sizeof(TI) == 8;
+    if constexpr (kNarrow) {
+        if (*narrow_flag != 0) return;           // the probe (or another workgroup) already found a lossy sample
+    }
+    bool lossy = false;
     constexpr int W = 5;
     constexpr int R = 2 * W + 1;
     static_assert(SUBS == 8 || SUBS == 4, "8 or 4 lanes per cell");
@@ -428,7 +437,7 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
     const bool cell_ok = cell < C;
     const DevChunk ch = chunks[blockIdx.y];
     const uint32_t* tab = table + sub;           // y-major: entry of slot y at tab[step * NTP + y * SUBS]
-    const float* col = ts + (cell_ok ? cell : C - 1);
+    const TI* col = ts + (cell_ok ? cell : C - 1);
     const uint32_t negmask = negate ? 0xFFFFFFFFu : 0u;
     const uint32_t tmax = static_cast<uint32_t>(Tn - 1);
     const bool padded_last = (YPS - 1) * SUBS + sub >= ntracks;
@@ -473,16 +482,16 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
     };
     // (the row stride in BYTES as a 32-bit number -- the launcher refuses ld >= 2^30 -- so that a sample address is ONE
     // v_mad_u64_u32 with the column pointer as its addend)
-    const uint32_t ld4 = static_cast<uint32_t>(ld) * 4u;
-    auto request = [&](float (&x)[YPS]) {
+    const uint32_t ld4 = static_cast<uint32_t>(ld) * static_cast<uint32_t>(sizeof(TI));
+    auto request = [&](TI (&x)[YPS]) {
 #pragma unroll
         for (int y = 0; y < YPS; ++y)
-            x[y] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(col) + static_cast<uint64_t>(tix[y]) * ld4);
+            x[y] = *reinterpret_cast<const TI*>(reinterpret_cast<const char*>(col) + static_cast<uint64_t>(tix[y]) * ld4);
     };
 
-    float x_raw[YPS];
+    TI x_in[YPS];           // the samples as requested (one row ahead)
     point_at(ch.warm_start);
-    request(x_raw);
+    request(x_in);
 
     int m = (ch.warm_start - step_min) % R;
     // carried across rows, uniform over the lanes of a cell
@@ -537,6 +546,13 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
         uint32_t cmask = ALLC;
         hmask = 0;
         bool wave_hold = false;
+        // the samples of this row as float32 (narrowed and checked for float64 input)
+        float x_raw[YPS];
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) {
+            x_raw[y] = static_cast<float>(x_in[y]);
+            if constexpr (kNarrow) lossy |= (static_cast<TI>(x_raw[y]) != x_in[y]) && (x_in[y] == x_in[y]);
+        }
         float xs = x_raw[0];
 #pragma unroll
         for (int y = 1; y < YPS; ++y) xs += x_raw[y];
@@ -626,7 +642,7 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
         if (s + 1 < ch.end) {
             if (sf_nxt & 2u) advance();
             else point_at(s + 1);
-            request(x_raw);
+            request(x_in);
         }
         tick(0);
 
@@ -1074,7 +1090,15 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
         // (profiles/r3_rendezvous.txt): no rendezvous at all is 3 % faster (55.3 against 56.9 ms) but fetches 1.65 x
         // the algorithmic bytes -- every line again for the wave that comes late; bounding the lead of a wave by 8..32
         // rows through a counter in LDS does not help (1.6 x: the partner has to arrive within about three rows).
-        if ((s & 31) == 31) __syncthreads();
+        if constexpr (kNarrow) {
+            // (no rendezvous here: a wave that has seen a lossy sample leaves, and the others must not wait for it)
+            if ((s & 63) == 63 && __any(lossy)) {
+                if (lossy) atomicOr(narrow_flag, 1u);
+                return;
+            }
+        } else {
+            if ((s & 31) == 31) __syncthreads();
+        }
         sf_cur = sf_nxt;
         sf_nxt = sf_nn;
     }
@@ -1095,6 +1119,9 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
             ring[y][0] = e0;
         }
     }
+    }
+    if constexpr (kNarrow) {
+        if (lossy) atomicOr(narrow_flag, 1u);
     }
     if (STATS && stats != nullptr && lane == 0) {
         atomicAdd(&stats[0], static_cast<unsigned long long>(st_rows));
@@ -1122,15 +1149,22 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
 // ---------------------------------------------------------------------------
 namespace {
 typedef void (*Ring3Kernel)(const float*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*, int32_t,
-                            const DevChunk*, double, int, int32_t, double*, double*, int64_t, unsigned long long*);
-struct Ring3Entry { int yps, subs; Ring3Kernel fn, fn_stats; };
-#define XMHW_R3(Y, S) {Y, S, clim_ring3_f32<Y, S, false>, clim_ring3_f32<Y, S, true>}
+                            const DevChunk*, double, int, int32_t, double*, double*, int64_t, unsigned long long*,
+                            uint32_t*);
+typedef void (*Ring3KernelN)(const double*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*, int32_t,
+                             const DevChunk*, double, int, int32_t, double*, double*, int64_t, unsigned long long*,
+                             uint32_t*);
+struct Ring3Entry { int yps, subs; Ring3Kernel fn, fn_stats; Ring3KernelN fn_narrow; };
+#define XMHW_R3(Y, S) {Y, S, clim_ring3_f32<Y, S, false>, clim_ring3_f32<Y, S, true>, nullptr}
+// (with the narrowing instantiation for float64 input: the layouts the automatic choice uses)
+#define XMHW_R3N(Y, S) {Y, S, clim_ring3_f32<Y, S, false>, clim_ring3_f32<Y, S, true>, clim_ring3_f32<Y, S, false, double>}
 const Ring3Entry kRing3[] = {
     XMHW_R3(2, 8), XMHW_R3(3, 8), XMHW_R3(4, 8), XMHW_R3(5, 8), XMHW_R3(6, 8),
-    XMHW_R3(3, 4), XMHW_R3(4, 4), XMHW_R3(5, 4), XMHW_R3(6, 4), XMHW_R3(7, 4), XMHW_R3(8, 4), XMHW_R3(9, 4),
-    XMHW_R3(10, 4), XMHW_R3(11, 4), XMHW_R3(12, 4),
+    XMHW_R3(3, 4), XMHW_R3(4, 4), XMHW_R3(5, 4), XMHW_R3(6, 4), XMHW_R3N(7, 4), XMHW_R3N(8, 4), XMHW_R3N(9, 4),
+    XMHW_R3N(10, 4), XMHW_R3N(11, 4), XMHW_R3N(12, 4),
 };
 #undef XMHW_R3
+#undef XMHW_R3N
 const Ring3Entry* find_ring3(int32_t yps, int32_t subs) {
     for (const auto& e : kRing3)
         if (e.yps == yps && e.subs == subs) return &e;
@@ -1161,7 +1195,30 @@ hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
     const int64_t cells_per_block = (64 / subs) * kWaves3;
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
     hipLaunchKernelGGL(stats ? e->fn_stats : e->fn, grid, dim3(64 * kWaves3), 0, stream, ts, C, ld, Tn, table, sflags,
-                       step_min, chunks, q, negate, ntracks, thresh, seas, ldo, stats);
+                       step_min, chunks, q, negate, ntracks, thresh, seas, ldo, stats, static_cast<uint32_t*>(nullptr));
+    return hipGetLastError();
+}
+
+bool ring3_narrowing_supported(int32_t w, int32_t yps, int32_t subs) {
+    const Ring3Entry* e = w == 5 ? find_ring3(yps, subs) : nullptr;
+    return e != nullptr && e->fn_narrow != nullptr;
+}
+
+// float64 input on the float32 kernel: the flag must have been cleared and the sparse probe queued by the caller
+// (launch_narrow_probe, kernels_ring.hip); the kernel leaves as soon as the flag is set
+hipError_t launch_ring3_f32_narrowing(const double* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
+                                      const uint32_t* sflags, int32_t step_min, const DevChunk* chunks,
+                                      int32_t nchunks, int32_t w, int32_t yps, int32_t subs, int32_t ntracks, double q,
+                                      int negate, double* thresh, double* seas, int64_t ldo, hipStream_t stream,
+                                      uint32_t* narrow_flag) {
+    const Ring3Entry* e = w == 5 ? find_ring3(yps, subs) : nullptr;
+    if (!e || !e->fn_narrow || !narrow_flag || ld >= (int64_t(1) << 29)) return hipErrorInvalidValue;
+    if (C <= 0 || nchunks <= 0) return hipSuccess;
+    const int kWaves3 = waves3(subs);
+    const int64_t cells_per_block = (64 / subs) * kWaves3;
+    dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
+    hipLaunchKernelGGL(e->fn_narrow, grid, dim3(64 * kWaves3), 0, stream, ts, C, ld, Tn, table, sflags, step_min, chunks,
+                       q, negate, ntracks, thresh, seas, ldo, static_cast<unsigned long long*>(nullptr), narrow_flag);
     return hipGetLastError();
 }
 
