@@ -373,9 +373,15 @@ __device__ __forceinline__ uint32_t pick_reg(const uint32_t (&c)[CAP], uint32_t 
 
 constexpr int kBudget3 = 6;
 
+// NB buckets per cell, CAP sorted list slots per lane, LW words per lane list (= most keys a band may hold: the bound
+// is the cell's total, all of it may fall into one lane), JM merged slow-path list.
+// 4 lanes: a workgroup (2 waves) takes 2 * 16 * (NB + 1) + 128 * LW words = 40,064 bytes of LDS, four of them a CU's
+// 160 KB.  Lists of 24 instead of 16 words (and 216 instead of 224 buckets to pay for them) send 60 % fewer bands to
+// the slow path for being too populous: 56.9 -> 54.7 ms; 28 words / 200 buckets is no better, 24 words with 224
+// buckets costs the fourth workgroup (70.7 ms).
 template <int SUBS> struct Cfg3;
 template <> struct Cfg3<4> {   // 16 cells per wave
-    static constexpr int NB = 224, CAP = 8, LW = 16, JM = 7;
+    static constexpr int NB = 216, CAP = 8, LW = 24, JM = 7;
 };
 template <> struct Cfg3<8> {   // 8 cells per wave
     static constexpr int NB = 128, CAP = 4, LW = 16, JM = 8;
