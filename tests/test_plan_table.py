@@ -96,8 +96,9 @@ def test_too_many_tracks_falls_back_to_generic():
 
 def test_ring2_layout_choice():
     """which float32 ring kernel a plan runs on (capi.cpp: ring2_resolved): the third-generation kernel on 4 lanes
-    per cell (21) where a lane holds at least 7 tracks (25..48 tracks); otherwise the second-generation one -- 8
-    lanes per cell unless the 4-lane layout pads fewer tracks; outside both the round-1 kernel runs (-1)"""
+    per cell (21) where a lane holds at least 4 tracks (13..48 tracks: measured faster than every second-generation
+    layout there, tools/bench_ring2.py --years); otherwise the second-generation one -- 8 lanes per cell unless the
+    4-lane layout pads fewer tracks; outside both the round-1 kernel runs (-1)"""
     from xmhw_amd.device import Plan
 
     def years(n, w=5, ring2=None):
@@ -107,15 +108,17 @@ def test_ring2_layout_choice():
     assert years(40).ring2_in_use() == 21                     # 4 x 10 = 40 tracks: ring3
     assert years(30).ring2_in_use() == 21                     # 4 x 8 (2 padded)
     assert years(25).ring2_in_use() == 21 and years(48).ring2_in_use() == 21      # 7 .. 12 tracks per lane
-    assert years(24).ring2_in_use() == 8                      # 6 tracks per lane at 4 lanes: ring2 (8 x 3 = 24 exactly)
+    assert years(24).ring2_in_use() == 21 and years(13).ring2_in_use() == 21      # 4 .. 6 tracks per lane
     assert years(40, ring2=8).ring2_in_use() == 8 and years(40, ring2=20).ring2_in_use() == 20      # forced
-    assert years(20).ring2_in_use() == 10                     # 4 x 5 = 20 exactly, 8 x 3 would pad 4
-    assert Plan(np.tile(np.arange(1, 1461), 20), 5).ring2_in_use() == 10     # config 5's tstep axis
+    assert years(20).ring2_in_use() == 21                     # 4 x 5 = 20 tracks
+    assert Plan(np.tile(np.arange(1, 1461), 20), 5).ring2_in_use() == 21     # config 5's tstep axis
+    assert years(12).ring2_in_use() == 10                     # 3 tracks per lane: the second-generation kernel
     assert years(20, ring2=0).ring2_in_use() == 0             # forced
     assert years(40, ring2=7).ring2_in_use() == 7
     assert years(40, ring2=-1).ring2_in_use() == -1           # round-1 kernel
     assert years(10).ring2_in_use() == 10                     # 10 tracks: 4 x 3 = 12 slots against 8 x 2 = 16
-    assert years(16).ring2_in_use() == 8                      # 16 tracks: 8 x 2 = 4 x 4 exactly: a tie goes to 8 lanes
+    assert years(16).ring2_in_use() == 21                     # 16 tracks: 4 x 4
+    assert years(16, ring2=8).ring2_in_use() == 8             # (8 x 2 = 4 x 4 exactly: the second generation's tie goes to 8 lanes)
     assert years(43).ring2_in_use() == 21                     # 41..48 tracks (OISST 1982-2024): 4 x 11
     assert years(49).ring2_in_use() == 12 and years(96).ring2_in_use() == 12   # 49..96 tracks: 16 lanes per cell
     assert years(97).ring2_in_use() == -1                     # beyond: round-1 kernel (32 lanes per cell)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--variants", type=int, nargs="*", default=[-1, 0, 1, 2, 3, 4])
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--chunks", type=int, default=0)
+    ap.add_argument("--years", type=int, nargs=2, default=None, help="first and last year instead of the preset's")
     args = ap.parse_args()
     import xmhw_amd.device as dev
     from xmhw_amd.calendar import add_doy
@@ -30,6 +31,8 @@ def main():
                "0.25deg_nan": (1440 * 720, (1982, 2021), 0.05, False), "0.05deg_tstep": (810000, (2001, 2020), 0.0, True)}
     C, years, nan, tstep = presets[args.config]
     C = args.cells or C
+    if args.years:
+        years = tuple(args.years)
     if tstep:
         doy = np.tile(np.arange(1, 1461, dtype=np.int64), years[1] - years[0] + 1)
     else:

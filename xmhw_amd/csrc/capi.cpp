@@ -167,16 +167,18 @@ int32_t ring2_legacy(const xmhw_plan* p) {
 
 int32_t ring2_resolved(const xmhw_plan* p) {
     if (p->ring2_variant != -2) return p->ring2_variant;
-    // the third-generation kernel (kernels_ring3.hip) on 4 lanes per cell where a lane holds at least 7 tracks
-    // (w = 5, 25..48 tracks): 65 ms against 80 ms on the 0.25 degree / 40 year grid, 4.1 against 4.9 ms on the
-    // 1 degree / 30 year one; with fewer keys per lane its per-row overheads (histogram, walk, sort) outweigh the
-    // cheaper selection (20 tracks, 6-hourly share: 130.6 ms against 121.5 ms for variant 10) -- profiles/r3_*
-    if (xmhw::ring3_pick_yps(p->host.w, p->host.ntracks, 4) >= 7) return 21;
+    // the third-generation kernel (kernels_ring3.hip) on 4 lanes per cell where a lane holds at least 4 tracks
+    // (w = 5, 13..48 tracks).  1,036,800 cells, daily (tools/bench_ring2.py --years, counters on): 40 tracks 57.6 ms
+    // against 80 ms for the second-generation layouts, 24 tracks 41.8 against 59.8, 20 tracks 38.3 against 44.0,
+    // 16 tracks 34.5 against 35.3; 12 tracks 31.0 against 29.7 -- with so few keys per lane its per-row overheads
+    // (histogram, walk, sort) outweigh the cheaper selection.  The 6-hourly share of configs[4] (20 tracks): 116 against
+    // 130 ms.
+    if (xmhw::ring3_pick_yps(p->host.w, p->host.ntracks, 4) >= 4) return 21;
     return ring2_legacy(p);
 }
 
 // float64 input that is really float32 (decoded archives): which ring2 variant narrows it, and on which of the
-// plan's tables.  The third-generation kernel narrows on the layouts the automatic choice uses (7..12 tracks per lane
+// plan's tables.  The third-generation kernel narrows on the layouts the automatic choice uses (4..12 tracks per lane
 // at 4 lanes per cell); any other plan whose float32 layout is variant 20 / 21 narrows on the second-generation
 // kernel: its table is the plan's own when the lane layout is the same (4 lanes: variant 10), the 64-bit mode's
 // 8-lane table otherwise.

@@ -1166,7 +1166,7 @@ struct Ring3Entry { int yps, subs; Ring3Kernel fn, fn_stats; Ring3KernelN fn_nar
 #define XMHW_R3N(Y, S) {Y, S, clim_ring3_f32<Y, S, false>, clim_ring3_f32<Y, S, true>, clim_ring3_f32<Y, S, false, double>}
 const Ring3Entry kRing3[] = {
     XMHW_R3(2, 8), XMHW_R3(3, 8), XMHW_R3(4, 8), XMHW_R3(5, 8), XMHW_R3(6, 8),
-    XMHW_R3(3, 4), XMHW_R3(4, 4), XMHW_R3(5, 4), XMHW_R3(6, 4), XMHW_R3N(7, 4), XMHW_R3N(8, 4), XMHW_R3N(9, 4),
+    XMHW_R3(3, 4), XMHW_R3N(4, 4), XMHW_R3N(5, 4), XMHW_R3N(6, 4), XMHW_R3N(7, 4), XMHW_R3N(8, 4), XMHW_R3N(9, 4),
     XMHW_R3N(10, 4), XMHW_R3N(11, 4), XMHW_R3N(12, 4),
 };
 #undef XMHW_R3
