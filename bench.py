@@ -177,6 +177,13 @@ def live_traffic(argv):
     return 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"], "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, this run's box and workload"
 
 
+def _ring_name(variant):
+    """the kernel a float32 plan runs on, by its layout number (include/xmhw_amd.h: xmhw_plan_set_ring2)"""
+    if variant >= 20:
+        return f"clim_ring3_f32 ({4 if variant == 21 else 8} lanes per cell, layout {variant})"
+    return f"clim_ring2_f32 (layout {variant})"
+
+
 def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, clim_finish, steps=3, parity_cells=24):
     """One more BASELINE config on this GPU: kernel + finish, `steps` timed steps (HIP events around the ring
     kernel), parity of a few cells against the oracle.  Same synthetic generator, seeds and shapes as the
@@ -230,7 +237,7 @@ def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, c
             err = max(float(np.nanmax(np.abs(got[:D] - th0) / np.abs(th0))), float(np.nanmax(np.abs(got[D:] - se0) / np.abs(se0))))
         v2 = plan.ring2_in_use() if isz == 4 and plan.kernel == "ring" else -1
         x64 = plan.f64_mode() if isz == 8 and plan.kernel == "ring" else -1
-        kname = (f"clim_ring2_f32 (variant {v2})" if v2 >= 0 else
+        kname = (_ring_name(v2) if v2 >= 0 else
                  f"clim_ring2_f32<double, 64-bit keys> (layout {x64})" if x64 >= 0 else "clim_generic")
         bpc = T * isz + 2 * D * 8
         ring_avg = float(np.mean(ring_ms))
@@ -376,7 +383,7 @@ def run(args):
     achieved = cells_per_launch * bytes_per_cell / (ring_avg_ms * 1e-3) / 1e9
     v2 = plan.ring2_in_use() if isz == 4 and plan.kernel == "ring" else -1
     x64 = plan.f64_mode() if isz == 8 and plan.kernel == "ring" else -1
-    kname = (f"clim_ring2_f32 (variant {v2})" if v2 >= 0 else
+    kname = (_ring_name(v2) if v2 >= 0 else
              f"clim_ring2_f32<double, 64-bit keys> (layout {x64})" if x64 >= 0 else
              "clim_generic" if isz == 8 else
              ("clim_ring_" + args.dtype if plan.kernel == "ring" else "clim_generic"))
