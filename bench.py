@@ -185,6 +185,13 @@ def _ring_name(variant):
     return f"clim_ring2_f32 (layout {variant})"
 
 
+def _ring_name_f64(layout):
+    """the kernel genuinely float64 samples run on (64-bit keys as high / low words), by its layout number"""
+    if layout >= 20:
+        return f"clim_ring3_f32<double, 64-bit keys> (8 lanes per cell, layout {layout})"
+    return f"clim_ring2_f32<double, 64-bit keys> (layout {layout})"
+
+
 def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, clim_finish, steps=3, parity_cells=24):
     """One more BASELINE config on this GPU: kernel + finish, `steps` timed steps (HIP events around the ring
     kernel), parity of a few cells against the oracle.  Same synthetic generator, seeds and shapes as the
@@ -239,7 +246,7 @@ def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, c
         v2 = plan.ring2_in_use() if isz == 4 and plan.kernel == "ring" else -1
         x64 = plan.f64_mode() if isz == 8 and plan.kernel == "ring" else -1
         kname = (_ring_name(v2) if v2 >= 0 else
-                 f"clim_ring2_f32<double, 64-bit keys> (layout {x64})" if x64 >= 0 else "clim_generic")
+                 _ring_name_f64(x64) if x64 >= 0 else "clim_generic")
         bpc = T * isz + 2 * D * 8
         ring_avg = float(np.mean(ring_ms))
         return {"workload": f"{ps['name']}: {C} cells, T={T}, D={D}, nan_frac={ps['nan']}", "dtype": f"{dtype} in / f64 out",
@@ -385,7 +392,7 @@ def run(args):
     v2 = plan.ring2_in_use() if isz == 4 and plan.kernel == "ring" else -1
     x64 = plan.f64_mode() if isz == 8 and plan.kernel == "ring" else -1
     kname = (_ring_name(v2) if v2 >= 0 else
-             f"clim_ring2_f32<double, 64-bit keys> (layout {x64})" if x64 >= 0 else
+             _ring_name_f64(x64) if x64 >= 0 else
              "clim_generic" if isz == 8 else
              ("clim_ring_" + args.dtype if plan.kernel == "ring" else "clim_generic"))
 

@@ -160,10 +160,11 @@ int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out16);
 int xmhw_plan_set_ring2(xmhw_plan *plan, int32_t variant);
 /* the variant float32 input of this plan will run on, -1 if the round-1 / generic kernel */
 int xmhw_plan_ring2_in_use(const xmhw_plan *plan, int32_t *variant);
-/* genuinely float64 samples (those that do not narrow to float32): the layout variant of the
- * second-generation kernel's 64-bit mode this plan will run on (8 / 10: the float32 layouts, 12: 16
- * lanes per cell), or -1 (generic kernel; the round-1 float64 ring only on an explicit
- * XMHW_KERNEL_RING request).  w = 5, up to 96 tracks.                                           */
+/* genuinely float64 samples (those that do not narrow to float32): the layout of the 64-bit mode
+ * (64-bit keys as a high word -- what the selection runs on -- and a low word) this plan will run on:
+ * 20 = the third-generation kernel on 8 lanes per cell (9..40 tracks; XMHW_RING3_F64=0 turns it off),
+ * 8 = the second-generation kernel on 8 lanes per cell (41..48 tracks), 12 = on 16 lanes per cell
+ * (other records up to 96 tracks), or -1 (generic kernel).  w = 5.                              */
 int xmhw_plan_f64_mode(const xmhw_plan *plan, int32_t *variant);
 
 /* ---- the hot path ------------------------------------------------------ *

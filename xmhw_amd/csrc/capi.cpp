@@ -108,6 +108,15 @@ X64Choice x64_choice(const xmhw_plan* p) {
     // 8 lanes per cell: low words in registers up to 4 tracks per lane (9..32 tracks), in LDS at 5 and 6 (33..48) ...
     const int32_t y8 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 8);
     static const bool lds_on = [] { const char* v = std::getenv("XMHW_RING2_F64_LDS"); return !(v && v[0] == '0'); }();
+    // (the third-generation kernel's 64-bit mode where both rings fit its registers: up to 5 tracks per lane = 9..40
+    // tracks, layout 20; XMHW_RING3_F64=0 keeps the second-generation kernel)
+    static const bool r3_on = [] { const char* v = std::getenv("XMHW_RING3_F64"); return !(v && v[0] == '0'); }();
+    if (r3_on && y8 > 0 && xmhw::ring3_pick_yps(p->host.w, p->host.ntracks, 8) == y8 &&
+        xmhw::ring3_x64_supported(p->host.w, y8, 8)) {
+        c.variant = 20;
+        c.yps = y8;
+        return c;
+    }
     if (y8 > 0 && (y8 <= 4 || lds_on) && xmhw::ring2_x64_supported(p->host.w, y8, 8)) {
         c.variant = 8;
         c.yps = y8;
@@ -212,7 +221,7 @@ int upload(xmhw_plan* p, int64_t C) {
     std::lock_guard<std::mutex> lock(p->mu);
     const int32_t nchunks = auto_chunks(p, C);
     const X64Choice xc0 = x64_choice(p);
-    const bool need_x = xc0.variant == 8 && !(p->subs2 == 8 && p->yps2 == xc0.yps);
+    const bool need_x = (xc0.variant == 8 || xc0.variant == 20) && !(p->subs2 == 8 && p->yps2 == xc0.yps);
     if (p->uploaded && nchunks == p->nchunks &&
         p->subs2 == xmhw::ring2_subs(ring2_resolved(p)) &&
         p->yps2 == (ring2_resolved(p) >= 0 ? xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, ring2_resolved(p)) : 0) &&
@@ -259,7 +268,7 @@ int upload(xmhw_plan* p, int64_t C) {
     {
         // the 64-bit mode's own 8-lane table, when the float32 layout of this plan is a different one
         const X64Choice xc = x64_choice(p);
-        if (xc.variant == 8 && !(p->subs2 == 8 && p->yps2 == xc.yps) && p->ypsx != xc.yps) {
+        if ((xc.variant == 8 || xc.variant == 20) && !(p->subs2 == 8 && p->yps2 == xc.yps) && p->ypsx != xc.yps) {
             if (p->d_tablex) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p->d_tablex)); p->d_tablex = nullptr; }
             const std::vector<uint32_t> tx = h.ring_table(8, xc.yps);
             HIP_TRY(hipMalloc(&p->d_tablex, sizeof(uint32_t) * tx.size()));

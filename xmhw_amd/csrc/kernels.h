@@ -58,6 +58,12 @@ hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
                             double* thresh, double* seas, int64_t ldo, hipStream_t stream,
                             unsigned long long* stats = nullptr);
 
+// genuinely float64 samples: the 64-bit mode (high / low key words) of the third-generation kernel, 8 lanes per cell
+bool ring3_x64_supported(int32_t w, int32_t yps, int32_t subs);
+hipError_t launch_ring3_f64(const double* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
+                            const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,
+                            int32_t w, int32_t yps, int32_t subs, int32_t ntracks, double q, int negate, double* thresh,
+                            double* seas, int64_t ldo, hipStream_t stream, const uint32_t* run_flag);
 // the same for float64 input whose samples are float32-representable (see launch_ring2_f32_narrowing)
 bool ring3_narrowing_supported(int32_t w, int32_t yps, int32_t subs);
 hipError_t launch_ring3_f32_narrowing(const double* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,

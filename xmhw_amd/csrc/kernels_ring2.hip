@@ -1321,6 +1321,9 @@ hipError_t launch_ring2_f64(const double* ts, int64_t C, int64_t ld, int64_t Tn,
                             int32_t w, int32_t yps, int32_t ntracks, int32_t variant, double q, int negate,
                             double* thresh, double* seas, int64_t ldo, hipStream_t stream, const uint32_t* run_flag) {
     const int32_t subs = ring2_subs(variant);
+    if (variant >= 20)
+        return launch_ring3_f64(ts, C, ld, Tn, table, sflags, step_min, chunks, nchunks, w, yps, subs, ntracks, q, negate,
+                                thresh, seas, ldo, stream, run_flag);
     const Ring2Entry* e = find_ring2(w, yps, subs, variant);
     if (!e || !e->fn_x64) return hipErrorInvalidValue;
     if (C <= 0 || nchunks <= 0) return hipSuccess;

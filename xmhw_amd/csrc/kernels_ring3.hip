@@ -117,7 +117,32 @@ __device__ __forceinline__ double value_of_key3(uint32_t k) {   // 0 for an inva
     const float f = __uint_as_float(bits_of_key3(k));
     return k == kInv3 ? 0.0 : static_cast<double>(f);
 }
+// 64-bit mode (genuinely float64 samples): the order-preserving 64-bit key of a double as a HIGH word -- what the rings,
+// the histogram and the whole selection work on, exactly as on a float32 key -- and a LOW word kept beside it
+// (kernels_ring2.hip: key64_of)
+__device__ __forceinline__ void key64_of3(double v, uint32_t negmask, uint32_t& hi, uint32_t& lo) {
+    const uint64_t b = static_cast<uint64_t>(__double_as_longlong(v));
+    const uint32_t bh = static_cast<uint32_t>(b >> 32), bl = static_cast<uint32_t>(b);
+    const uint32_t sgn = ashr31_3(bh);                       // all ones for a negative sample
+    hi = bh ^ (sgn | 0x80000000u) ^ negmask;
+    lo = bl ^ sgn ^ negmask;
+}
+// the double a VALID key pair stands for (the negated sample under coldSpells)
+__device__ __forceinline__ double double_of_key64_3(uint32_t hi, uint32_t lo) {
+    const uint32_t sgn = ~ashr31_3(hi);                      // all ones if the value is negative
+    const uint32_t bh = hi ^ (sgn | 0x80000000u), bl = lo ^ sgn;
+    return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(bh) << 32) | bl));
+}
+__device__ __forceinline__ double value_of_key64_3(uint32_t hi, uint32_t lo) {      // 0 for an invalid key
+    return hi == kInv3 ? 0.0 : double_of_key64_3(hi, lo);
+}
 __device__ __forceinline__ uint32_t opaque3(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+// (a running float64 sum made opaque after every term: the rare paths that re-sum a whole ring otherwise have all their
+// keys converted ahead of the first addition -- one register pair per key)
+__device__ __forceinline__ double opaque3d(double v) {
     asm volatile("" : "+v"(v));
     return v;
 }
@@ -235,6 +260,63 @@ __device__ __forceinline__ void compact11(const RingT& r, uint32_t e0, uint32_t 
           [k6] "v"(r[6]), [k7] "v"(r[7]), [k8] "v"(r[8]), [k9] "v"(r[9]), [k10] "v"(r[10]), [e0] "v"(e0),
           [w] "v"(w)
         : "memory", "scc");
+}
+
+// 64-bit mode: compact11 with the LOW word of every band key written beside its high word (ds_write2_b32: list entries
+// are pairs, p += 8), so that the low words of the order statistics can be read from the lists instead of being
+// fetched by another pass over the rings.  In two halves (an asm statement takes 30 operands).
+template <int K0, int N, class RingT>
+__device__ __forceinline__ void compact_half_x(const RingT& r, const RingT& rl, uint32_t e0, uint32_t w, uint32_t& p) {
+    static_assert(N == 5 || N == 6, "halves of 11");
+    unsigned long long m0, m1, m2, m3, m4, m5, sv;
+    uint32_t t0, t1;
+    constexpr int K5 = N == 6 ? K0 + 5 : K0 + 4;      // (a sixth key of the second half: its mask is forced to 0)
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_sub_u32 %[t0], %[k0], %[e0]\n\t"
+        "v_sub_u32 %[t1], %[k1], %[e0]\n\t"
+        "v_cmp_lt_u32_e64 %[m0], %[t0], %[w]\n\t"
+        "v_sub_u32 %[t0], %[k2], %[e0]\n\t"
+        "v_cmp_lt_u32_e64 %[m1], %[t1], %[w]\n\t"
+        "v_sub_u32 %[t1], %[k3], %[e0]\n\t"
+        "v_cmp_lt_u32_e64 %[m2], %[t0], %[w]\n\t"
+        "v_sub_u32 %[t0], %[k4], %[e0]\n\t"
+        "v_cmp_lt_u32_e64 %[m3], %[t1], %[w]\n\t"
+        "v_sub_u32 %[t1], %[k5], %[e0]\n\t"
+        "v_cmp_lt_u32_e64 %[m4], %[t0], %[w]\n\t"
+        "v_cmp_lt_u32_e64 %[m5], %[t1], %[w]\n\t"
+        "s_and_b64 %[m5], %[m5], %[last]\n\t"
+        "s_and_b64 exec, %[sv], %[m0]\n\t"
+        "ds_write2_b32 %[p], %[k0], %[l0] offset1:1\n\t"
+        "v_add_u32 %[p], 8, %[p]\n\t"
+        "s_and_b64 exec, %[sv], %[m1]\n\t"
+        "ds_write2_b32 %[p], %[k1], %[l1] offset1:1\n\t"
+        "v_add_u32 %[p], 8, %[p]\n\t"
+        "s_and_b64 exec, %[sv], %[m2]\n\t"
+        "ds_write2_b32 %[p], %[k2], %[l2] offset1:1\n\t"
+        "v_add_u32 %[p], 8, %[p]\n\t"
+        "s_and_b64 exec, %[sv], %[m3]\n\t"
+        "ds_write2_b32 %[p], %[k3], %[l3] offset1:1\n\t"
+        "v_add_u32 %[p], 8, %[p]\n\t"
+        "s_and_b64 exec, %[sv], %[m4]\n\t"
+        "ds_write2_b32 %[p], %[k4], %[l4] offset1:1\n\t"
+        "v_add_u32 %[p], 8, %[p]\n\t"
+        "s_and_b64 exec, %[sv], %[m5]\n\t"
+        "ds_write2_b32 %[p], %[k5], %[l5] offset1:1\n\t"
+        "v_add_u32 %[p], 8, %[p]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [p] "+v"(p), [t0] "=&v"(t0), [t1] "=&v"(t1), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2),
+          [m3] "=&s"(m3), [m4] "=&s"(m4), [m5] "=&s"(m5), [sv] "=&s"(sv)
+        : [k0] "v"(r[K0]), [k1] "v"(r[K0 + 1]), [k2] "v"(r[K0 + 2]), [k3] "v"(r[K0 + 3]), [k4] "v"(r[K0 + 4]),
+          [k5] "v"(r[K5]), [l0] "v"(rl[K0]), [l1] "v"(rl[K0 + 1]), [l2] "v"(rl[K0 + 2]), [l3] "v"(rl[K0 + 3]),
+          [l4] "v"(rl[K0 + 4]), [l5] "v"(rl[K5]), [e0] "v"(e0), [w] "v"(w),
+          [last] "s"(N == 6 ? ~0ull : 0ull)
+        : "memory", "scc");
+}
+template <class RingT>
+__device__ __forceinline__ void compact11x(const RingT& r, const RingT& rl, uint32_t e0, uint32_t w, uint32_t& p) {
+    compact_half_x<0, 6>(r, rl, e0, w, p);
+    compact_half_x<6, 5>(r, rl, e0, w, p);
 }
 
 // ---- slow path: the round-2 extraction list (kernels_ring2.hip: Top2), on the adjacent lane layout ----
@@ -400,15 +482,25 @@ constexpr float kBucketRanks = 3.5f;
 // reader): the samples are narrowed on load, `narrow_flag` is set as soon as one does not survive the round trip, the
 // kernel gives up and the float64 kernel queued behind it (which looks at the same flag) does the work instead
 // (the protocol of kernels_ring2.hip).
-template <int YPS, int SUBS, bool STATS, typename TI = float>
+// X64 (TI = double): genuinely float64 samples.  The rings hold the HIGH words of the 64-bit keys -- histogram, walk,
+// band compaction, sort and the slow path run on them exactly as on float32 keys -- and, in a second set of tuples,
+// the LOW words; once the two order statistics are known by their high words, one pass over the rings fetches their low
+// words (a tie of high words -- repeated values, or distinct doubles within 2^-20 relative of each other at the target
+// rank -- is settled by successive minima of the low words: kernels_ring2.hip).  `narrow_flag` is then the RUN flag:
+// the kernel is queued behind the narrowing one and returns unless that one gave up.
+template <int YPS, int SUBS, bool STATS, typename TI = float, bool X64 = false>
 __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
     const TI* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, int32_t step_min, const DevChunk* __restrict__ chunks, double q,
     int negate, int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
     unsigned long long* __restrict__ stats, uint32_t* __restrict__ narrow_flag) {
-    constexpr bool kNarrow = sizeof(TI) == 8;
+    static_assert(!X64 || sizeof(TI) == 8, "the 64-bit mode takes double input");
+    constexpr bool kNarrow = sizeof(TI) == 8 && !X64;
     if constexpr (kNarrow) {
         if (*narrow_flag != 0) return;           // the probe (or another workgroup) already found a lossy sample
+    }
+    if constexpr (X64) {
+        if (narrow_flag != nullptr && *narrow_flag == 0) return;     // the narrowing kernel did the work
     }
     bool lossy = false;
     constexpr int W = 5;
@@ -420,7 +512,8 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
     constexpr int NB = Cfg3<SUBS>::NB;           // buckets per cell
     constexpr int HS = NB + 1;                   // words per cell histogram (one bank of skew per cell)
     constexpr int CAP = Cfg3<SUBS>::CAP;         // list slots per lane that are sorted
-    constexpr int LW = Cfg3<SUBS>::LW;           // words per lane list = most keys a band may hold (MCAP)
+    constexpr int LW = Cfg3<SUBS>::LW;           // entries per lane list = most keys a band may hold (MCAP)
+    constexpr int LWL = X64 ? 2 * LW : LW;       // words per lane list (64-bit mode: an entry is a high and a low word)
     constexpr int Q = 16 / SUBS;                 // buckets per lane of the 16 the walk looks at
     constexpr int J = 5;
     constexpr int JM = Cfg3<SUBS>::JM;
@@ -433,7 +526,7 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
     constexpr int32_t M16_TARGET = 16 * 5, M16_HI_TRIG = 16 * 11, M16_LO_TRIG = 16 * 5 / 2, M16_HI_ADJ = 16 * 15 / 2,
                       M16_LO_ADJ = 16 * 7 / 2;
 
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kWaves3 * CPWAVE * HS + 64 * kWaves3 * LW];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kWaves3 * CPWAVE * HS + 64 * kWaves3 * LWL];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -451,7 +544,7 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
     const uint32_t full_valid = static_cast<uint32_t>((padded_last ? YPS - 1 : YPS) * R);
 
     uint32_t* const hist = lds + (wave * CPWAVE + cw) * HS;
-    uint32_t* const list = lds + kWaves3 * CPWAVE * HS + threadIdx.x * LW;
+    uint32_t* const list = lds + kWaves3 * CPWAVE * HS + threadIdx.x * LWL;
     // LDS byte address of this lane's list (the low 32 bits of a generic LDS pointer are the LDS offset)
     const uint32_t list_addr =
         static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t*)list));
@@ -466,6 +559,14 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
     RingT ring[YPS];
 #pragma unroll
     for (int y = 0; y < YPS; ++y) ring[y] = kInv3;
+    RingT ringlo[X64 ? YPS : 1];                 // 64-bit mode: the low words of the keys, slot for slot
+#pragma unroll
+    for (int y = 0; y < (X64 ? YPS : 1); ++y) ringlo[y] = kInv3;
+    // the value a key stands for (0 for an invalid key): slot k of track y / a key with its low word
+    auto val_at = [&](int y, int k) __attribute__((always_inline)) -> double {
+        if constexpr (X64) return value_of_key64_3(opaque3(ring[y][k]), opaque3(ringlo[y][k]));
+        else return value_of_key3(opaque3(ring[y][k]));
+    };
     double lsum = 0.0;
     uint32_t nval = 0;
 
@@ -534,7 +635,7 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
     };
 
     // inputs of the epilogue of the row this lane finishes (see below)
-    uint32_t e_alo = 0, e_ahi = 0, e_n = 0;
+    uint32_t e_alo = 0, e_ahi = 0, e_n = 0, e_la = 0, e_lb = 0;
     double e_total = 0.0, e_g = 0.0;
 
     uint32_t hmask = 0;
@@ -554,21 +655,43 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
         bool wave_hold = false;
         // the samples of this row as float32 (narrowed and checked for float64 input)
         float x_raw[YPS];
+        uint32_t khi[X64 ? YPS : 1], kin_lo[X64 ? YPS : 1], kout_lo[X64 ? YPS : 1];      // 64-bit mode: key words
+        uint32_t nanbits = 0;                                                              // ... bit y: sample y is NaN
 #pragma unroll
         for (int y = 0; y < YPS; ++y) {
-            x_raw[y] = static_cast<float>(x_in[y]);
+            x_raw[y] = X64 ? 0.0f : static_cast<float>(x_in[y]);
             if constexpr (kNarrow) lossy |= (static_cast<TI>(x_raw[y]) != x_in[y]) && (x_in[y] == x_in[y]);
+            if constexpr (X64) {
+                const double v = static_cast<double>(x_in[y]);
+                key64_of3(v, negmask, khi[y], kin_lo[y]);
+                nanbits |= (v != v ? 1u : 0u) << y;
+            }
         }
-        float xs = x_raw[0];
+        bool row_nan;
+        if constexpr (X64) {
+            row_nan = nanbits != 0;
+        } else {
+            float xs = x_raw[0];
 #pragma unroll
-        for (int y = 1; y < YPS; ++y) xs += x_raw[y];
-        const bool row_nan = xs != xs;
+            for (int y = 1; y < YPS; ++y) xs += x_raw[y];
+            row_nan = xs != xs;
+        }
         const bool fast = (sf & 1u) && clean && !__any(row_nan);
-        auto key_in = [&](int y) -> uint32_t { return key_of_bits3(__float_as_uint(x_raw[y]), negmask); };
-        auto is_nan = [&](int y) -> bool { return x_raw[y] != x_raw[y]; };
+        auto key_in = [&](int y) -> uint32_t {
+            if constexpr (X64) return khi[y];
+            else return key_of_bits3(__float_as_uint(x_raw[y]), negmask);
+        };
+        auto is_nan = [&](int y) -> bool {
+            if constexpr (X64) return ((nanbits >> y) & 1u) != 0;
+            else return x_raw[y] != x_raw[y];
+        };
         if (fast) {
             if constexpr (STATS) ++st_fast;
-            if (negate) {
+            if constexpr (X64) {
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) kin[y] = khi[y];
+                kin_lo[YPS - 1] |= padmask;
+            } else if (negate) {
 #pragma unroll
                 for (int y = 0; y < YPS; ++y) kin[y] = key_of_bits3_fast<true>(__float_as_uint(x_raw[y]));
             } else {
@@ -578,8 +701,13 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
             kin[YPS - 1] |= padmask;
         } else if (sf & 1u) {
 #pragma unroll
-            for (int y = 0; y < YPS; ++y) kin[y] = !is_nan(y) ? key_in(y) : kInv3;
+            for (int y = 0; y < YPS; ++y) {
+                const bool ok = !is_nan(y);
+                kin[y] = ok ? key_in(y) : kInv3;
+                if constexpr (X64) kin_lo[y] = ok ? kin_lo[y] : kInv3;
+            }
             kin[YPS - 1] |= padmask;
+            if constexpr (X64) kin_lo[YPS - 1] |= padmask;
         } else {
             uint32_t e_cur[YPS];
             entries_of(s, e_cur);
@@ -591,18 +719,31 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
                 hmask |= (code == kCodeHold ? 1u : 0u) << y;
                 const bool ok = code >= 2u && !is_nan(y);
                 kin[y] = ok ? key_in(y) : kInv3;
+                if constexpr (X64) kin_lo[y] = ok ? kin_lo[y] : kInv3;
             }
             wave_hold = __any(hmask != 0);
         }
         // ---- the one place where the rings are written (slot m of every track) ------------
 #pragma unroll
         for (int y = 0; y < YPS; ++y) kout[y] = ring[y][m];
+        if constexpr (X64) {
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) kout_lo[y] = opaque3(ringlo[y][m]);      // (opaque: or the extract is sunk below
+                                                                                      // the write and the old tuple kept)
+        }
         if (wave_hold) {
 #pragma unroll
-            for (int y = 0; y < YPS; ++y) kin[y] = ((hmask >> y) & 1u) ? kout[y] : kin[y];
+            for (int y = 0; y < YPS; ++y) {
+                kin[y] = ((hmask >> y) & 1u) ? kout[y] : kin[y];
+                if constexpr (X64) kin_lo[y] = ((hmask >> y) & 1u) ? kout_lo[y] : kin_lo[y];
+            }
         }
 #pragma unroll
         for (int y = 0; y < YPS; ++y) ring[y][m] = kin[y];
+        if constexpr (X64) {
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) ringlo[y][m] = kin_lo[y];
+        }
         // ---- the histogram mirrors the ring (a held track adds and removes the same key) ------
 #pragma unroll
         for (int y = 0; y < YPS; ++y) {
@@ -620,23 +761,35 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
             double din, dout;
 #pragma unroll
             for (int y = 0; y < YPS; ++y) {
-                uint32_t bi = __float_as_uint(x_raw[y]);
-                uint32_t bo = bits_of_key3(kout[y]);
-                if (y == YPS - 1) {
-                    bi &= ~padmask;
-                    bo &= ~padmask;
+                double di, dq;
+                if constexpr (X64) {
+                    // (from the key words: the samples themselves are not kept; a padded track's key is invalid = 0)
+                    di = value_of_key64_3(kin[y], kin_lo[y]);
+                    dq = value_of_key64_3(kout[y], kout_lo[y]);
+                } else {
+                    uint32_t bi = __float_as_uint(x_raw[y]);
+                    uint32_t bo = bits_of_key3(kout[y]);
+                    if (y == YPS - 1) {
+                        bi &= ~padmask;
+                        bo &= ~padmask;
+                    }
+                    di = static_cast<double>(__uint_as_float(bi));
+                    dq = static_cast<double>(__uint_as_float(bo));
                 }
-                const double di = static_cast<double>(__uint_as_float(bi));
-                const double dq = static_cast<double>(__uint_as_float(bo));
                 din = y == 0 ? di : din + di;
                 dout = y == 0 ? dq : dout + dq;
             }
-            lsum += (negate ? -din : din) - dout;
+            lsum += ((negate && !X64) ? -din : din) - dout;
         } else {
 #pragma unroll
             for (int y = 0; y < YPS; ++y) {
+                if constexpr (X64) {
+                    lsum += value_of_key64_3(kin[y], kin_lo[y]);
+                    lsum -= value_of_key64_3(kout[y], kout_lo[y]);
+                } else {
                 lsum += value_of_key3(kin[y]);
                 lsum -= value_of_key3(kout[y]);
+                }
                 nval += (kin[y] != kInv3 ? 1u : 0u) - (kout[y] != kInv3 ? 1u : 0u);
             }
             rotate = wave_hold;
@@ -671,7 +824,7 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
                     for (int k = 0; k < R; ++k) {
                         const uint32_t key = opaque3(ring[y][k]);
                         cy += key != kInv3 ? 1u : 0u;
-                        ty += value_of_key3(key);
+                        ty = opaque3d(ty + val_at(y, k));
                     }
                     const bool cnt = (cmask >> y) & 1u;
                     nl += cnt ? cy : 0u;
@@ -686,7 +839,7 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
                 for (int y = 0; y < YPS; ++y) {
                     double ty = 0.0;
 #pragma unroll
-                    for (int k = 0; k < R; ++k) ty += value_of_key3(opaque3(ring[y][k]));
+                    for (int k = 0; k < R; ++k) ty = opaque3d(ty + val_at(y, k));
                     t += ty;
                     tl += ((cmask >> y) & 1u) ? ty : 0.0;
                 }
@@ -722,6 +875,8 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
             };
 
             bool resolved = (n == 0);
+            uint32_t la = 0, lb = 0;      // 64-bit mode: the low words of the two order statistics
+            bool low_done = false;        // ... already taken from the band lists
             uint32_t alo = 0, ahi = 0, pe = 0, Fe = 0;
             bool band_done = false;       // this cell was settled by the band path
             bool lost = false;            // this cell's window must be rebuilt (anchor lost, target off the block)
@@ -780,18 +935,34 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
                 tick(2);
                 // ---- 2. compaction: the keys of the band, appended to this lane's list ----------
 #pragma unroll
-                for (int i = 0; i < CAP; i += 4)
+                for (int i = 0; i < (X64 ? 2 * CAP : CAP); i += 4)
                     *reinterpret_cast<uint4*>(list + i) = make_uint4(kInv3, kInv3, kInv3, kInv3);
                 uint32_t ptr = list_addr;
-#pragma unroll
-                for (int y = 0; y < YPS; ++y) compact11(ring[y], E0, width, ptr);
-                const uint32_t cntl = (ptr - list_addr) >> 2;
-                tick(3);
+                uint32_t cntl;
                 uint32_t c[CAP];
+                uint32_t bh[X64 ? CAP : 1], bl[X64 ? CAP : 1];     // 64-bit mode: the lane's band entries as read back
+                if constexpr (X64) {
 #pragma unroll
-                for (int i = 0; i < CAP; i += 4) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(list + i);
-                    c[i] = v.x; c[i + 1] = v.y; c[i + 2] = v.z; c[i + 3] = v.w;
+                    for (int y = 0; y < YPS; ++y) compact11x(ring[y], ringlo[y], E0, width, ptr);
+                    cntl = (ptr - list_addr) >> 3;
+                    tick(3);
+#pragma unroll
+                    for (int i = 0; i < CAP; i += 2) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(list + 2 * i);
+                        bh[i] = v.x; bl[i] = v.y; bh[i + 1] = v.z; bl[i + 1] = v.w;
+                    }
+#pragma unroll
+                    for (int i = 0; i < CAP; ++i) c[i] = bh[i];
+                } else {
+#pragma unroll
+                    for (int y = 0; y < YPS; ++y) compact11(ring[y], E0, width, ptr);
+                    cntl = (ptr - list_addr) >> 2;
+                    tick(3);
+#pragma unroll
+                    for (int i = 0; i < CAP; i += 4) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(list + i);
+                        c[i] = v.x; c[i + 1] = v.y; c[i + 2] = v.z; c[i + 3] = v.w;
+                    }
                 }
                 // (mm == mb always: the histogram mirrors the ring; the check costs one reduction and turns a
                 // bookkeeping error into a slow row instead of a wrong one)
@@ -815,6 +986,69 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
                     const uint32_t va = pick_reg<CAP>(c, j & (CAP - 1)), vb = pick_reg<CAP>(c, j1 & (CAP - 1));
                     xa = cmax<SUBS>((static_cast<uint32_t>(sub) == j / CAP) ? va : 0u);
                     xb = cmax<SUBS>((static_cast<uint32_t>(sub) == j1 / CAP) ? vb : 0u);
+                }
+                if constexpr (X64) {
+                    // ---- the low words of the two picks, from the lists: every key that shares a high word with a
+                    // pick is in the band (same bucket), so its multiplicity and the r-th smallest low word of the
+                    // group are settled on the <= CAP entries per lane instead of a pass over the rings
+                    const uint32_t xb2 = need2 ? xb : xa;
+                    uint32_t ca = 0, cb = 0, ta = 0, tb = 0, fa = 0;
+#pragma unroll
+                    for (int i = 0; i < CAP; ++i) {
+                        const bool ea = bh[i] == xa, eb = bh[i] == xb2;
+                        ca += ea ? 1u : 0u;
+                        cb += eb ? 1u : 0u;
+                        ta = ea ? bl[i] : ta;
+                        tb = eb ? bl[i] : tb;
+                        fa += bh[i] < xa ? 1u : 0u;
+                    }
+                    ca = csum<SUBS>(ca);
+                    cb = csum<SUBS>(cb);
+                    ta = cmax<SUBS>(ta);            // (exact for a group of one: the other lanes offer 0)
+                    tb = cmax<SUBS>(tb);
+                    const bool tie_a = bok && ca > 1u, tie_b = bok && need2 && cb > 1u;
+                    if (__any(tie_a || tie_b)) {
+                        const uint32_t below_a = csum<SUBS>(fa);                         // band entries below group A
+                        const uint32_t ra = j - below_a;                                   // rank inside group A
+                        const uint32_t rb = xb2 == xa ? ra + 1u : j1 - (below_a + ca);     // rank inside group B
+                        auto nth_low = [&](uint32_t H, uint32_t r, bool want) -> uint32_t {
+                            uint32_t prev = 0, rem = r, ans = 0;
+                            bool have_prev = false, open = want;
+                            while (__any(open)) {
+                                uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+                                for (int i = 0; i < CAP; ++i) {
+                                    const bool in = bh[i] == H && (!have_prev || bl[i] > prev);
+                                    mn = in ? minu3(mn, bl[i]) : mn;
+                                }
+                                mn = cmin<SUBS>(mn);
+                                uint32_t cnt = 0;
+#pragma unroll
+                                for (int i = 0; i < CAP; ++i) cnt += (bh[i] == H && bl[i] == mn) ? 1u : 0u;
+                                cnt = csum<SUBS>(cnt);
+                                if (open) {
+                                    if (rem < cnt || cnt == 0u) {
+                                        ans = mn;
+                                        open = false;
+                                    } else {
+                                        rem -= cnt;
+                                        prev = mn;
+                                        have_prev = true;
+                                    }
+                                }
+                            }
+                            return ans;
+                        };
+                        const uint32_t ya = nth_low(xa, ra, tie_a);
+                        const uint32_t yb = nth_low(xb2, rb, tie_b);
+                        ta = tie_a ? ya : ta;
+                        tb = tie_b ? yb : tb;
+                    }
+                    if (bok) {
+                        la = ta;
+                        lb = tb;
+                        low_done = true;
+                    }
                 }
                 if constexpr (STATS) {
                     st_try += btry ? 1u : 0u;
@@ -982,6 +1216,91 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
                 }
             }
 
+            // ---- 64-bit mode: the low words of the two order statistics (alo, ahi are HIGH words) ----------
+            if constexpr (X64) {
+            if (!__all(low_done || n == 0)) {
+                // (only rows on which some cell went through the slow path: the band path reads the low words from
+                // its lists)  One pass: how many pooled keys carry each high word, and the low word of one of them
+                const uint32_t la_band = la, lb_band = lb;
+                la = 0;
+                lb = 0;
+                uint32_t ca = 0, cb = 0;
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) {
+                    const bool cnt = wallc || ((cmask >> y) & 1u);
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const uint32_t key = opaque3(ring[y][k]), l = opaque3(ringlo[y][k]);
+                        const bool ea = cnt && key == alo, eb = cnt && key == ahi;
+                        ca += ea ? 1u : 0u;
+                        cb += eb ? 1u : 0u;
+                        la = ea ? l : la;
+                        lb = eb ? l : lb;
+                    }
+                }
+                ca = csum<SUBS>(ca);
+                cb = csum<SUBS>(cb);
+                la = cmax<SUBS>(la);            // (exact when the cell holds ONE such key: the other lanes offer 0)
+                lb = cmax<SUBS>(lb);
+                // ties of high words (repeated values, or distinct doubles within 2^-20 of each other at the target
+                // rank): the r-th smallest low word of the group, by successive minima with their multiplicities
+                const bool tie_a = n > 0 && ca > 1u, tie_b = n > 0 && need2 && cb > 1u;
+                if (__any(tie_a || tie_b)) {
+                    uint32_t below_a = lo;     // keys below group A: lo itself when A is a single key, otherwise counted
+                    if (__any(tie_a)) {
+                        const uint32_t c = count_le(tie_a ? alo - 1u : 0u);
+                        below_a = tie_a ? c : lo;
+                    }
+                    const uint32_t ra = lo - below_a;                                    // rank inside group A
+                    const uint32_t rb = ahi == alo ? ra + 1u : lo + 1u - (below_a + ca);   // rank inside group B
+                    auto nth_low = [&](uint32_t H, uint32_t r, bool want) -> uint32_t {
+                        uint32_t prev = 0, rem = r, ans = 0;
+                        bool have_prev = false, open = want;
+                        while (__any(open)) {
+                            uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+                            for (int y = 0; y < YPS; ++y) {
+                                const bool cnt = wallc || ((cmask >> y) & 1u);
+#pragma unroll
+                                for (int k = 0; k < R; ++k) {
+                                    const uint32_t key = opaque3(ring[y][k]), l = opaque3(ringlo[y][k]);
+                                    const bool in = cnt && key == H && (!have_prev || l > prev);
+                                    mn = in ? minu3(mn, l) : mn;
+                                }
+                            }
+                            mn = cmin<SUBS>(mn);
+                            uint32_t c = 0;
+#pragma unroll
+                            for (int y = 0; y < YPS; ++y) {
+                                const bool cnt = wallc || ((cmask >> y) & 1u);
+#pragma unroll
+                                for (int k = 0; k < R; ++k)
+                                    c += (cnt && opaque3(ring[y][k]) == H && opaque3(ringlo[y][k]) == mn) ? 1u : 0u;
+                            }
+                            c = csum<SUBS>(c);
+                            if (open) {
+                                if (rem < c || c == 0u) {       // (c == 0 cannot happen for r inside the group; it ends the loop)
+                                    ans = mn;
+                                    open = false;
+                                } else {
+                                    rem -= c;
+                                    prev = mn;
+                                    have_prev = true;
+                                }
+                            }
+                        }
+                        return ans;
+                    };
+                    const uint32_t xa = nth_low(alo, ra, tie_a);
+                    const uint32_t xb = nth_low(ahi, rb, tie_b);
+                    la = tie_a ? xa : la;
+                    lb = tie_b ? xb : lb;
+                }
+                la = low_done ? la_band : la;
+                lb = low_done ? lb_band : lb;
+            }
+            }
+
             tick(5);
             if constexpr (STATS) ++st_rows;
             // The epilogue (key -> value, numpy's lerp, the float64 division, the two stores) is the same ~50
@@ -992,6 +1311,10 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
             if (static_cast<uint32_t>(sub) == eph) {
                 e_alo = alo;
                 e_ahi = ahi;
+                if constexpr (X64) {
+                    e_la = la;
+                    e_lb = lb;
+                }
                 e_n = n;
                 e_total = total;
                 e_g = g;
@@ -999,8 +1322,14 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
             if (eph == static_cast<uint32_t>(SUBS - 1) || s + 1 == ch.end) {
                 double th = make_nan(), se = make_nan();
                 if (e_n > 0) {
-                    const double v_lo = static_cast<double>(__uint_as_float(bits_of_key3(e_alo)));
-                    const double v_hi = static_cast<double>(__uint_as_float(bits_of_key3(e_ahi)));
+                    double v_lo, v_hi;
+                    if constexpr (X64) {
+                        v_lo = double_of_key64_3(e_alo, e_la);
+                        v_hi = double_of_key64_3(e_ahi, e_lb);
+                    } else {
+                        v_lo = static_cast<double>(__uint_as_float(bits_of_key3(e_alo)));
+                        v_hi = static_cast<double>(__uint_as_float(bits_of_key3(e_ahi)));
+                    }
                     th = numpy_lerp(v_lo, v_hi, e_g);
                     se = e_total / static_cast<double>(e_n);
                 }
@@ -1123,6 +1452,19 @@ __global__ __launch_bounds__(64 * waves3(SUBS), 2) void clim_ring3_f32(
             uint32_t e0 = ring[y][0];
             ring_sel3(e0, last, hy);
             ring[y][0] = e0;
+            if constexpr (X64) {
+                const uint32_t lastl = opaque3(ringlo[y][R - 1]);
+                asm volatile("s_nop 1");
+#pragma unroll
+                for (int k = R - 1; k >= 1; --k) {
+                    uint32_t e = ringlo[y][k];
+                    ring_sel3(e, ringlo[y][k - 1], hy);
+                    ringlo[y][k] = e;
+                }
+                uint32_t l0 = ringlo[y][0];
+                ring_sel3(l0, lastl, hy);
+                ringlo[y][0] = l0;
+            }
         }
     }
     }
@@ -1160,17 +1502,20 @@ typedef void (*Ring3Kernel)(const float*, int64_t, int64_t, int64_t, const uint3
 typedef void (*Ring3KernelN)(const double*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*, int32_t,
                              const DevChunk*, double, int, int32_t, double*, double*, int64_t, unsigned long long*,
                              uint32_t*);
-struct Ring3Entry { int yps, subs; Ring3Kernel fn, fn_stats; Ring3KernelN fn_narrow; };
-#define XMHW_R3(Y, S) {Y, S, clim_ring3_f32<Y, S, false>, clim_ring3_f32<Y, S, true>, nullptr}
+struct Ring3Entry { int yps, subs; Ring3Kernel fn, fn_stats; Ring3KernelN fn_narrow, fn_x64; };
+#define XMHW_R3(Y, S) {Y, S, clim_ring3_f32<Y, S, false>, clim_ring3_f32<Y, S, true>, nullptr, nullptr}
+// (with the 64-bit mode for genuinely float64 input: 8 lanes per cell, where the two rings fit the register file)
+#define XMHW_R3X(Y, S) {Y, S, clim_ring3_f32<Y, S, false>, clim_ring3_f32<Y, S, true>, nullptr, clim_ring3_f32<Y, S, false, double, true>}
 // (with the narrowing instantiation for float64 input: the layouts the automatic choice uses)
-#define XMHW_R3N(Y, S) {Y, S, clim_ring3_f32<Y, S, false>, clim_ring3_f32<Y, S, true>, clim_ring3_f32<Y, S, false, double>}
+#define XMHW_R3N(Y, S) {Y, S, clim_ring3_f32<Y, S, false>, clim_ring3_f32<Y, S, true>, clim_ring3_f32<Y, S, false, double>, nullptr}
 const Ring3Entry kRing3[] = {
-    XMHW_R3(2, 8), XMHW_R3(3, 8), XMHW_R3(4, 8), XMHW_R3(5, 8), XMHW_R3(6, 8),
+    XMHW_R3X(2, 8), XMHW_R3X(3, 8), XMHW_R3X(4, 8), XMHW_R3X(5, 8), XMHW_R3(6, 8),
     XMHW_R3(3, 4), XMHW_R3N(4, 4), XMHW_R3N(5, 4), XMHW_R3N(6, 4), XMHW_R3N(7, 4), XMHW_R3N(8, 4), XMHW_R3N(9, 4),
     XMHW_R3N(10, 4), XMHW_R3N(11, 4), XMHW_R3N(12, 4),
 };
 #undef XMHW_R3
 #undef XMHW_R3N
+#undef XMHW_R3X
 const Ring3Entry* find_ring3(int32_t yps, int32_t subs) {
     for (const auto& e : kRing3)
         if (e.yps == yps && e.subs == subs) return &e;
@@ -1202,6 +1547,29 @@ hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
     hipLaunchKernelGGL(stats ? e->fn_stats : e->fn, grid, dim3(64 * kWaves3), 0, stream, ts, C, ld, Tn, table, sflags,
                        step_min, chunks, q, negate, ntracks, thresh, seas, ldo, stats, static_cast<uint32_t*>(nullptr));
+    return hipGetLastError();
+}
+
+bool ring3_x64_supported(int32_t w, int32_t yps, int32_t subs) {
+    const Ring3Entry* e = w == 5 ? find_ring3(yps, subs) : nullptr;
+    return e != nullptr && e->fn_x64 != nullptr;
+}
+
+// genuinely float64 samples (64-bit keys as high / low words); run_flag: device flag of the narrowing launch queued
+// before it (nullptr: always run; 0 at run time: nothing to do)
+hipError_t launch_ring3_f64(const double* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
+                            const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,
+                            int32_t w, int32_t yps, int32_t subs, int32_t ntracks, double q, int negate, double* thresh,
+                            double* seas, int64_t ldo, hipStream_t stream, const uint32_t* run_flag) {
+    const Ring3Entry* e = w == 5 ? find_ring3(yps, subs) : nullptr;
+    if (!e || !e->fn_x64 || ld >= (int64_t(1) << 29)) return hipErrorInvalidValue;
+    if (C <= 0 || nchunks <= 0) return hipSuccess;
+    const int kWaves3 = waves3(subs);
+    const int64_t cells_per_block = (64 / subs) * kWaves3;
+    dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
+    hipLaunchKernelGGL(e->fn_x64, grid, dim3(64 * kWaves3), 0, stream, ts, C, ld, Tn, table, sflags, step_min, chunks, q,
+                       negate, ntracks, thresh, seas, ldo, static_cast<unsigned long long*>(nullptr),
+                       const_cast<uint32_t*>(run_flag));
     return hipGetLastError();
 }
 
