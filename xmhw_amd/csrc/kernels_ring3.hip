@@ -490,7 +490,7 @@ constexpr float kBucketRanks = 3.5f;
 // rank -- is settled by successive minima of the low words: kernels_ring2.hip).  `narrow_flag` is then the RUN flag:
 // the kernel is queued behind the narrowing one and returns unless that one gave up.
 template <int YPS, int SUBS, bool STATS, typename TI = float, bool X64 = false>
-__global__ __launch_bounds__(64 * waves3(SUBS, sizeof(TI)), 2) void clim_ring3_f32(
+__global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_f32(
     const TI* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, int32_t step_min, const DevChunk* __restrict__ chunks, double q,
     int negate, int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
@@ -507,7 +507,9 @@ __global__ __launch_bounds__(64 * waves3(SUBS, sizeof(TI)), 2) void clim_ring3_f
     constexpr int W = 5;
     constexpr int R = 2 * W + 1;
     static_assert(SUBS == 8 || SUBS == 4, "8 or 4 lanes per cell");
-    constexpr int kWaves3 = waves3(SUBS, sizeof(TI));
+    // (the narrowing instantiation keeps the float32 shape: its waves never wait for each other, and single-wave
+    // workgroups measured 7 % slower)
+    constexpr int kWaves3 = waves3(SUBS, X64 ? 8 : 4);
     constexpr int NTP = SUBS * YPS;
     constexpr int CPWAVE = 64 / SUBS;
     constexpr int NB = Cfg3<SUBS>::NB;           // buckets per cell
@@ -1589,7 +1591,7 @@ hipError_t launch_ring3_f32_narrowing(const double* ts, int64_t C, int64_t ld, i
     const Ring3Entry* e = w == 5 ? find_ring3(yps, subs) : nullptr;
     if (!e || !e->fn_narrow || !narrow_flag || ld >= (int64_t(1) << 29)) return hipErrorInvalidValue;
     if (C <= 0 || nchunks <= 0) return hipSuccess;
-    const int kWaves3 = waves3(subs, 8);
+    const int kWaves3 = waves3(subs, 4);
     const int64_t cells_per_block = (64 / subs) * kWaves3;
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
     hipLaunchKernelGGL(e->fn_narrow, grid, dim3(64 * kWaves3), 0, stream, ts, C, ld, Tn, table, sflags, step_min, chunks,
