@@ -1,4 +1,4 @@
-// kernels_ring3.hip -- third-generation float32 ring kernel (round 3): selection by BAND COMPACTION.
+// kernels_ring3.hip -- third-generation ring kernel (round 3): selection by BAND COMPACTION.
 //
 // The ring (R = 2w+1 samples of every owned track as order-preserving 32-bit keys in VGPRs), the step
 // table, the push logic, the running sums and the carried pivot with its exact count ("free probe")
@@ -30,7 +30,13 @@
 // target comes near an end of its window or its band population drifts out of range.
 //
 // Lane layout: the lanes of a cell are ADJACENT (lane = cell_in_wave * SUBS + sub), so that every
-// exchange inside a cell is one quad_perm / row_half_mirror DPP operation.
+// exchange inside a cell is one quad_perm / row_half_mirror DPP operation.  A workgroup covers one 128-byte
+// line of a sample row (two waves of 16 float32 cells at 4 lanes per cell).
+//
+// Three instantiations per layout: float32 input; float64 input whose samples are float32-representable
+// (narrowed on load, gives up at the first lossy sample); genuinely float64 samples (64-bit mode: the rings
+// and everything above hold the HIGH words of the 64-bit keys, the low words ride in a second set of tuples
+// and in the band lists -- 8 lanes per cell, up to 5 tracks per lane).
 //
 // Reference semantics restated: window_roll() (identify.py:184-209),
 // calculate_thresh()/calculate_seas() without the Feb-29 step (identify.py:233-235, :263),
