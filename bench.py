@@ -72,6 +72,9 @@ def parse_args(argv=None):
                     help="N>1: strong = one grid split over the ranks (default); weak = a full grid per rank")
     ap.add_argument("--cells", type=int, default=0, help="total cells (strong) / cells per GPU (weak, N=1); 0: the preset's")
     ap.add_argument("--slabs", type=int, default=0, help="launches per step (0: 1 at N=1, 4 at N>1)")
+    ap.add_argument("--finish-stream", type=int, default=-1,
+                    help="1: the finish kernel of a slab runs on a second stream behind its ring kernel and overlaps the "
+                         "next slab's ring kernel (default: on when a step has more than one slab)")
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--ring2", type=int, default=None, help="ring2 variant override (-2 auto, -1 round-1 kernel, 0..11)")
     ap.add_argument("--chunks", type=int, default=0)
@@ -339,6 +342,8 @@ def run(args):
     raw_se = [DeviceBuffer(8 * D * (b - a)) for a, b in slabs]
     out = [DeviceBuffer(8 * 2 * D * (b - a)) for a, b in slabs]          # dense (2D, n): thresh rows, then seas rows
     comm_stream = h.stream_create() if use_dist else 0
+    two_streams = (args.finish_stream == 1 or (args.finish_stream < 0 and len(slabs) > 1)) and len(slabs) > 1
+    fin_stream = h.stream_create() if two_streams else 0
     recv, cols_of_rank = [], []
     if use_dist:
         for i, (a, b) in enumerate(slabs):
@@ -355,14 +360,20 @@ def run(args):
             h.event_record(ev[i][0], 0)
             clim_raw(plan, ts.ptr + isz * a, isz, n, q, False, raw_th[i], raw_se[i], ld=C, ldo=n)
             h.event_record(ev[i][1], 0)
-            clim_finish(plan, raw_th[i], raw_se[i], n, not tstep, True, width, out[i].ptr, out[i].ptr + 8 * D * n, ldo=n)
-            h.event_record(ev[i][2], 0)
+            if two_streams:
+                # the memory-bound finish kernel of this slab overlaps the issue-bound ring kernel of the next one
+                h.stream_wait_event(fin_stream, ev[i][1])
+            clim_finish(plan, raw_th[i], raw_se[i], n, not tstep, True, width, out[i].ptr, out[i].ptr + 8 * D * n, ldo=n,
+                        stream=fin_stream)
+            h.event_record(ev[i][2], fin_stream)
             if use_dist:
                 # the slab's gather rides a second stream behind its finish kernel and overlaps the next slab
                 h.stream_wait_event(comm_stream, ev[i][2])
                 h.gather_blocks(tr._comm, out[i].ptr, 2 * D, n, recv[i].ptr if rank == 0 else 0,
                                 cols_of_rank[i] if rank == 0 else np.zeros(0, dtype=np.int64), 0, comm_stream)
         h.stream_sync(0)
+        if two_streams:
+            h.stream_sync(fin_stream)
         if use_dist:
             h.stream_sync(comm_stream)
         if timed:
