@@ -149,7 +149,8 @@ int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out16);
 /* float32 ring kernels for w = 5 (what replaces xmhw/xmhw.py:184-197 + identify.py:212-270 per cell).
  * variant: -2 = auto (the default): 21 -- the third-generation kernel (xmhw_amd/csrc/kernels_ring3.hip:
  * per-cell histogram in LDS, band compaction, sort across the lanes of a cell) on 4 lanes per cell -- where a
- * lane holds at least 4 tracks (13..48 tracks), otherwise the second-generation kernel
+ * lane holds at least 4 tracks (13..48 tracks), 20 -- the same on 8 lanes per cell -- for 49..88 tracks, otherwise
+ * the second-generation kernel
  * (kernels_ring2.hip, 9..96 tracks): 8, or 10 where the 4-lane layout pads fewer tracks (e.g. 12 tracks),
  * 12 = 16 lanes per cell (49..96 tracks).  -1 = off (round-1 kernel); 0 / 7 = 8 / 4 lanes per cell with
  * 32-bit count passes and a 5-key extraction list (8 / 10 are these with the lanes' lists merged into the

@@ -120,7 +120,8 @@ def test_ring2_layout_choice():
     assert years(16).ring2_in_use() == 21                     # 16 tracks: 4 x 4
     assert years(16, ring2=8).ring2_in_use() == 8             # (8 x 2 = 4 x 4 exactly: the second generation's tie goes to 8 lanes)
     assert years(43).ring2_in_use() == 21                     # 41..48 tracks (OISST 1982-2024): 4 x 11
-    assert years(49).ring2_in_use() == 12 and years(96).ring2_in_use() == 12   # 49..96 tracks: 16 lanes per cell
+    assert years(49).ring2_in_use() == 20 and years(88).ring2_in_use() == 20   # 49..88 tracks: ring3 on 8 lanes per cell
+    assert years(89).ring2_in_use() == 12 and years(96).ring2_in_use() == 12   # 89..96 tracks: 16 lanes per cell (ring2)
     assert years(97).ring2_in_use() == -1                     # beyond: round-1 kernel (32 lanes per cell)
     assert years(40, ring2=12).ring2_in_use() == -1           # (that layout's short-record entries are float64-only)
     assert years(8).ring2_in_use() == -1                      # 8 tracks or fewer: round-1 kernel

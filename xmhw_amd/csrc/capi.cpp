@@ -124,10 +124,9 @@ X64Choice x64_choice(const xmhw_plan* p) {
     }
     // ... 16 lanes per cell for longer and for very short records (the table of the 16-lane rings)
     const int32_t y16 = xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, 12);
-    // (its table: the 16-lane rings' one up to 3 tracks per lane, the plan's own ring2 table beyond -- there the
-    // float32 layout is the same 16 lanes)
-    if (y16 > 0 && xmhw::ring2_x64_supported(p->host.w, y16, 12) &&
-        (y16 <= 3 || ring2_resolved(p) == 12)) {
+    // (its table: the plan's own ring2 table where the float32 layout is the same 16 lanes, the 16-lane table kept for
+    // the 64-bit mode otherwise)
+    if (y16 > 0 && y16 <= 6 && xmhw::ring2_x64_supported(p->host.w, y16, 12)) {
         c.variant = 12;
         c.yps = y16;
     }
@@ -183,6 +182,13 @@ int32_t ring2_resolved(const xmhw_plan* p) {
     // (histogram, walk, sort) outweigh the cheaper selection.  The 6-hourly share of configs[4] (20 tracks): 116 against
     // 130 ms.
     if (xmhw::ring3_pick_yps(p->host.w, p->host.ntracks, 4) >= 4) return 21;
+    // ... and on 8 lanes per cell for longer records (49..88 tracks, 7..11 per lane) instead of the second-generation
+    // kernel's 16-lane layout: 259,200 cells daily, counters on: 50 tracks 24.9 against 36.6 ms, 65 tracks 31.6 / 45.1,
+    // 85 tracks 42.8 / 51.0; 96 tracks (12 per lane, 256 registers) 53.5 / 52.0 -- those stay where they were
+    {
+        const int32_t y8 = xmhw::ring3_pick_yps(p->host.w, p->host.ntracks, 8);
+        if (y8 >= 7 && y8 <= 11) return 20;
+    }
     return ring2_legacy(p);
 }
 
@@ -245,7 +251,7 @@ int upload(xmhw_plan* p, int64_t C) {
         HIP_TRY(put(&p->d_sflags, h.step_flags()));
         {
             const int32_t y16 = xmhw::ring2_pick_yps(h.w, h.ntracks, 12);
-            p->yps64 = (y16 >= 1 && y16 <= 3) ? y16 : 0;
+            p->yps64 = (y16 >= 1 && y16 <= 6) ? y16 : 0;      // (also for 49..96 tracks: their float32 layout may be another)
         }
         if (p->yps64) HIP_TRY(put(&p->d_table64, h.ring_table(16, p->yps64)));
     }
