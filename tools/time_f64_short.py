@@ -1,0 +1,22 @@
+import sys, os, numpy as np
+sys.path.insert(0, '.')
+import xmhw_amd.device as dev
+from xmhw_amd.calendar import add_doy
+h = dev.hip()
+C = 518400
+for y0, y1 in ((2002, 2021), (2006, 2021)):
+    doy = add_doy(np.arange(f"{y0}-01-01", f"{y1 + 1}-01-01", dtype="datetime64[D]"))
+    T = doy.shape[0]
+    ts = dev.DeviceBuffer(8 * T * C)
+    h.synth_sst(ts.ptr, 8, T, C, C, 0, 5, 0.0, 0)
+    plan = dev.Plan(doy, 5)
+    th, se = dev.DeviceBuffer(8 * plan.D * C), dev.DeviceBuffer(8 * plan.D * C)
+    e0, e1 = h.event_create(), h.event_create()
+    dev.clim_raw(plan, ts, 8, C, 0.9, False, th, se); h.stream_sync(0)
+    ms = []
+    for _ in range(3):
+        h.event_record(e0, 0); dev.clim_raw(plan, ts, 8, C, 0.9, False, th, se); h.event_record(e1, 0); h.stream_sync(0)
+        ms.append(h.event_elapsed_ms(e0, e1))
+    print(f"{y0}-{y1} ({plan.ntracks} tracks) f64 mode {plan.f64_mode()}: {min(ms):.2f} ms for {C} cells", flush=True)
+    for b in (ts, th, se): b.free()
+    plan.destroy()

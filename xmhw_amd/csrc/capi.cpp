@@ -111,6 +111,17 @@ X64Choice x64_choice(const xmhw_plan* p) {
     // (the third-generation kernel's 64-bit mode where both rings fit its registers: up to 5 tracks per lane = 9..40
     // tracks, layout 20; XMHW_RING3_F64=0 keeps the second-generation kernel)
     static const bool r3_on = [] { const char* v = std::getenv("XMHW_RING3_F64"); return !(v && v[0] == '0'); }();
+    // (13..20 tracks: the 4-lane layout of the float32 path, 16 cells per wave, on the plan's own table;
+    // XMHW_RING3_F64_LANES=8 keeps the 8-lane layout)
+    static const bool r3_4 = [] { const char* v = std::getenv("XMHW_RING3_F64_LANES"); return !(v && v[0] == '8'); }();
+    if (r3_on && r3_4 && ring2_resolved(p) == 21) {
+        const int32_t y4 = xmhw::ring3_pick_yps(p->host.w, p->host.ntracks, 4);
+        if (y4 > 0 && xmhw::ring3_x64_supported(p->host.w, y4, 4)) {
+            c.variant = 21;
+            c.yps = y4;
+            return c;
+        }
+    }
     if (r3_on && y8 > 0 && xmhw::ring3_pick_yps(p->host.w, p->host.ntracks, 8) == y8 &&
         xmhw::ring3_x64_supported(p->host.w, y8, 8)) {
         c.variant = 20;
@@ -357,6 +368,7 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
                 if (xc.variant >= 0)
                     e = xmhw::launch_ring2_f64(reinterpret_cast<const double*>(ts), C, ld, h.T,
                                                xc.variant == 12 ? ((plan->subs2 == 16 && plan->yps2 == xc.yps) ? plan->d_table2 : plan->d_table64)
+                                               : xc.variant == 21 ? plan->d_table2
                                                : (plan->subs2 == 8 && plan->yps2 == xc.yps) ? plan->d_table2 : plan->d_tablex,
                                                plan->d_sflags,
                                                h.step_min, plan->d_chunks, plan->nchunks, h.w, xc.yps, h.ntracks, xc.variant,

@@ -1519,16 +1519,19 @@ struct Ring3Entry { int yps, subs; Ring3Kernel fn, fn_stats; Ring3KernelN fn_nar
 #define XMHW_R3X(Y, S) {Y, S, clim_ring3_f32<Y, S, false>, clim_ring3_f32<Y, S, true>, nullptr, clim_ring3_f32<Y, S, false, double, true>}
 // (with the narrowing instantiation for float64 input: the layouts the automatic choice uses)
 #define XMHW_R3N(Y, S) {Y, S, clim_ring3_f32<Y, S, false>, clim_ring3_f32<Y, S, true>, clim_ring3_f32<Y, S, false, double>, nullptr}
+// (narrowing and the 64-bit mode: short records on 4 lanes per cell, both rings of 4 / 5 tracks per lane fit)
+#define XMHW_R3NX(Y, S) {Y, S, clim_ring3_f32<Y, S, false>, clim_ring3_f32<Y, S, true>, clim_ring3_f32<Y, S, false, double>, clim_ring3_f32<Y, S, false, double, true>}
 const Ring3Entry kRing3[] = {
     XMHW_R3X(2, 8), XMHW_R3X(3, 8), XMHW_R3X(4, 8), XMHW_R3X(5, 8), XMHW_R3(6, 8),
     // (long records -- reanalyses, model runs: 49..96 tracks on 8 lanes per cell)
     XMHW_R3N(7, 8), XMHW_R3N(8, 8), XMHW_R3N(9, 8), XMHW_R3N(10, 8), XMHW_R3N(11, 8), XMHW_R3(12, 8),
-    XMHW_R3(3, 4), XMHW_R3N(4, 4), XMHW_R3N(5, 4), XMHW_R3N(6, 4), XMHW_R3N(7, 4), XMHW_R3N(8, 4), XMHW_R3N(9, 4),
+    XMHW_R3(3, 4), XMHW_R3NX(4, 4), XMHW_R3NX(5, 4), XMHW_R3N(6, 4), XMHW_R3N(7, 4), XMHW_R3N(8, 4), XMHW_R3N(9, 4),
     XMHW_R3N(10, 4), XMHW_R3N(11, 4), XMHW_R3N(12, 4),
 };
 #undef XMHW_R3
 #undef XMHW_R3N
 #undef XMHW_R3X
+#undef XMHW_R3NX
 const Ring3Entry* find_ring3(int32_t yps, int32_t subs) {
     for (const auto& e : kRing3)
         if (e.yps == yps && e.subs == subs) return &e;
