@@ -164,8 +164,8 @@ int xmhw_plan_ring2_in_use(const xmhw_plan *plan, int32_t *variant);
 /* genuinely float64 samples (those that do not narrow to float32): the layout of the 64-bit mode
  * (64-bit keys as a high word -- what the selection runs on -- and a low word) this plan will run on:
  * 21 / 20 = the third-generation kernel on 4 lanes per cell (13..20 tracks) / 8 lanes per cell (9..12 and
- * 21..40 tracks; XMHW_RING3_F64=0 turns both off, XMHW_RING3_F64_LANES=8 the 4-lane layout),
- * 8 = the second-generation kernel on 8 lanes per cell (41..48 tracks), 12 = on 16 lanes per cell
+ * 21..48 tracks; XMHW_RING3_F64=0 turns both off, XMHW_RING3_F64_LANES=8 the 4-lane layout),
+ * 8 = the second-generation kernel on 8 lanes per cell (only with XMHW_RING3_F64=0), 12 = on 16 lanes per cell
  * (other records up to 96 tracks), or -1 (generic kernel).  w = 5.                              */
 int xmhw_plan_f64_mode(const xmhw_plan *plan, int32_t *variant);
 

@@ -127,11 +127,11 @@ def test_ring2_layout_choice():
     assert years(8).ring2_in_use() == -1                      # 8 tracks or fewer: round-1 kernel
     assert years(40, w=3).ring2_in_use() == -1                # other windows: round-1 kernel
     # genuinely float64 samples: the 64-bit mode's layout -- the third-generation kernel on 4 lanes per cell for 13..20
-    # tracks (21), on 8 lanes where a lane holds up to 5 tracks (9..12 and 21..40 tracks: 20), the second-generation
-    # one on 8 lanes with its low words in LDS for 41..48 tracks (8), 16 lanes for shorter and longer records (12)
+    # tracks (21), on 8 lanes otherwise up to 48 tracks (20), the second-generation one on 16 lanes for shorter and longer
+    # records (12)
     assert years(30).f64_mode() == 20 and years(12).f64_mode() == 20
     assert years(20).f64_mode() == 21 and years(13).f64_mode() == 21      # 4 / 5 tracks per lane: the 4-lane layout
-    assert years(40).f64_mode() == 20 and years(43).f64_mode() == 8 and years(5).f64_mode() == 12
+    assert years(40).f64_mode() == 20 and years(43).f64_mode() == 20 and years(5).f64_mode() == 12
     assert years(49).f64_mode() == 12 and years(96).f64_mode() == 12             # 16 lanes, low words in LDS
     assert years(97).f64_mode() == -1 and years(40, w=3).f64_mode() == -1        # generic kernel
     with pytest.raises(Exception):

@@ -3,8 +3,9 @@ sys.path.insert(0, '.')
 import xmhw_amd.device as dev
 from xmhw_amd.calendar import add_doy
 h = dev.hip()
-C = 518400
-for y0, y1 in ((2002, 2021), (2006, 2021)):
+C = int(os.environ.get('CELLS', 518400))
+years = [tuple(int(v) for v in a.split('-')) for a in sys.argv[1:]] or [(2002, 2021), (2006, 2021)]
+for y0, y1 in years:
     doy = add_doy(np.arange(f"{y0}-01-01", f"{y1 + 1}-01-01", dtype="datetime64[D]"))
     T = doy.shape[0]
     ts = dev.DeviceBuffer(8 * T * C)

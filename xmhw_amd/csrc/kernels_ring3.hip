@@ -1522,7 +1522,7 @@ struct Ring3Entry { int yps, subs; Ring3Kernel fn, fn_stats; Ring3KernelN fn_nar
 // (narrowing and the 64-bit mode: short records on 4 lanes per cell, both rings of 4 / 5 tracks per lane fit)
 #define XMHW_R3NX(Y, S) {Y, S, clim_ring3_f32<Y, S, false>, clim_ring3_f32<Y, S, true>, clim_ring3_f32<Y, S, false, double>, clim_ring3_f32<Y, S, false, double, true>}
 const Ring3Entry kRing3[] = {
-    XMHW_R3X(2, 8), XMHW_R3X(3, 8), XMHW_R3X(4, 8), XMHW_R3X(5, 8), XMHW_R3(6, 8),
+    XMHW_R3X(2, 8), XMHW_R3X(3, 8), XMHW_R3X(4, 8), XMHW_R3X(5, 8), XMHW_R3X(6, 8),
     // (long records -- reanalyses, model runs: 49..96 tracks on 8 lanes per cell)
     XMHW_R3N(7, 8), XMHW_R3N(8, 8), XMHW_R3N(9, 8), XMHW_R3N(10, 8), XMHW_R3N(11, 8), XMHW_R3(12, 8),
     XMHW_R3(3, 4), XMHW_R3NX(4, 4), XMHW_R3NX(5, 4), XMHW_R3N(6, 4), XMHW_R3N(7, 4), XMHW_R3N(8, 4), XMHW_R3N(9, 4),
