@@ -36,7 +36,7 @@
 // Three instantiations per layout: float32 input; float64 input whose samples are float32-representable
 // (narrowed on load, gives up at the first lossy sample); genuinely float64 samples (64-bit mode: the rings
 // and everything above hold the HIGH words of the 64-bit keys, the low words ride in a second set of tuples
-// and in the band lists -- 8 lanes per cell, up to 5 tracks per lane).
+// and in the band lists -- 8 lanes per cell up to 6 tracks per lane, 4 lanes per cell at 4 and 5).
 //
 // Reference semantics restated: window_roll() (identify.py:184-209),
 // calculate_thresh()/calculate_seas() without the Feb-29 step (identify.py:233-235, :263),
