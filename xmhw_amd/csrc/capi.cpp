@@ -166,8 +166,18 @@ int32_t auto_chunks(const xmhw_plan* p, int64_t C) {
     if (p->host.nchunks_req > 0) return std::min(p->host.nchunks_req, p->host.D);
     // enough waves to fill 256 CUs x 16 waves a few times over; each chunk
     // re-reads 2w rows per track and cold-starts its bracket, so keep them long
-    const int64_t waves = (C + 7) / 8;
+    int64_t waves = (C + 7) / 8;
     int64_t want = (4 * 4096 + waves - 1) / std::max<int64_t>(waves, 1);
+    {
+        // the third-generation kernel runs two waves per SIMD (2,048 at a time) of 16 or 8 cells: twice that many
+        // waves in all is enough, and every further chunk costs its warm-up rows (1 degree grid, 64,800 cells: 3.67 ms
+        // with 1 or 2 chunks, 3.87 with 3, 4.16 with 6)
+        const int32_t v = ring2_resolved(p);
+        if (v >= 20) {
+            waves = (C + (v == 21 ? 15 : 7)) / (v == 21 ? 16 : 8);
+            want = (4096 + waves - 1) / std::max<int64_t>(waves, 1);
+        }
+    }
     want = std::max<int64_t>(1, std::min<int64_t>(want, p->host.D / 24));
     return static_cast<int32_t>(std::max<int64_t>(want, 1));
 }
