@@ -184,7 +184,7 @@ def live_traffic(argv):
 def _ring_name(variant):
     """the kernel a float32 plan runs on, by its layout number (include/xmhw_amd.h: xmhw_plan_set_ring2)"""
     if variant >= 20:
-        return f"clim_ring3_f32 ({4 if variant == 21 else 8} lanes per cell, layout {variant})"
+        return f"clim_ring3_f32 ({ {20: 8, 21: 4, 22: 2}.get(variant, 8) } lanes per cell, layout {variant})"
     return f"clim_ring2_f32 (layout {variant})"
 
 

@@ -147,14 +147,13 @@ int xmhw_plan_table(const xmhw_plan *plan, int32_t years_per_lane, uint32_t *tab
 int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out16);
 
 /* float32 ring kernels for w = 5 (what replaces xmhw/xmhw.py:184-197 + identify.py:212-270 per cell).
- * variant: -2 = auto (the default): 21 -- the third-generation kernel (xmhw_amd/csrc/kernels_ring3.hip:
- * per-cell histogram in LDS, band compaction, sort across the lanes of a cell) on 4 lanes per cell -- where a
- * lane holds at least 4 tracks (13..48 tracks), 20 -- the same on 8 lanes per cell -- for 49..88 tracks, otherwise
- * the second-generation kernel
- * (kernels_ring2.hip, 9..96 tracks): 8, or 10 where the 4-lane layout pads fewer tracks (e.g. 12 tracks),
- * 12 = 16 lanes per cell (49..96 tracks).  -1 = off (round-1 kernel); 0 / 7 = 8 / 4 lanes per cell with
- * 32-bit count passes and a 5-key extraction list (8 / 10 are these with the lanes' lists merged into the
- * cell's 8 / 7 nearest keys); 20 = the third-generation kernel on 8 lanes per cell; 1..6, 9, 11 = measured
+ * variant: -2 = auto (the default): the third-generation kernel (xmhw_amd/csrc/kernels_ring3.hip: per-cell
+ * histogram in LDS, band compaction, sort across the lanes of a cell) on 2 lanes per cell for 9..24 tracks
+ * (22), on 4 lanes for 25..48 tracks (21), on 8 lanes for 49..88 tracks (20); the second-generation kernel
+ * (kernels_ring2.hip) on 16 lanes per cell for 89..96 tracks (12).  -1 = off (round-1 kernel); 0 / 7 =
+ * second-generation kernel on 8 / 4 lanes per cell with 32-bit count passes and a 5-key extraction list, 8 / 10
+ * = these with the lanes' lists merged into the cell's 8 / 7 nearest keys; 20 / 21 / 22 may be forced wherever
+ * they are instantiated (8 lanes: 9..88 tracks, 4 lanes: 9..48, 2 lanes: 9..24); 1..6, 9, 11 = measured
  * alternatives of round 2 (8/16-bit code rings, other list widths), compiled with -DXMHW_RING2_EXPERIMENTS
  * only.  The environment variable XMHW_RING2 sets the default of new plans.  All variants return
  * bit-identical thresh.                                                                            */

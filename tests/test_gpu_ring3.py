@@ -1,4 +1,4 @@
-"""Third-generation ring kernel (kernels_ring3.hip, ring2 variants 20 / 21): per-cell histogram in LDS, band
+"""Third-generation ring kernel (kernels_ring3.hip, ring2 variants 20 / 21 / 22: 8 / 4 / 2 lanes per cell): per-cell histogram in LDS, band
 compaction, bitonic sort across the lanes of a cell.  Raw thresh must be bit-identical to the generic kernel (an
 independent algorithm) and to the oracle; seas a float64 sum of the same float32 samples in another order.
 The debug counters show that the band path -- not the round-2 slow path kept inside the kernel -- settles the
@@ -69,7 +69,7 @@ def _band_share(st):
 def _check(dev, x, doy, q=0.9, negate=False, nchunks=1, min_band=None):
     tg, sg, _, _ = _raw(dev, x, doy, q, negate, kernel="generic")
     out = {}
-    for v in (20, 21):
+    for v in (20, 21, 22):
         t1, s1, st, use = _raw(dev, x, doy, q, negate, nchunks, ring2=v)
         if use != v:            # the layout is not instantiated for this track count
             continue

@@ -95,10 +95,10 @@ def test_too_many_tracks_falls_back_to_generic():
 
 
 def test_ring2_layout_choice():
-    """which float32 ring kernel a plan runs on (capi.cpp: ring2_resolved): the third-generation kernel on 4 lanes
-    per cell (21) where a lane holds at least 4 tracks (13..48 tracks: measured faster than every second-generation
-    layout there, tools/bench_ring2.py --years); otherwise the second-generation one -- 8 lanes per cell unless the
-    4-lane layout pads fewer tracks; outside both the round-1 kernel runs (-1)"""
+    """which float32 ring kernel a plan runs on (capi.cpp: ring2_resolved): the third-generation kernel on 2 lanes per
+    cell (22) for 9..24 tracks, on 4 lanes (21) for 25..48, on 8 lanes (20) for 49..88 -- each measured faster than
+    every second-generation layout there (tools/bench_ring2.py --years) -- and the second-generation kernel on 16 lanes
+    (12) for 89..96 tracks; outside the round-1 kernel runs (-1)"""
     from xmhw_amd.device import Plan
 
     def years(n, w=5, ring2=None):
@@ -108,16 +108,17 @@ def test_ring2_layout_choice():
     assert years(40).ring2_in_use() == 21                     # 4 x 10 = 40 tracks: ring3
     assert years(30).ring2_in_use() == 21                     # 4 x 8 (2 padded)
     assert years(25).ring2_in_use() == 21 and years(48).ring2_in_use() == 21      # 7 .. 12 tracks per lane
-    assert years(24).ring2_in_use() == 21 and years(13).ring2_in_use() == 21      # 4 .. 6 tracks per lane
+    assert years(24).ring2_in_use() == 22 and years(13).ring2_in_use() == 22      # 2 lanes per cell up to 24 tracks
+    assert years(24, ring2=21).ring2_in_use() == 21                                 # (forced)
     assert years(40, ring2=8).ring2_in_use() == 8 and years(40, ring2=20).ring2_in_use() == 20      # forced
-    assert years(20).ring2_in_use() == 21                     # 4 x 5 = 20 tracks
-    assert Plan(np.tile(np.arange(1, 1461), 20), 5).ring2_in_use() == 21     # config 5's tstep axis
-    assert years(12).ring2_in_use() == 10                     # 3 tracks per lane: the second-generation kernel
+    assert years(20).ring2_in_use() == 22                     # 2 x 10 = 20 tracks
+    assert Plan(np.tile(np.arange(1, 1461), 20), 5).ring2_in_use() == 22     # config 5's tstep axis
+    assert years(12).ring2_in_use() == 22 and years(9).ring2_in_use() == 22
     assert years(20, ring2=0).ring2_in_use() == 0             # forced
     assert years(40, ring2=7).ring2_in_use() == 7
     assert years(40, ring2=-1).ring2_in_use() == -1           # round-1 kernel
-    assert years(10).ring2_in_use() == 10                     # 10 tracks: 4 x 3 = 12 slots against 8 x 2 = 16
-    assert years(16).ring2_in_use() == 21                     # 16 tracks: 4 x 4
+    assert years(10).ring2_in_use() == 22 and years(10, ring2=10).ring2_in_use() == 10
+    assert years(16).ring2_in_use() == 22                     # 16 tracks: 2 x 8
     assert years(16, ring2=8).ring2_in_use() == 8             # (8 x 2 = 4 x 4 exactly: the second generation's tie goes to 8 lanes)
     assert years(43).ring2_in_use() == 21                     # 41..48 tracks (OISST 1982-2024): 4 x 11
     assert years(49).ring2_in_use() == 20 and years(88).ring2_in_use() == 20   # 49..88 tracks: ring3 on 8 lanes per cell

@@ -73,8 +73,8 @@ struct xmhw_plan {
     int32_t* d_row_ptr = nullptr;
     int32_t* d_centres = nullptr;
     unsigned long long* d_stats = nullptr;  // debug: ring kernel pass counters (xmhw_plan_debug_stats)
-    uint32_t* d_tablex = nullptr;           // 8-lane table of the 64-bit mode when the float32 layout is another one
-    int32_t ypsx = 0;
+    uint32_t* d_tablex = nullptr;           // the 64-bit mode's own table (8 or 4 lanes) when the float32 layout is another one
+    int32_t ypsx = 0, subsx = 0;
     uint32_t* d_narrow_flag = nullptr;      // float64 input: set when a sample is not float32-representable
     bool narrowing = true;                  // xmhw_plan_set_narrowing
 
@@ -114,7 +114,7 @@ X64Choice x64_choice(const xmhw_plan* p) {
     // (13..20 tracks: the 4-lane layout of the float32 path, 16 cells per wave, on the plan's own table;
     // XMHW_RING3_F64_LANES=8 keeps the 8-lane layout)
     static const bool r3_4 = [] { const char* v = std::getenv("XMHW_RING3_F64_LANES"); return !(v && v[0] == '8'); }();
-    if (r3_on && r3_4 && ring2_resolved(p) == 21) {
+    if (r3_on && r3_4) {
         const int32_t y4 = xmhw::ring3_pick_yps(p->host.w, p->host.ntracks, 4);
         if (y4 > 0 && xmhw::ring3_x64_supported(p->host.w, y4, 4)) {
             c.variant = 21;
@@ -174,7 +174,8 @@ int32_t auto_chunks(const xmhw_plan* p, int64_t C) {
         // with 1 or 2 chunks, 3.87 with 3, 4.16 with 6)
         const int32_t v = ring2_resolved(p);
         if (v >= 20) {
-            waves = (C + (v == 21 ? 15 : 7)) / (v == 21 ? 16 : 8);
+            const int64_t cpw = v == 22 ? 32 : v == 21 ? 16 : 8;
+            waves = (C + cpw - 1) / cpw;
             want = (4096 + waves - 1) / std::max<int64_t>(waves, 1);
         }
     }
@@ -202,6 +203,10 @@ int32_t ring2_resolved(const xmhw_plan* p) {
     // 16 tracks 34.5 against 35.3; 12 tracks 31.0 against 29.7 -- with so few keys per lane its per-row overheads
     // (histogram, walk, sort) outweigh the cheaper selection.  The 6-hourly share of configs[4] (20 tracks): 116 against
     // 130 ms.
+    // ... on 2 lanes per cell (32 cells per wave) for records of 9..24 tracks: 518,400 cells daily, counters on: 13
+    // tracks 12.4 against 17.7 ms on 4 lanes, 18 tracks 14.6 / 19.5, 22 tracks 17.5 / 21.3, 24 tracks 20.4 / 21.1; the
+    // 6-hourly share of configs[4] (20 tracks, 405,000 cells): 48.1 / 58.9
+    if (xmhw::ring3_pick_yps(p->host.w, p->host.ntracks, 2) >= 5) return 22;
     if (xmhw::ring3_pick_yps(p->host.w, p->host.ntracks, 4) >= 4) return 21;
     // ... and on 8 lanes per cell for longer records (49..88 tracks, 7..11 per lane) instead of the second-generation
     // kernel's 16-lane layout: 259,200 cells daily, counters on: 50 tracks 24.9 against 36.6 ms, 65 tracks 31.6 / 45.1,
@@ -236,7 +241,7 @@ NarrowChoice narrow_choice(const xmhw_plan* p) {
     if (!yps || !xmhw::ring2_narrowing_supported(p->host.w, yps, v)) return c;
     const uint32_t* t = nullptr;
     if (p->subs2 == subs && p->yps2 == yps) t = p->d_table2;
-    else if (subs == 8 && p->ypsx == yps) t = p->d_tablex;
+    else if (p->subsx == subs && p->ypsx == yps) t = p->d_tablex;
     if (!t) return c;
     c.variant = v;
     c.yps = yps;
@@ -248,11 +253,13 @@ int upload(xmhw_plan* p, int64_t C) {
     std::lock_guard<std::mutex> lock(p->mu);
     const int32_t nchunks = auto_chunks(p, C);
     const X64Choice xc0 = x64_choice(p);
-    const bool need_x = (xc0.variant == 8 || xc0.variant == 20) && !(p->subs2 == 8 && p->yps2 == xc0.yps);
+    const int32_t xsubs0 = xc0.variant == 21 ? 4 : 8;
+    const bool need_x = (xc0.variant == 8 || xc0.variant == 20 || xc0.variant == 21) &&
+                        !(p->subs2 == xsubs0 && p->yps2 == xc0.yps);
     if (p->uploaded && nchunks == p->nchunks &&
         p->subs2 == xmhw::ring2_subs(ring2_resolved(p)) &&
         p->yps2 == (ring2_resolved(p) >= 0 ? xmhw::ring2_pick_yps(p->host.w, p->host.ntracks, ring2_resolved(p)) : 0) &&
-        (!need_x || p->ypsx == xc0.yps))
+        (!need_x || (p->ypsx == xc0.yps && p->subsx == xsubs0)))
         return XMHW_OK;
     const xmhw::Plan& h = p->host;
     if (!p->uploaded) {
@@ -293,14 +300,18 @@ int upload(xmhw_plan* p, int64_t C) {
         }
     }
     {
-        // the 64-bit mode's own 8-lane table, when the float32 layout of this plan is a different one
+        // the 64-bit mode's own table (8 lanes, or 4 for short records), when the float32 layout of this plan is a
+        // different one
         const X64Choice xc = x64_choice(p);
-        if ((xc.variant == 8 || xc.variant == 20) && !(p->subs2 == 8 && p->yps2 == xc.yps) && p->ypsx != xc.yps) {
+        const int32_t xsubs = xc.variant == 21 ? 4 : 8;
+        if ((xc.variant == 8 || xc.variant == 20 || xc.variant == 21) && !(p->subs2 == xsubs && p->yps2 == xc.yps) &&
+            !(p->ypsx == xc.yps && p->subsx == xsubs)) {
             if (p->d_tablex) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p->d_tablex)); p->d_tablex = nullptr; }
-            const std::vector<uint32_t> tx = h.ring_table(8, xc.yps);
+            const std::vector<uint32_t> tx = h.ring_table(xsubs, xc.yps);
             HIP_TRY(hipMalloc(&p->d_tablex, sizeof(uint32_t) * tx.size()));
             HIP_TRY(hipMemcpy(p->d_tablex, tx.data(), sizeof(uint32_t) * tx.size(), hipMemcpyHostToDevice));
             p->ypsx = xc.yps;
+            p->subsx = xsubs;
         }
     }
     if (p->yps || p->yps64 || p->yps2) {
@@ -378,8 +389,8 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
                 if (xc.variant >= 0)
                     e = xmhw::launch_ring2_f64(reinterpret_cast<const double*>(ts), C, ld, h.T,
                                                xc.variant == 12 ? ((plan->subs2 == 16 && plan->yps2 == xc.yps) ? plan->d_table2 : plan->d_table64)
-                                               : xc.variant == 21 ? plan->d_table2
-                                               : (plan->subs2 == 8 && plan->yps2 == xc.yps) ? plan->d_table2 : plan->d_tablex,
+                                               : (plan->subs2 == (xc.variant == 21 ? 4 : 8) && plan->yps2 == xc.yps) ? plan->d_table2
+                                               : plan->d_tablex,
                                                plan->d_sflags,
                                                h.step_min, plan->d_chunks, plan->nchunks, h.w, xc.yps, h.ntracks, xc.variant,
                                                q, negate, thresh, seas, ldo, st, run_flag);
@@ -1016,8 +1027,8 @@ int xmhw_plan_create(const int32_t* doy_host, int64_t T, int32_t window_half_wid
 }
 int xmhw_plan_set_ring2(xmhw_plan* plan, int32_t variant) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
-    if (variant < -2 || (variant > 12 && variant != 20 && variant != 21))
-        return fail(XMHW_ERR_INVALID, "ring2 variant must be -2 (auto), -1 (off), 0..12, 20 or 21");
+    if (variant < -2 || (variant > 12 && variant != 20 && variant != 21 && variant != 22))
+        return fail(XMHW_ERR_INVALID, "ring2 variant must be -2 (auto), -1 (off), 0..12 or 20..22");
     plan->ring2_variant = variant;
     return XMHW_OK;
 }

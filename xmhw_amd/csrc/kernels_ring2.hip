@@ -1267,7 +1267,7 @@ const Ring2Entry* find_ring2(int32_t w, int32_t yps, int32_t subs, int32_t varia
 
 // variants 20 / 21: the third-generation kernel (kernels_ring3.hip) on 8 / 4 lanes per cell
 int32_t ring2_subs(int32_t variant) {
-    if (variant >= 20) return variant == 21 ? 4 : 8;
+    if (variant >= 20) return variant == 22 ? 2 : variant == 21 ? 4 : 8;
     return variant == 12 ? 16 : (variant == 7 || variant >= 9) ? 4 : 8;
 }
 

@@ -64,7 +64,7 @@ constexpr int kShr1 = 0x111, kShr2 = 0x112, kShr4 = 0x114;
 template <int SUBS>
 __device__ __forceinline__ uint32_t csum(uint32_t v) {
     v += dpp3<kX1>(v);
-    v += dpp3<kX2>(v);
+    if constexpr (SUBS >= 4) v += dpp3<kX2>(v);
     if constexpr (SUBS == 8) v += dpp3<kX7>(v);
     return v;
 }
@@ -78,7 +78,7 @@ __device__ __forceinline__ double dpp3_f64(double v) {
 template <int SUBS>
 __device__ __forceinline__ double csum(double v) {
     v += dpp3_f64<kX1>(v);
-    v += dpp3_f64<kX2>(v);
+    if constexpr (SUBS >= 4) v += dpp3_f64<kX2>(v);
     if constexpr (SUBS == 8) v += dpp3_f64<kX7>(v);
     return v;
 }
@@ -87,14 +87,14 @@ __device__ __forceinline__ uint32_t maxu3(uint32_t a, uint32_t b) { return a > b
 template <int SUBS>
 __device__ __forceinline__ uint32_t cmax(uint32_t v) {
     v = maxu3(v, dpp3<kX1>(v));
-    v = maxu3(v, dpp3<kX2>(v));
+    if constexpr (SUBS >= 4) v = maxu3(v, dpp3<kX2>(v));
     if constexpr (SUBS == 8) v = maxu3(v, dpp3<kX7>(v));
     return v;
 }
 template <int SUBS>
 __device__ __forceinline__ uint32_t cmin(uint32_t v) {
     v = minu3(v, dpp3<kX1>(v));
-    v = minu3(v, dpp3<kX2>(v));
+    if constexpr (SUBS >= 4) v = minu3(v, dpp3<kX2>(v));
     if constexpr (SUBS == 8) v = minu3(v, dpp3<kX7>(v));
     return v;
 }
@@ -371,7 +371,7 @@ struct Top3 {
     template <int SUBS>
     __device__ __forceinline__ void merge_cell() {
         merge<kX1, true>();
-        merge<kX2>();
+        if constexpr (SUBS >= 4) merge<kX2>();
         if constexpr (SUBS == 8) merge<kX7>();
     }
     __device__ __forceinline__ void at2(uint32_t j, uint32_t& a, uint32_t& b) const {
@@ -439,9 +439,11 @@ __device__ __forceinline__ void sort_cell(uint32_t (&c)[CAP], uint32_t bnd1, uin
     sort_lane<CAP>(c);
     cross_step<CAP, kX1, true>(c, bnd1);                   // groups of 2 lanes
     clean_lane<CAP>(c);
-    cross_step<CAP, kX3, true>(c, bnd2);                   // groups of 4 lanes
-    cross_step<CAP, kX1, false>(c, bnd1);
-    clean_lane<CAP>(c);
+    if constexpr (SUBS >= 4) {
+        cross_step<CAP, kX3, true>(c, bnd2);               // groups of 4 lanes
+        cross_step<CAP, kX1, false>(c, bnd1);
+        clean_lane<CAP>(c);
+    }
     if constexpr (SUBS == 8) {
         cross_step<CAP, kX7, true>(c, bnd4);               // groups of 8 lanes
         cross_step<CAP, kX2, false>(c, bnd2);
@@ -470,12 +472,19 @@ constexpr int kBudget3 = 6;
 // buckets costs the fourth workgroup (70.7 ms).
 template <int SUBS> struct Cfg3;
 template <> struct Cfg3<4> {   // 16 cells per wave
-    static constexpr int NB = 216, CAP = 8, LW = 24, JM = 7;
+    static constexpr int NB = 216, CAP = 8, LW = 24, JM = 7, PS = 16;
+};
+// 2 lanes: 32 cells per wave, a workgroup is ONE wave (32 float32 cells = one 128-byte line): 32 * (NB + 1) + 64 * LW
+// words = 19.6 KB, eight of them per CU.  Records of up to 24 tracks (264 pooled keys: 120 buckets cover them all).
+template <> struct Cfg3<2> {
+    // (bands three quarters as populous as on 4 lanes -- PS = 12 -- because a lane holds half of a cell's band and sorts
+    // at most 8 keys: 6-hourly share of 405,000 cells 56.9 ms at PS = 16, 48.1 at 12, 49.8 at 11, 56.7 at 10)
+    static constexpr int NB = 120, CAP = 8, LW = 16, JM = 7, PS = 12;
 };
 template <> struct Cfg3<8> {   // 8 cells per wave
     // (208 buckets and lists of 20 entries instead of 128 / 16: float64 configs[2] 103.8 -> 97.7 ms, fewer window
     // rebuilds and over-populated bands; a workgroup of two float64 waves takes 34 KB of LDS)
-    static constexpr int NB = 208, CAP = 4, LW = 20, JM = 8;
+    static constexpr int NB = 208, CAP = 4, LW = 20, JM = 8, PS = 16;
 };
 // buckets are sized to hold about this many pooled keys near the target
 constexpr float kBucketRanks = 3.5f;
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
     bool lossy = false;
     constexpr int W = 5;
     constexpr int R = 2 * W + 1;
-    static_assert(SUBS == 8 || SUBS == 4, "8 or 4 lanes per cell");
+    static_assert(SUBS == 8 || SUBS == 4 || SUBS == 2, "8, 4 or 2 lanes per cell");
     // (the narrowing instantiation keeps the float32 shape: its waves never wait for each other, and single-wave
     // workgroups measured 7 % slower)
     constexpr int kWaves3 = waves3(SUBS, X64 ? 8 : 4);
@@ -534,8 +543,11 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
     // band population x 16 (running mean): a rebuild is asked for outside [LO_TRIG, HI_TRIG]; whenever the wave
     // rebuilds, every cell outside [LO_ADJ, HI_ADJ] changes its bucket width too (so that it does not ask for
     // a rebuild of its own a few rows later)
-    constexpr int32_t M16_TARGET = 16 * 5, M16_HI_TRIG = 16 * 11, M16_LO_TRIG = 16 * 5 / 2, M16_HI_ADJ = 16 * 15 / 2,
-                      M16_LO_ADJ = 16 * 7 / 2;
+    // (PS: the thresholds in units of 1/16 key, 16 = as measured for 4 and 8 lanes per cell; the 2-lane layout, whose
+    // lane holds half a cell's band, keeps its bands smaller)
+    constexpr int32_t PS = Cfg3<SUBS>::PS;
+    constexpr int32_t M16_TARGET = PS * 5, M16_HI_TRIG = PS * 11, M16_LO_TRIG = PS * 5 / 2, M16_HI_ADJ = PS * 15 / 2,
+                      M16_LO_ADJ = PS * 7 / 2;
 
     __shared__ __attribute__((aligned(16))) uint32_t lds[kWaves3 * CPWAVE * HS + 64 * kWaves3 * LWL];
 
@@ -909,11 +921,15 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
                 const uint32_t T = pf[Q - 1];
                 uint32_t incl = T;
                 incl += dpp3<kShr1>(incl) & mk1;
-                incl += dpp3<kShr2>(incl) & mk2;
+                if constexpr (SUBS >= 4) incl += dpp3<kShr2>(incl) & mk2;
                 if constexpr (SUBS == 8) incl += dpp3<kShr4>(incl) & mk4;
                 const uint32_t excl = incl - T;
                 const uint32_t tot = cmax<SUBS>(incl);                    // keys in the 16 buckets
-                const uint32_t p12 = cmax<SUBS>(incl & mk12);             // keys in buckets 0..11 of the block
+                // keys in buckets 0..11 of the block: the inclusive prefix at bucket 11 (the last bucket of a lane with
+                // 4 or 2 buckets per lane, the fourth of the second lane's eight at 2 lanes per cell)
+                uint32_t p12;
+                if constexpr (Q <= 4) p12 = cmax<SUBS>(incl & mk12);
+                else p12 = cmax<SUBS>(sub == 11 / Q ? excl + pf[11 % Q] : 0u);
                 const uint32_t CS = up ? Fc : Fc - p12;                   // keys below the block
                 bok = bok && CS <= lo && lo + (need2 ? 1u : 0u) < CS + tot;
                 const uint32_t t0 = lo - CS, t1 = t0 + (need2 ? 1u : 0u);
@@ -1384,7 +1400,7 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
                     // bucket width: from the key spacing on a first build, one step at a time afterwards
                     uint32_t sh;
                     if (hbuilt == 0) {
-                        const float bw = fminf(fmaxf(kpr * kBucketRanks, 1.0f), 8.0e6f);
+                        const float bw = fminf(fmaxf(kpr * kBucketRanks * (static_cast<float>(PS) * 0.0625f), 1.0f), 8.0e6f);
                         sh = 31u - static_cast<uint32_t>(__builtin_clz(static_cast<uint32_t>(bw)));
                         m16 = M16_TARGET;
                     } else {
@@ -1525,6 +1541,9 @@ const Ring3Entry kRing3[] = {
     XMHW_R3X(2, 8), XMHW_R3X(3, 8), XMHW_R3X(4, 8), XMHW_R3X(5, 8), XMHW_R3X(6, 8),
     // (long records -- reanalyses, model runs: 49..96 tracks on 8 lanes per cell)
     XMHW_R3N(7, 8), XMHW_R3N(8, 8), XMHW_R3N(9, 8), XMHW_R3N(10, 8), XMHW_R3N(11, 8), XMHW_R3(12, 8),
+    // (2 lanes per cell, 32 cells per wave: records of 9..24 tracks; narrowing up to 10 tracks per lane)
+    XMHW_R3N(5, 2), XMHW_R3N(6, 2), XMHW_R3N(7, 2), XMHW_R3N(8, 2), XMHW_R3N(9, 2), XMHW_R3N(10, 2), XMHW_R3(11, 2),
+    XMHW_R3(12, 2),
     XMHW_R3(3, 4), XMHW_R3NX(4, 4), XMHW_R3NX(5, 4), XMHW_R3N(6, 4), XMHW_R3N(7, 4), XMHW_R3N(8, 4), XMHW_R3N(9, 4),
     XMHW_R3N(10, 4), XMHW_R3N(11, 4), XMHW_R3N(12, 4),
 };
