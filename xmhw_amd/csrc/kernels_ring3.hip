@@ -472,19 +472,19 @@ constexpr int kBudget3 = 6;
 // buckets costs the fourth workgroup (70.7 ms).
 template <int SUBS> struct Cfg3;
 template <> struct Cfg3<4> {   // 16 cells per wave
-    static constexpr int NB = 216, CAP = 8, LW = 24, JM = 7, PS = 16;
+    static constexpr int NB = 216, CAP = 8, LW = 24, JM = 7, PS = 16, EDGE_LO = 20, EDGE_HI = 36;
 };
 // 2 lanes: 32 cells per wave, a workgroup is ONE wave (32 float32 cells = one 128-byte line): 32 * (NB + 1) + 64 * LW
 // words = 19.6 KB, eight of them per CU.  Records of up to 24 tracks (264 pooled keys: 120 buckets cover them all).
 template <> struct Cfg3<2> {
     // (bands three quarters as populous as on 4 lanes -- PS = 12 -- because a lane holds half of a cell's band and sorts
     // at most 8 keys: 6-hourly share of 405,000 cells 56.9 ms at PS = 16, 48.1 at 12, 49.8 at 11, 56.7 at 10)
-    static constexpr int NB = 120, CAP = 8, LW = 16, JM = 7, PS = 12;
+    static constexpr int NB = 120, CAP = 8, LW = 16, JM = 7, PS = 12, EDGE_LO = 14, EDGE_HI = 22;
 };
 template <> struct Cfg3<8> {   // 8 cells per wave
     // (208 buckets and lists of 20 entries instead of 128 / 16: float64 configs[2] 103.8 -> 97.7 ms, fewer window
     // rebuilds and over-populated bands; a workgroup of two float64 waves takes 34 KB of LDS)
-    static constexpr int NB = 208, CAP = 4, LW = 20, JM = 8, PS = 16;
+    static constexpr int NB = 208, CAP = 4, LW = 20, JM = 8, PS = 16, EDGE_LO = 20, EDGE_HI = 36;
 };
 // buckets are sized to hold about this many pooled keys near the target
 constexpr float kBucketRanks = 3.5f;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
     constexpr int JM = Cfg3<SUBS>::JM;
     constexpr uint32_t SLACK = JM - 2;
     constexpr uint32_t ALLC = (1u << YPS) - 1u;
-    constexpr int EDGE_LO = 20, EDGE_HI = 36;    // rebuild when the target bucket is this close to an end
+    constexpr int EDGE_LO = Cfg3<SUBS>::EDGE_LO, EDGE_HI = Cfg3<SUBS>::EDGE_HI;    // rebuild when the target bucket is this close to an end
     // band population x 16 (running mean): a rebuild is asked for outside [LO_TRIG, HI_TRIG]; whenever the wave
     // rebuilds, every cell outside [LO_ADJ, HI_ADJ] changes its bucket width too (so that it does not ask for
     // a rebuild of its own a few rows later)
