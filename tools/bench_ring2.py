@@ -45,6 +45,10 @@ def main():
     d_idx = dev.DeviceBuffer.from_array(idx)
     for v in args.variants:
         plan = dev.Plan(doy, 5, nchunks=args.chunks, ring2=v)
+        if v >= 0 and plan.ring2_in_use() != v:      # the layout is not instantiated for this record length
+            print(json.dumps({"variant": v, "config": args.config, "skipped": f"not instantiated for {plan.ntracks} tracks"}), flush=True)
+            plan.destroy()
+            continue
         D = plan.D
         th, se = dev.DeviceBuffer(8 * D * C), dev.DeviceBuffer(8 * D * C)
         e0, e1 = h.event_create(), h.event_create()

@@ -5,7 +5,7 @@
 #   r3_pmc_sq_v21.txt        SQ counters of clim_ring3_f32 on 4 lanes per cell (variant 21, shipped), 129,600 cells
 #   r3_pmc_sq_v20.txt        ... on 8 lanes per cell (variant 20)
 #   r3_pmc_lds_v21.txt       LDS counters of variant 21: instructions, bank conflicts, busy cycles (own --pmc pass)
-#   r3_ring3_variants.jsonl  tools/bench_ring2.py on the four grid configs, variants 8 / 10 (ring2) and 20 / 21 (ring3)
+#   r3_ring3_variants.jsonl  tools/bench_ring2.py on the four grid configs, variants 8 / 10 (ring2) and 20 / 21 / 22 (ring3 on 8 / 4 / 2 lanes per cell)
 # Every step runs under its own timeout.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r3; mkdir -p $O
@@ -30,7 +30,7 @@ for k in sorted(agg):
     print(f'{k:24s} {agg[k] / w / 376.0:10.1f}')
 PY
 for cfg in 0.25deg 1deg 0.25deg_nan 0.05deg_tstep; do
-  timeout 600 python3 $R/tools/bench_ring2.py --config $cfg --variants 8 10 20 21 --reps 3 >> $O/r3_ring3_variants.jsonl 2>> $O/variants.err
+  timeout 600 python3 $R/tools/bench_ring2.py --config $cfg --variants 8 10 20 21 22 --reps 3 >> $O/r3_ring3_variants.jsonl 2>> $O/variants.err
 done
 head -4 $O/r3_kernel_stats.csv
 cat $O/r3_pmc_sq_v21.txt
