@@ -141,24 +141,45 @@ int xmhw_plan_table(const xmhw_plan *plan, int32_t years_per_lane, uint32_t *tab
 /* debug: ring-kernel pass counters {rows, 32-bit count passes, extractions, cold starts,
  * fast steps, 8-bit probes, code-ring rebuilds} per wave, then count passes summed over CELLS (what
  * each cell needed on its own); all summed since the last read; the third-generation kernel
- * (variants 20, 21) reports its band-path counters in slots 5..7 (csrc/kernels_ring3.hip) and
- * shader-clock ticks per section of its row loop in slots 8..15;
- * enable != 0 allocates the counters; out16 receives 16 values                        */
-int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out16);
+ * (layouts 20..22) reports its band-path counters in slots 5..7 (csrc/kernels_ring3.hip) and
+ * shader-clock ticks per section of its row loop in slots 8..15.
+ * The counters live in counter twins of the ring kernels that the PRODUCT build does not contain
+ * (make STATS=1 builds them: tools/); xmhw_debug_stats_available() tells, and without them every
+ * counter reads 0.
+ * enable != 0 allocates the counters.  xmhw_plan_debug_stats_n: `out` receives min(n, 16) values.
+ * xmhw_plan_debug_stats (the round-1 entry point): out8 receives the first 8 values.          */
+int xmhw_debug_stats_available(void);
+int xmhw_plan_debug_stats_n(xmhw_plan *plan, int enable, uint64_t *out, int32_t n);
+int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out8);
 
-/* float32 ring kernels for w = 5 (what replaces xmhw/xmhw.py:184-197 + identify.py:212-270 per cell).
- * variant: -2 = auto (the default): the third-generation kernel (xmhw_amd/csrc/kernels_ring3.hip: per-cell
- * histogram in LDS, band compaction, sort across the lanes of a cell) on 2 lanes per cell for 9..24 tracks
- * (22), on 4 lanes for 25..48 tracks (21), on 8 lanes for 49..88 tracks (20); the second-generation kernel
- * (kernels_ring2.hip) on 16 lanes per cell for 89..96 tracks (12).  -1 = off (round-1 kernel); 0 / 7 =
- * second-generation kernel on 8 / 4 lanes per cell with 32-bit count passes and a 5-key extraction list, 8 / 10
- * = these with the lanes' lists merged into the cell's 8 / 7 nearest keys; 20 / 21 / 22 may be forced wherever
- * they are instantiated (8 lanes: 9..88 tracks, 4 lanes: 9..48, 2 lanes: 9..24); 1..6, 9, 11 = measured
- * alternatives of round 2 (8/16-bit code rings, other list widths), compiled with -DXMHW_RING2_EXPERIMENTS
- * only.  The environment variable XMHW_RING2 sets the default of new plans.  All variants return
- * bit-identical thresh.                                                                            */
+/* ---- which ring kernel and lane layout float32 input runs on ------------- *
+ * Every layout returns bit-identical thresh; the choice is about speed only.
+ * XMHW_LAYOUT_AUTO (the default): the third-generation kernel (xmhw_amd/csrc/kernels_ring3.hip:
+ * per-cell histogram in LDS, band compaction, sort across the lanes of a cell) on 2 lanes per cell
+ * for 9..24 tracks, on 4 lanes for 25..48, on 8 lanes for 49..88; the second-generation kernel
+ * (kernels_ring2.hip) on 16 lanes per cell for 89..96 tracks; the round-1 kernel otherwise.
+ * A layout may be forced wherever it is instantiated (RING3_8LANE: 9..88 tracks, RING3_4LANE: 9..48,
+ * RING3_2LANE: 9..24, RING2_8LANE / RING2_4LANE: 9..48, RING2_16LANE: 49..96); a plan it is not
+ * instantiated for falls back to the round-1 kernel (xmhw_plan_layout_in_use tells).
+ * The environment variable XMHW_RING2 sets the default of new plans (the same numbers).        */
+enum {
+    XMHW_LAYOUT_AUTO = -2,
+    XMHW_LAYOUT_RING1 = -1,          /* round-1 kernel (csrc/kernels_ring.hip): other windows, > 96 or < 9 tracks */
+    XMHW_LAYOUT_RING2_8LANE = 8,     /* second generation, lists merged into the cell's 8 nearest keys */
+    XMHW_LAYOUT_RING2_4LANE = 10,    /* second generation, 4 lanes per cell, 7 merged keys */
+    XMHW_LAYOUT_RING2_16LANE = 12,   /* second generation, 16 lanes per cell: 49..96 tracks */
+    XMHW_LAYOUT_RING3_8LANE = 20,    /* third generation, 8 cells per wave */
+    XMHW_LAYOUT_RING3_4LANE = 21,    /* third generation, 16 cells per wave: the headline layout (40 tracks) */
+    XMHW_LAYOUT_RING3_2LANE = 22     /* third generation, 32 cells per wave */
+};
+int xmhw_plan_set_layout(xmhw_plan *plan, int32_t layout);
+/* the layout float32 input of this plan will run on (XMHW_LAYOUT_RING1 if the round-1 / generic kernel) */
+int xmhw_plan_layout_in_use(const xmhw_plan *plan, int32_t *layout);
+/* DEPRECATED names of the two entries above (rounds 2 and 3, when the numbers meant variants of the
+ * second-generation kernel); also accepted: 1..7, 9, 11 = measured-and-rejected alternatives of round 2,
+ * built with -DXMHW_RING2_EXPERIMENTS only; 30..32 = the round-4 key-store experiment
+ * (csrc/kernels_ring4.hip, built with `make RING4=1` only; profiles/r4_store_experiment.txt)          */
 int xmhw_plan_set_ring2(xmhw_plan *plan, int32_t variant);
-/* the variant float32 input of this plan will run on, -1 if the round-1 / generic kernel */
 int xmhw_plan_ring2_in_use(const xmhw_plan *plan, int32_t *variant);
 /* genuinely float64 samples (those that do not narrow to float32): the layout of the 64-bit mode
  * (64-bit keys as a high word -- what the selection runs on -- and a low word) this plan will run on:

@@ -75,10 +75,11 @@ def _check(dev, x, doy, q=0.9, negate=False, nchunks=1, min_band=None):
             continue
         npt.assert_array_equal(t1, tg, err_msg=f"variant {v}")
         npt.assert_allclose(s1, sg, rtol=1e-12, atol=1e-300, equal_nan=True, err_msg=f"variant {v}")
-        assert st[0] > 0, "the ring3 kernel did not run"
-        assert int(st[3]) >> 32 == 0, f"variant {v}: the histogram disagreed with the ring {st}"
-        if min_band is not None:
-            assert _band_share(st) >= min_band, (v, _band_share(st), st)
+        if dev.hip().debug_stats_available():       # counter twins: make STATS=1 (the product build has none)
+            assert st[0] > 0, "the ring3 kernel did not run"
+            assert int(st[3]) >> 32 == 0, f"variant {v}: the histogram disagreed with the ring {st}"
+            if min_band is not None:
+                assert _band_share(st) >= min_band, (v, _band_share(st), st)
         out[v] = (t1, s1, st)
     assert out, "no ring3 layout ran"
     return tg, sg, out

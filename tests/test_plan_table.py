@@ -114,8 +114,8 @@ def test_ring2_layout_choice():
     assert years(20).ring2_in_use() == 22                     # 2 x 10 = 20 tracks
     assert Plan(np.tile(np.arange(1, 1461), 20), 5).ring2_in_use() == 22     # config 5's tstep axis
     assert years(12).ring2_in_use() == 22 and years(9).ring2_in_use() == 22
-    assert years(20, ring2=0).ring2_in_use() == 0             # forced
-    assert years(40, ring2=7).ring2_in_use() == 7
+    assert years(20, ring2=0).ring2_in_use() == -1            # (0 / 7: the plain second-generation layouts left the default build in round 4)
+    assert years(40, ring2=7).ring2_in_use() == -1
     assert years(40, ring2=-1).ring2_in_use() == -1           # round-1 kernel
     assert years(10).ring2_in_use() == 22 and years(10, ring2=10).ring2_in_use() == 10
     assert years(16).ring2_in_use() == 22                     # 16 tracks: 2 x 8
@@ -137,6 +137,19 @@ def test_ring2_layout_choice():
     assert years(97).f64_mode() == -1 and years(40, w=3).f64_mode() == -1        # generic kernel
     with pytest.raises(Exception):
         years(40, ring2=14)
+    # the round-4 names: xmhw_plan_set_layout / xmhw_plan_layout_in_use with the XMHW_LAYOUT_* constants
+    from xmhw_amd.device import LAYOUTS
+    assert LAYOUTS == {"auto": -2, "ring1": -1, "ring2_8lane": 8, "ring2_4lane": 10, "ring2_16lane": 12,
+                       "ring3_8lane": 20, "ring3_4lane": 21, "ring3_2lane": 22}
+    t40 = ora.add_doy(np.arange("1982-01-01", "2022-01-01", dtype="datetime64[D]"))
+    assert Plan(t40, 5).layout_in_use() == LAYOUTS["ring3_4lane"]
+    assert Plan(t40, 5, layout="ring3_8lane").layout_in_use() == 20
+    assert Plan(t40, 5, layout="ring2_8lane").layout_in_use() == 8
+    assert Plan(t40, 5, layout="ring2_4lane").layout_in_use() == 10
+    assert Plan(t40, 5, layout="ring1").layout_in_use() == -1
+    assert Plan(t40, 5, layout="ring3_2lane").layout_in_use() == -1      # 40 tracks do not fit 2 lanes per cell
+    with pytest.raises(Exception):
+        Plan(t40, 5, layout=14)
 
 
 def test_bad_arguments():

@@ -95,7 +95,7 @@ def check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks, msg=""):
         npt.assert_array_equal(tr, t0, err_msg=f"{msg} round-1 ring")
         npt.assert_allclose(sr, s0, rtol=1e-12, atol=1e-300, equal_nan=True, err_msg=f"{msg} round-1 ring")
     seen = set()
-    for v in (None, 0, 7, 8, 10, 12, 20, 21, 22):
+    for v in (None, 0, 7, 8, 10, 12, 20, 21, 22, 30, 31, 32):
         plan = dev.Plan(doy, 5, ring2=v)
         use = plan.ring2_in_use()
         plan.destroy()
@@ -103,7 +103,7 @@ def check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks, msg=""):
             continue
         seen.add(use)
         t1, s1, st = _raw(dev, x, doy, pct / 100.0, cold, nchunks, ring2=use)
-        assert st[0] > 0, "the ring2 kernel did not run"
+        assert st[0] > 0 or not dev.hip().debug_stats_available(), "the ring2 kernel did not run"
         with np.errstate(invalid="ignore"):
             npt.assert_array_equal(t1, t0, err_msg=f"{msg} variant {use}")
             npt.assert_allclose(s1, s0, rtol=1e-12, atol=1e-300, equal_nan=True, err_msg=f"{msg} variant {use}")
@@ -167,7 +167,7 @@ def main():
                            msg=f"seed {args.seed} case {i}: T={x.shape[0]} C={x.shape[1]} pct={pct} tstep={tstep} cold={cold}")
         print(f"{args.cases} random float64 cases: 0 mismatches against the generic kernel ({time.perf_counter() - t0:.0f} s)")
         return
-    layouts = {0: 0, 7: 0, 8: 0, 10: 0, 20: 0, 21: 0}
+    layouts = {0: 0, 7: 0, 8: 0, 10: 0, 20: 0, 21: 0, 31: 0}
     for i in range(args.cases):
         x, doy, pct, tstep, cold, nchunks = random_ring2_case(rng, (49, 121) if args.long else (9, 49))
         seen = check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks,

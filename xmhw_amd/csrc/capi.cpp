@@ -174,7 +174,7 @@ int32_t auto_chunks(const xmhw_plan* p, int64_t C) {
         // with 1 or 2 chunks, 3.87 with 3, 4.16 with 6)
         const int32_t v = ring2_resolved(p);
         if (v >= 20) {
-            const int64_t cpw = v == 22 ? 32 : v == 21 ? 16 : 8;
+            const int64_t cpw = 64 / xmhw::ring2_subs(v);
             waves = (C + cpw - 1) / cpw;
             want = (4096 + waves - 1) / std::max<int64_t>(waves, 1);
         }
@@ -1025,21 +1025,24 @@ int xmhw_plan_create(const int32_t* doy_host, int64_t T, int32_t window_half_wid
     *plan = p;
     return XMHW_OK;
 }
-int xmhw_plan_set_ring2(xmhw_plan* plan, int32_t variant) {
+int xmhw_plan_set_layout(xmhw_plan* plan, int32_t layout) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
-    if (variant < -2 || (variant > 12 && variant != 20 && variant != 21 && variant != 22))
-        return fail(XMHW_ERR_INVALID, "ring2 variant must be -2 (auto), -1 (off), 0..12 or 20..22");
-    plan->ring2_variant = variant;
+    if (layout < -2 || (layout > 12 && !(layout >= 20 && layout <= 22) && !(layout >= 30 && layout <= 32)))
+        return fail(XMHW_ERR_INVALID, "layout must be one of the XMHW_LAYOUT_* constants (-2, -1, 8, 10, 12, 20..22)");
+    plan->ring2_variant = layout;
     return XMHW_OK;
 }
-int xmhw_plan_ring2_in_use(const xmhw_plan* plan, int32_t* variant) {
-    if (!plan || !variant) return fail(XMHW_ERR_INVALID, "NULL argument");
-    const bool ring = resolve_kernel(plan, 4) == XMHW_KERNEL_RING;
+int xmhw_plan_layout_in_use(const xmhw_plan* plan, int32_t* layout) {
+    if (!plan || !layout) return fail(XMHW_ERR_INVALID, "NULL argument");
     const int32_t v2 = ring2_resolved(plan);
+    const bool ring = resolve_kernel(plan, 4) == XMHW_KERNEL_RING;
     const int32_t y2 = v2 >= 0 ? xmhw::ring2_pick_yps(plan->host.w, plan->host.ntracks, v2) : 0;
-    *variant = (ring && y2 > 0 && xmhw::ring2_f32_supported(plan->host.w, y2, v2)) ? v2 : -1;
+    *layout = (ring && y2 > 0 && xmhw::ring2_f32_supported(plan->host.w, y2, v2)) ? v2 : -1;
     return XMHW_OK;
 }
+// deprecated aliases (rounds 2 and 3)
+int xmhw_plan_set_ring2(xmhw_plan* plan, int32_t variant) { return xmhw_plan_set_layout(plan, variant); }
+int xmhw_plan_ring2_in_use(const xmhw_plan* plan, int32_t* variant) { return xmhw_plan_layout_in_use(plan, variant); }
 int xmhw_plan_f64_mode(const xmhw_plan* plan, int32_t* variant) {
     if (!plan || !variant) return fail(XMHW_ERR_INVALID, "NULL argument");
     *variant = resolve_kernel(plan, 8) == XMHW_KERNEL_RING ? x64_choice(plan).variant : -1;
@@ -1091,19 +1094,27 @@ int xmhw_plan_set_chunks(xmhw_plan* plan, int32_t nchunks) {
     plan->host.nchunks_req = nchunks;
     return XMHW_OK;
 }
-int xmhw_plan_debug_stats(xmhw_plan* plan, int enable, uint64_t* out4) {
+int xmhw_debug_stats_available(void) { return xmhw::ring_stats_built() ? 1 : 0; }
+int xmhw_plan_debug_stats_n(xmhw_plan* plan, int enable, uint64_t* out, int32_t n) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
+    if (out && n <= 0) return fail(XMHW_ERR_INVALID, "n must be > 0");
     if (enable && !plan->d_stats) {
         HIP_TRY(hipMalloc(&plan->d_stats, 16 * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(plan->d_stats, 0, 16 * sizeof(unsigned long long)));
     }
-    if (out4) {
+    if (out) {
         if (!plan->d_stats) return fail(XMHW_ERR_INVALID, "stats not enabled");
+        unsigned long long all[16];
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(out4, plan->d_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemset(plan->d_stats, 0, 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemcpy(all, plan->d_stats, sizeof(all), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(plan->d_stats, 0, sizeof(all)));
+        for (int32_t i = 0; i < std::min<int32_t>(n, 16); ++i) out[i] = all[i];
     }
     return XMHW_OK;
+}
+// (the round-1 contract: 8 values)
+int xmhw_plan_debug_stats(xmhw_plan* plan, int enable, uint64_t* out8) {
+    return xmhw_plan_debug_stats_n(plan, enable, out8, 8);
 }
 int xmhw_plan_table(const xmhw_plan* plan, int32_t years_per_lane, uint32_t* table_out,
                     int32_t* ntracks_padded) {

@@ -41,6 +41,7 @@ hipError_t launch_ring2_f64(const double* ts, int64_t C, int64_t ld, int64_t Tn,
                             const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,
                             int32_t w, int32_t yps, int32_t ntracks, int32_t variant, double q, int negate,
                             double* thresh, double* seas, int64_t ldo, hipStream_t stream, const uint32_t* run_flag);
+bool ring_stats_built();                                                // the counter twins exist (-DXMHW_RING_STATS)
 int32_t ring2_subs(int32_t variant);                                    // lanes per cell of that variant
 hipError_t launch_ring2_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
                             const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,
@@ -53,6 +54,17 @@ hipError_t launch_ring2_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
 int32_t ring3_pick_yps(int32_t w, int32_t ntracks, int32_t subs);
 bool ring3_supported(int32_t w, int32_t yps, int32_t subs);
 hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
+                            const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,
+                            int32_t w, int32_t yps, int32_t subs, int32_t ntracks, double q, int negate,
+                            double* thresh, double* seas, int64_t ldo, hipStream_t stream,
+                            unsigned long long* stats = nullptr);
+
+// fourth-generation float32 ring kernel (kernels_ring4.hip): a windowed key store in LDS instead of histogram + band
+// compaction; same lane layouts and step tables as the third generation (ring2 variants 30 / 31 / 32 = 8 / 4 / 2 lanes)
+int32_t ring4_pick_yps(int32_t w, int32_t ntracks, int32_t subs);
+bool ring4_supported(int32_t w, int32_t yps, int32_t subs);
+bool ring4_stats_built();
+hipError_t launch_ring4_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
                             const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,
                             int32_t w, int32_t yps, int32_t subs, int32_t ntracks, double q, int negate,
                             double* thresh, double* seas, int64_t ldo, hipStream_t stream,

@@ -1204,21 +1204,27 @@ struct Ring2Entry { int w, yps, subs, variant; Ring2Kernel fn, fn_stats; Ring2Ke
 //   10 / 11: as 9 with 7 / 6 merged keys (4 lanes per cell: a lane holds 5 of the cell's 8 nearest more often)
 //   12: 16 lanes per cell (4 cells per wave), wide merge: the 64-bit mode's layout for short records, and the
 //       float32 layout of 49..96-track records
-#define XMHW_R2V(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>, nullptr, nullptr}
+// (the counter twins are built with -DXMHW_RING_STATS only: tools/, not the product)
+#ifdef XMHW_RING_STATS
+#define XMHW_R2S(W, Y, PB, JX, JM, S) clim_ring2_f32<W, Y, PB, JX, JM, S, true>
+#else
+#define XMHW_R2S(W, Y, PB, JX, JM, S) nullptr
+#endif
+#define XMHW_R2V(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, XMHW_R2S(W, Y, PB, JX, JM, S), nullptr, nullptr}
 // the shipped layouts also exist for float64 input: narrowing to float32 where that is lossless, and the
 // 64-bit mode (high / low key words) for genuinely float64 samples
-#define XMHW_R2N(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>, \
+#define XMHW_R2N(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, XMHW_R2S(W, Y, PB, JX, JM, S), \
                                           clim_ring2_f32<W, Y, PB, JX, JM, S, false, double>,             \
                                           clim_ring2_f32<W, Y, PB, JX, JM, S, false, double, 1>}
 // (narrowing only: the 64-bit mode would spill heavily at 66 or more keys per lane; those plans keep the
 // round-1 float64 kernel)
-#define XMHW_R2M(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>, \
+#define XMHW_R2M(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, XMHW_R2S(W, Y, PB, JX, JM, S), \
                                           clim_ring2_f32<W, Y, PB, JX, JM, S, false, double>, nullptr}
 // 16 lanes per cell, 64-bit mode only (variant 12): genuinely float64 samples of plans with more keys per lane
 // than the 8- and 4-lane layouts can hold in registers next to the low words, and of short records
 #define XMHW_R2X(W, Y, S, V, PB, JX, JM) {W, Y, S, V, nullptr, nullptr, nullptr, clim_ring2_f32<W, Y, PB, JX, JM, S, false, double, 1>}
 // narrowing + the 64-bit mode with the low words in LDS (5 and 6 tracks per lane at 8 lanes per cell)
-#define XMHW_R2L(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, clim_ring2_f32<W, Y, PB, JX, JM, S, true>, \
+#define XMHW_R2L(W, Y, S, V, PB, JX, JM) {W, Y, S, V, clim_ring2_f32<W, Y, PB, JX, JM, S, false>, XMHW_R2S(W, Y, PB, JX, JM, S), \
                                           clim_ring2_f32<W, Y, PB, JX, JM, S, false, double>,             \
                                           clim_ring2_f32<W, Y, PB, JX, JM, S, false, double, 2>}
 // Default build: the layouts the library can pick on its own or for float64 input -- variant 8 (8 lanes, wide
@@ -1229,29 +1235,32 @@ struct Ring2Entry { int w, yps, subs, variant; Ring2Kernel fn, fn_stats; Ring2Ke
 #ifdef XMHW_RING2_EXPERIMENTS
 #define XMHW_R2(W, Y) XMHW_R2V(W, Y, 8, 0, 0, 5, 5), XMHW_R2V(W, Y, 8, 1, 8, 5, 5), XMHW_R2V(W, Y, 8, 2, 16, 5, 5), \
                       XMHW_R2V(W, Y, 8, 3, 16, 4, 4), XMHW_R2V(W, Y, 8, 4, 16, 3, 3), XMHW_R2V(W, Y, 8, 5, 0, 4, 4), \
-                      XMHW_R2V(W, Y, 8, 6, 0, 6, 6)
+                      XMHW_R2V(W, Y, 8, 6, 0, 6, 6),
 #define XMHW_R2E(...) __VA_ARGS__,
 #else
-#define XMHW_R2(W, Y) XMHW_R2V(W, Y, 8, 0, 0, 5, 5)
+#define XMHW_R2(W, Y)
 #define XMHW_R2E(...)
 #endif
+// (round 4: the plain layouts 0 and 7 -- the shipped 8 and 10 without the merged lists -- left the default build with
+// the other experiments)
 const Ring2Entry kRing2[] = {
-    XMHW_R2(5, 3), XMHW_R2(5, 4), XMHW_R2(5, 5),
+    XMHW_R2(5, 3) XMHW_R2(5, 4) XMHW_R2(5, 5)
     XMHW_R2L(5, 3, 8, 8, 0, 5, 8), XMHW_R2N(5, 4, 8, 8, 0, 5, 8), XMHW_R2L(5, 5, 8, 8, 0, 5, 8),
-    XMHW_R2V(5, 5, 4, 7, 0, 5, 5), XMHW_R2V(5, 8, 4, 7, 0, 5, 5), XMHW_R2V(5, 10, 4, 7, 0, 5, 5),
+    XMHW_R2E(XMHW_R2V(5, 5, 4, 7, 0, 5, 5), XMHW_R2V(5, 8, 4, 7, 0, 5, 5), XMHW_R2V(5, 10, 4, 7, 0, 5, 5))
     XMHW_R2E(XMHW_R2V(5, 5, 4, 9, 0, 5, 8), XMHW_R2V(5, 8, 4, 9, 0, 5, 8), XMHW_R2V(5, 10, 4, 9, 0, 5, 8))
     XMHW_R2N(5, 5, 4, 10, 0, 5, 7), XMHW_R2M(5, 8, 4, 10, 0, 5, 7), XMHW_R2M(5, 10, 4, 10, 0, 5, 7),
     XMHW_R2E(XMHW_R2V(5, 5, 4, 11, 0, 5, 6), XMHW_R2V(5, 8, 4, 11, 0, 5, 6), XMHW_R2V(5, 10, 4, 11, 0, 5, 6))
-    // shorter and longer records (9..16 and 41..48 tracks: 10-year series, OISST 1982-today), shipped layouts
-    // and their plain counterparts only
-    XMHW_R2V(5, 2, 8, 0, 0, 5, 5), XMHW_R2N(5, 2, 8, 8, 0, 5, 8), XMHW_R2V(5, 6, 8, 0, 0, 5, 5), XMHW_R2L(5, 6, 8, 8, 0, 5, 8),
-    XMHW_R2V(5, 3, 4, 7, 0, 5, 5), XMHW_R2N(5, 3, 4, 10, 0, 5, 7), XMHW_R2V(5, 4, 4, 7, 0, 5, 5), XMHW_R2N(5, 4, 4, 10, 0, 5, 7),
+    // shorter and longer records (9..16 and 41..48 tracks: 10-year series, OISST 1982-today), shipped layouts only
+    XMHW_R2E(XMHW_R2V(5, 2, 8, 0, 0, 5, 5), XMHW_R2V(5, 6, 8, 0, 0, 5, 5), XMHW_R2V(5, 3, 4, 7, 0, 5, 5), XMHW_R2V(5, 4, 4, 7, 0, 5, 5))
+    XMHW_R2N(5, 2, 8, 8, 0, 5, 8), XMHW_R2L(5, 6, 8, 8, 0, 5, 8),
+    XMHW_R2N(5, 3, 4, 10, 0, 5, 7), XMHW_R2N(5, 4, 4, 10, 0, 5, 7),
     XMHW_R2X(5, 1, 16, 12, 0, 5, 8), XMHW_R2X(5, 2, 16, 12, 0, 5, 8), XMHW_R2X(5, 3, 16, 12, 0, 5, 8),
     // long records (49..96 tracks: reanalyses, model runs) on 16 lanes per cell: float32, narrowing float64 and the
     // 64-bit mode with its low words in LDS
     XMHW_R2L(5, 4, 16, 12, 0, 5, 8), XMHW_R2L(5, 5, 16, 12, 0, 5, 8), XMHW_R2L(5, 6, 16, 12, 0, 5, 8),
 };
 #undef XMHW_R2
+#undef XMHW_R2S
 #undef XMHW_R2E
 #undef XMHW_R2V
 #undef XMHW_R2N
@@ -1265,18 +1274,24 @@ const Ring2Entry* find_ring2(int32_t w, int32_t yps, int32_t subs, int32_t varia
 }
 }  // namespace
 
-// variants 20 / 21: the third-generation kernel (kernels_ring3.hip) on 8 / 4 lanes per cell
+// variants 20 / 21 / 22: the third-generation kernel (kernels_ring3.hip) on 8 / 4 / 2 lanes per cell; 30 / 31 / 32: the
+// round-4 key-store experiment (kernels_ring4.hip, built with `make RING4=1` only: profiles/r4_store_experiment.txt)
 int32_t ring2_subs(int32_t variant) {
-    if (variant >= 20) return variant == 22 ? 2 : variant == 21 ? 4 : 8;
+    if (variant >= 20) return variant % 10 == 2 ? 2 : variant % 10 == 1 ? 4 : 8;
     return variant == 12 ? 16 : (variant == 7 || variant >= 9) ? 4 : 8;
 }
 
 int32_t ring2_pick_yps(int32_t w, int32_t ntracks, int32_t variant) {
     const int32_t subs = ring2_subs(variant);
+#ifdef XMHW_RING4
+    if (variant >= 30) return ring4_pick_yps(w, ntracks, subs);
+#else
+    if (variant >= 30) return 0;
+#endif
     if (variant >= 20) return ring3_pick_yps(w, ntracks, subs);
     int32_t best = 0;
     for (const auto& e : kRing2)
-        if (e.w == w && e.variant == (variant < 0 ? 0 : variant) && e.subs == subs && e.yps * subs >= ntracks &&
+        if (e.w == w && e.variant == (variant < 0 ? 8 : variant) && e.subs == subs && e.yps * subs >= ntracks &&
             (best == 0 || e.yps < best))
             best = e.yps;
     // padding may only sit in the last slot of a lane
@@ -1290,6 +1305,13 @@ hipError_t launch_ring2_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
                             double* thresh, double* seas, int64_t ldo, hipStream_t stream,
                             unsigned long long* stats) {
     const int32_t subs = ring2_subs(variant);
+#ifdef XMHW_RING4
+    if (variant >= 30)
+        return launch_ring4_f32(ts, C, ld, Tn, table, sflags, step_min, chunks, nchunks, w, yps, subs, ntracks, q, negate,
+                                thresh, seas, ldo, stream, stats);
+#else
+    if (variant >= 30) return hipErrorInvalidValue;
+#endif
     if (variant >= 20)
         return launch_ring3_f32(ts, C, ld, Tn, table, sflags, step_min, chunks, nchunks, w, yps, subs, ntracks, q, negate,
                                 thresh, seas, ldo, stream, stats);
@@ -1298,12 +1320,19 @@ hipError_t launch_ring2_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
     if (C <= 0 || nchunks <= 0) return hipSuccess;
     const int64_t cells_per_block = (64 / subs) * kWaves2;
     dim3 grid(static_cast<unsigned>((C + cells_per_block - 1) / cells_per_block), static_cast<unsigned>(nchunks));
-    hipLaunchKernelGGL(stats ? e->fn_stats : e->fn, grid, dim3(64 * kWaves2), 0, stream, ts, C, ld, Tn, table, sflags, step_min,
-                       chunks, q, negate, ntracks, thresh, seas, ldo, stats, static_cast<uint32_t*>(nullptr));
+    const bool twin = stats != nullptr && e->fn_stats != nullptr;
+    hipLaunchKernelGGL(twin ? e->fn_stats : e->fn, grid, dim3(64 * kWaves2), 0, stream, ts, C, ld, Tn, table, sflags, step_min,
+                       chunks, q, negate, ntracks, thresh, seas, ldo, twin ? stats : nullptr,
+                       static_cast<uint32_t*>(nullptr));
     return hipGetLastError();
 }
 
 bool ring2_f32_supported(int32_t w, int32_t yps, int32_t variant) {
+#ifdef XMHW_RING4
+    if (variant >= 30) return ring4_supported(w, yps, ring2_subs(variant));
+#else
+    if (variant >= 30) return false;
+#endif
     if (variant >= 20) return ring3_supported(w, yps, ring2_subs(variant));
     const Ring2Entry* e = find_ring2(w, yps, ring2_subs(variant), variant);
     return e != nullptr && e->fn != nullptr;
@@ -1321,6 +1350,7 @@ hipError_t launch_ring2_f64(const double* ts, int64_t C, int64_t ld, int64_t Tn,
                             int32_t w, int32_t yps, int32_t ntracks, int32_t variant, double q, int negate,
                             double* thresh, double* seas, int64_t ldo, hipStream_t stream, const uint32_t* run_flag) {
     const int32_t subs = ring2_subs(variant);
+    if (variant >= 30) return hipErrorInvalidValue;
     if (variant >= 20)
         return launch_ring3_f64(ts, C, ld, Tn, table, sflags, step_min, chunks, nchunks, w, yps, subs, ntracks, q, negate,
                                 thresh, seas, ldo, stream, run_flag);
@@ -1336,6 +1366,7 @@ hipError_t launch_ring2_f64(const double* ts, int64_t C, int64_t ld, int64_t Tn,
 }
 
 bool ring2_narrowing_supported(int32_t w, int32_t yps, int32_t variant) {
+    if (variant >= 30) return false;
     if (variant >= 20) return ring3_narrowing_supported(w, yps, ring2_subs(variant));
     const Ring2Entry* e = find_ring2(w, yps, ring2_subs(variant), variant);
     return e != nullptr && e->fn_narrow != nullptr;
@@ -1349,6 +1380,7 @@ hipError_t launch_ring2_f32_narrowing(const double* ts, int64_t C, int64_t ld, i
                                       double q, int negate, double* thresh, double* seas, int64_t ldo,
                                       hipStream_t stream, uint32_t* narrow_flag) {
     const int32_t subs = ring2_subs(variant);
+    if (variant >= 30) return hipErrorInvalidValue;
     if (variant >= 20)
         return launch_ring3_f32_narrowing(ts, C, ld, Tn, table, sflags, step_min, chunks, nchunks, w, yps, subs, ntracks, q,
                                           negate, thresh, seas, ldo, stream, narrow_flag);

@@ -1,6 +1,7 @@
 // pybind.cpp -- thin pybind11 layer over the C ABI (include/xmhw_amd.h).
 // No logic lives here: argument unpacking, error code -> exception.
 #include <pybind11/numpy.h>
+#include <algorithm>
 #include <pybind11/pybind11.h>
 
 #include <cstdint>
@@ -136,9 +137,13 @@ PYBIND11_MODULE(_xmhw_hip, m) {
 
     m.def("plan_debug_stats", [](uintptr_t p, int enable, bool read) {
         py::array_t<uint64_t> out(16);
-        check(xmhw_plan_debug_stats(pp(p), enable, read ? out.mutable_data() : nullptr));
+        std::fill(out.mutable_data(), out.mutable_data() + 16, uint64_t(0));
+        check(xmhw_plan_debug_stats_n(pp(p), enable, read ? out.mutable_data() : nullptr, 16));
         return out;
     });
+    m.def("debug_stats_available", []() { return xmhw_debug_stats_available() != 0; });
+    m.def("plan_set_layout", [](uintptr_t p, int layout) { check(xmhw_plan_set_layout(pp(p), layout)); });
+    m.def("plan_layout_in_use", [](uintptr_t p) { int32_t v = -1; check(xmhw_plan_layout_in_use(pp(p), &v)); return v; });
     m.def("plan_ring2_in_use", [](uintptr_t p) { int32_t v = -1; check(xmhw_plan_ring2_in_use(pp(p), &v)); return v; });
     m.def("plan_f64_mode", [](uintptr_t p) { int32_t v = -1; check(xmhw_plan_f64_mode(pp(p), &v)); return v; });
     m.def("plan_set_ring2", [](uintptr_t p, int variant) { check(xmhw_plan_set_ring2(pp(p), variant)); });

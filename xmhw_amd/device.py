@@ -172,10 +172,15 @@ class DeviceBuffer:
             pass
 
 
+# include/xmhw_amd.h: XMHW_LAYOUT_*
+LAYOUTS = {"auto": -2, "ring1": -1, "ring2_8lane": 8, "ring2_4lane": 10, "ring2_16lane": 12,
+           "ring3_8lane": 20, "ring3_4lane": 21, "ring3_2lane": 22}
+
+
 class Plan:
     """Everything derived from the doy labels (xmhw_plan_* in the C ABI)."""
 
-    def __init__(self, doy, window_half_width, kernel="auto", nchunks=0, narrowing=True, ring2=None):
+    def __init__(self, doy, window_half_width, kernel="auto", nchunks=0, narrowing=True, ring2=None, layout=None):
         self._h = hip()
         doy = np.ascontiguousarray(doy, dtype=np.int32)
         try:
@@ -185,8 +190,10 @@ class Plan:
         self._h.plan_set_kernel(self.handle, KERNELS[kernel])
         self._h.plan_set_chunks(self.handle, int(nchunks))
         self._h.plan_set_narrowing(self.handle, int(bool(narrowing)))
-        if ring2 is not None:           # None: the library default (environment XMHW_RING2)
-            self._h.plan_set_ring2(self.handle, int(ring2))
+        if layout is None:
+            layout = ring2              # (the rounds 2-3 name of the same argument)
+        if layout is not None:          # None: the library default (environment XMHW_RING2)
+            self._h.plan_set_layout(self.handle, int(LAYOUTS.get(layout, layout)))
         info = self._h.plan_info(self.handle)
         self.D = info["D"]
         self.ntracks = info["ntracks"]
@@ -197,9 +204,11 @@ class Plan:
         self.T = doy.shape[0]
         self.w = int(window_half_width)
 
-    def ring2_in_use(self):
-        """variant of the second-generation ring kernel float32 input will run on (-1: none)"""
-        return int(self._h.plan_ring2_in_use(self.handle))
+    def layout_in_use(self):
+        """the ring kernel + lane layout float32 input will run on (an XMHW_LAYOUT_* number; -1: round-1 / generic)"""
+        return int(self._h.plan_layout_in_use(self.handle))
+
+    ring2_in_use = layout_in_use        # deprecated name (rounds 2-3)
 
     def f64_mode(self):
         """layout variant of the 64-bit mode float64 samples will run on (-1: generic kernel)"""
