@@ -21,10 +21,12 @@ smoothing (finish kernel).  Timing: barrier + device sync, K steps, device sync 
 ranks.  One JSON line on rank 0's stdout (see the driver contract):
   roofline      ring kernel: algorithmic bytes (T*4 + 2*D*8 per cell) / average launch time from HIP
                 events recorded on the kernels' stream; `traffic` = HBM bytes per launch measured
-                LIVE: before this process touches the GPU it runs itself twice under
-                `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE in separate passes, the gfx950 x2
+                LIVE: before this process touches the GPU it runs itself three times under
+                `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE, SQ_* in separate passes, the gfx950 x2
                 correction of FETCH_SIZE applied) on one step of the same workload; null when
-                rocprofv3 is unavailable (N > 1: null)
+                rocprofv3 is unavailable (N > 1: null).  `binding`: the resource that actually limits
+                the kernel -- vector-instruction issue: instructions per wave-row and the share of the
+                SIMD's cycles its vector ALU is busy, from the SQ pass
   cpu_baseline  the per-cell numpy restatement of the reference (oracle/oracle_percell.py) on the
                 box's PHYSICAL cores (spawned workers, pool start-up and pool-index construction
                 outside the timed region), a bounded sample of the same synthetic input
@@ -85,7 +87,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-other", action="store_true", help="skip the other_configs leg (N = 1: float64 configs[2], float32 configs[1], [3], [4] share)")
     ap.add_argument("--other-cells", type=int, default=0, help="cells of each other_configs run (0: the preset's own grid)")
     ap.add_argument("--cpu-cells", type=int, default=16384)
-    ap.add_argument("--parity-cells", type=int, default=512)
+    ap.add_argument("--parity-cells", type=int, default=4096, help="cells of the headline parity check (SURVEY 8d: 4,096)")
+    ap.add_argument("--other-parity-cells", type=int, default=512, help="cells of each other_configs parity check")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
@@ -142,43 +145,67 @@ def launch_workers(args):
     return rc
 
 
-def live_traffic(argv):
-    """HBM bytes per ring-kernel launch measured on THIS box for THIS workload: two rocprofv3 --pmc
-    passes (FETCH_SIZE, WRITE_SIZE: TCC slots do not fit both) of one untimed step, run as child
-    processes before this process touches the GPU.  FETCH_SIZE is reported in KB and counts a wide
-    coalesced stream at half its bytes on gfx950 (MI355X_MICROARCH.md, HBM): x2."""
+def live_counters(argv, rows_per_wave):
+    """Counters of the ring kernel measured on THIS box for THIS workload by rocprofv3 --pmc passes of one
+    untimed step, run as child processes before this process touches the GPU (the program directly after `--`):
+      FETCH_SIZE, WRITE_SIZE (separate passes: the TCC slots do not fit both) -> HBM bytes per launch.  FETCH_SIZE is
+        reported in KB and counts a wide coalesced stream at half its bytes on gfx950 (MI355X_MICROARCH.md, HBM): x2;
+      SQ_* (one pass) -> instructions per wave-row and the share of a wave's cycles its vector ALU is busy: the
+        binding resource of this kernel is instruction issue, not HBM.
+    Returns (traffic bytes per launch or None, its source text, dict of SQ results or None)."""
     import csv
     import glob
     import shutil
     import tempfile
     if shutil.which("rocprofv3") is None:
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", None
     out = {}
+    sq = None
     tmp = tempfile.mkdtemp(prefix="xmhw_pmc_", dir="/tmp")
+    sq_names = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU",
+                "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+        for tag, counters in (("FETCH_SIZE", ["FETCH_SIZE"]), ("WRITE_SIZE", ["WRITE_SIZE"]), ("SQ", sq_names)):
+            d = os.path.join(tmp, tag)
+            cmd = ["rocprofv3", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--",
                    sys.executable, os.path.abspath(__file__)] + argv + \
                   ["--steps", "1", "--warmup", "0", "--no-cpu", "--no-pmc", "--parity-cells", "0", "--pmc-child"]
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
-            tot, n = 0.0, 0
+                if tag == "SQ":
+                    break           # the traffic stands without the issue counters
+                return None, f"rocprofv3 --pmc {tag} failed (rc {r.returncode})", None
+            tot, n, name = {}, 0, None
             for row in csv.DictReader(open(files[0])):
-                if "clim_ring" in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                    tot += float(row["Counter_Value"])
-                    n += 1
+                if "clim_ring" in row["Kernel_Name"] and row["Counter_Name"] in counters:
+                    tot[row["Counter_Name"]] = tot.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                    n += row["Counter_Name"] == counters[0]
+                    name = row["Kernel_Name"]
             if n == 0:
-                return None, "no ring-kernel dispatch in the counter file"
-            out[counter] = tot / n * 1024.0        # KB -> bytes, per launch
+                if tag == "SQ":
+                    break
+                return None, "no ring-kernel dispatch in the counter file", None
+            if tag == "SQ":
+                waves = max(tot.get("SQ_WAVES", 0.0), 1.0)
+                wr = waves * rows_per_wave               # wave-rows of all launches in the file
+                wc = max(tot.get("SQ_WAVE_CYCLES", 0.0), 1.0)
+                sq = {"kernel": name, "launches": n, "waves_per_launch": waves / n, "rows_per_wave": rows_per_wave,
+                      "valu_per_wave_row": tot.get("SQ_INSTS_VALU", 0.0) / wr, "salu_per_wave_row": tot.get("SQ_INSTS_SALU", 0.0) / wr,
+                      "lds_per_wave_row": tot.get("SQ_INSTS_LDS", 0.0) / wr,
+                      "wave_quad_cycles_per_wave_row": wc / wr,
+                      "valu_busy_of_wave_cycles": tot.get("SQ_ACTIVE_INST_VALU", 0.0) / wc,
+                      "wait_any_of_wave_cycles": tot.get("SQ_WAIT_ANY", 0.0) / wc,
+                      "wait_inst_any_of_wave_cycles": tot.get("SQ_WAIT_INST_ANY", 0.0) / wc}
+            else:
+                out[tag] = tot[tag] / n * 1024.0        # KB -> bytes, per launch
     except Exception as e:      # noqa: BLE001 -- a profiler problem must not fail the benchmark
-        return None, f"{type(e).__name__}: {e}"
+        return None, f"{type(e).__name__}: {e}", None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"], "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, this run's box and workload"
+    return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"],
+            "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, this run's box and workload", sq)
 
 
 def _ring_name(variant):
@@ -195,7 +222,7 @@ def _ring_name_f64(layout):
     return f"clim_ring2_f32<double, 64-bit keys> (layout {layout})"
 
 
-def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, clim_finish, steps=3, parity_cells=24):
+def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, clim_finish, steps=3, parity_cells=512, cells=0):
     """One more BASELINE config on this GPU: kernel + finish, `steps` timed steps (HIP events around the ring
     kernel), parity of a few cells against the oracle.  Same synthetic generator, seeds and shapes as the
     headline leg."""
@@ -206,7 +233,7 @@ def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, c
         doy = np.tile(np.arange(1, 1461, dtype=np.int64), ps["years"][1] - ps["years"][0] + 1)
     else:
         doy = add_doy(np.arange(f"{ps['years'][0]}-01-01", f"{ps['years'][1] + 1}-01-01", dtype="datetime64[D]"))
-    T, C = int(doy.shape[0]), int(args.other_cells) or ps["cells"]
+    T, C = int(doy.shape[0]), int(cells) or int(args.other_cells) or ps["cells"]
     isz = 4 if dtype == "f32" else 8
     w, pctile, width = 5, 90, 31
     plan = Plan(doy, w, kernel=args.kernel, nchunks=args.chunks, ring2=args.ring2 if isz == 4 else None)
@@ -299,13 +326,14 @@ def run(args):
     if rank == 0 and world == 1 and not args.no_cpu:
         import parallel as opar
         pool = opar.OraclePool(doy, w)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, sq = None, None, None
     if rank == 0 and world == 1 and not args.no_pmc and not args.pmc_child:
         child_argv = ["--gpus", "1", "--config", cfg, "--dtype", args.dtype, "--kernel", args.kernel,
                       "--chunks", str(args.chunks), "--cells", str(args.cells)]
         if args.ring2 is not None:
             child_argv += ["--ring2", str(args.ring2)]
-        traffic, traffic_src = live_traffic(child_argv)
+        # (a wave runs every row of its chunk: the rows with output plus the 2w warm-up rows; one chunk unless --chunks)
+        traffic, traffic_src, sq = live_counters(child_argv, float(len(np.unique(doy))) / max(args.chunks, 1) + 2 * w)
 
     from xmhw_amd._lib import hip
     from xmhw_amd.device import DeviceBuffer, Plan, clim_finish, clim_raw, release_device_cache
@@ -436,6 +464,19 @@ def run(args):
             "algorithmic_bytes_per_launch": cells_per_launch * bytes_per_cell,
             "algorithmic_bytes_per_cell": bytes_per_cell, "cells_per_launch": cells_per_launch,
             "avg_launch_ms": ring_avg_ms,
+            # what actually binds this kernel: vector-instruction issue.  Two waves per SIMD (228 VGPRs) share one
+            # issue port; the share of the SIMD's cycles its vector ALU is busy is 2 x the per-wave share measured by
+            # SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES -- 1.0 would be the kernel's ceiling at this instruction count
+            "binding": None if sq is None else {
+                "resource": "vector-instruction issue (VALU), 2 waves per SIMD",
+                "insts_per_wave_row": {"valu": sq["valu_per_wave_row"], "salu": sq["salu_per_wave_row"],
+                                       "lds": sq["lds_per_wave_row"]},
+                "cells_per_wave": 16 if v2 in (21, 31) else 32 if v2 in (22, 32) else 8,
+                "valu_busy_of_wave_cycles": sq["valu_busy_of_wave_cycles"],
+                "wait_any_of_wave_cycles": sq["wait_any_of_wave_cycles"],
+                "frac_of_issue_peak": min(2.0 * sq["valu_busy_of_wave_cycles"], 1.0),
+                "kernel": sq["kernel"], "source": "rocprofv3 --pmc SQ_* on one step of this run's box and workload "
+                                                   "(the product kernel, no counter twin)"},
         },
         "finish_kernel_avg_launch_ms": float(np.mean(finish_ms)),
     }
@@ -466,7 +507,10 @@ def run(args):
                 one_step()
             single_ms = 1e3 * (time.perf_counter() - t1) / 2
             result["multi_gpu"]["single_rank_ms_same_workload"] = single_ms
+            # the step (kernels + whatever of the gather is not hidden behind them) and the kernels alone
             result["multi_gpu"]["speedup_vs_single_rank"] = single_ms / ms_per_step
+            result["multi_gpu"]["speedup_step_vs_single_rank"] = single_ms / ms_per_step
+            result["multi_gpu"]["speedup_kernel_only_vs_single_rank"] = single_ms / result["multi_gpu"]["kernels_ms_per_step_rank0"]
             for b_ in (f_ts, f_th, f_se, f_out):
                 b_.free()
         except Exception as e:      # noqa: BLE001 -- e.g. not enough HBM next to the shard: reported, not fatal
@@ -578,13 +622,24 @@ def run(args):
         release_device_cache()
         import oracle_fast as fast
         others = []
-        for ocfg, odt in (("0.25deg", "f64"), ("1deg", "f32"), ("0.25deg_nan", "f32"), ("0.05deg_tstep", "f32")):
+        for ocfg, odt in (("0.25deg", "f64"), ("1deg", "f32"), ("1deg", "f64"), ("0.25deg_nan", "f32"),
+                          ("0.05deg_tstep", "f32"), ("0.05deg_tstep", "f64")):
             if ocfg == cfg and odt == args.dtype:
                 continue
             try:
-                others.append(_other_config(h, np, fast, ocfg, odt, args, DeviceBuffer, Plan, clim_raw, clim_finish))
+                others.append(_other_config(h, np, fast, ocfg, odt, args, DeviceBuffer, Plan, clim_raw, clim_finish,
+                                            parity_cells=args.other_parity_cells))
             except Exception as e:      # noqa: BLE001 -- reported in the line, the headline number stands
-                others.append({"workload": PRESETS[ocfg]["name"], "dtype": odt, "error": f"{type(e).__name__}: {e}"})
+                err = f"{type(e).__name__}: {e}"
+                release_device_cache()
+                try:        # (the float64 share of configs[4] is 227 GB of buffers: half the share if that did not fit)
+                    half = PRESETS[ocfg]["cells"] // 2
+                    o = _other_config(h, np, fast, ocfg, odt, args, DeviceBuffer, Plan, clim_raw, clim_finish,
+                                      parity_cells=args.other_parity_cells, cells=half)
+                    o["note"] = f"the full share failed ({err}); half of it measured"
+                    others.append(o)
+                except Exception as e2:      # noqa: BLE001
+                    others.append({"workload": PRESETS[ocfg]["name"], "dtype": odt, "error": err, "error_half": f"{type(e2).__name__}: {e2}"})
             release_device_cache()
         result["other_configs"] = others
     if rank == 0:

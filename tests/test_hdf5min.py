@@ -90,3 +90,26 @@ def test_new_file_format_is_refused_by_name():
         f["x"]
     with pytest.raises(XmhwException, match="not an HDF5"):
         hdf5min.File(os.path.join(G, "oisst_2003_2004.npz"))
+
+
+def test_dense_attributes_and_links_of_a_file_edited_in_place():
+    """300 attributes on one dataset (fractal heap + a two-level version-2 B-tree name index), three of them deleted,
+    one rewritten longer, scale_factor rewritten with another type, a dataset unlinked and another linked -- what
+    ncatted / NCO leave behind: free-space gaps and stale messages in the heap.  Every attribute and link must come
+    back as h5py reads them (a lost scale_factor or _FillValue decodes packed data as raw counts)."""
+    import json
+    f = hdf5min.File(os.path.join(G, "hdf5", "dense_rewritten.h5"))
+    want = json.load(open(os.path.join(G, "hdf5", "dense_rewritten.json")))
+    assert sorted(f.keys()) == want["names"] and "var_07" not in f.keys() and "var_07b" in f.keys()
+    got = f["sst"].attrs
+    assert set(got) == set(want["attrs"]) and len(got) == 302
+    for k, v in want["attrs"].items():
+        g = got[k]
+        if isinstance(v, str):
+            assert g == v, k
+        else:
+            assert float(g) == v, k
+    assert got["scale_factor"].dtype == np.float64 and got["note_150"].startswith("rewritten")
+    npt.assert_array_equal(f["var_39"].read(), np.arange(40, dtype=np.float32))
+    s = ingest.open_series(os.path.join(G, "hdf5", "dense_rewritten.h5"), "sst")
+    assert s.values.decode["scale"] == 0.01 and s.values.decode["fill"] == -32768

@@ -66,3 +66,35 @@ def test_unavailable_codecs_and_layouts_are_refused_by_name(tmp_path):
         json.dump({**meta, **change}, open(meta_p, "w"))
         with pytest.raises(XmhwException, match=word):
             ingest.open_series(p, "sst")
+
+
+@pytest.mark.parametrize("dtype", ["<f4", "<f8"])
+def test_float_store_with_a_fill_value_only_in_zarray(tmp_path, dtype):
+    """what xarray's zarr v2 backend writes for a FLOAT variable with _FillValue=-999: the value is in .zarray's
+    fill_value and nowhere else; xr.open_zarr() turns it into NaN, so must the reader (land cells would
+    otherwise reach land_check as -999 data)"""
+    rng = np.random.default_rng(5)
+    T, ny, nx = 24, 4, 6
+    x = rng.normal(15, 3, size=(T, ny, nx)).astype(dtype)
+    x[:, 1, 2] = -999.0                                  # a land cell
+    x[3, 0, 0] = -999.0
+    arrays = {"sst": (("time", "lat", "lon"), x, {"_FillValue": -999.0, "units": "degC"}, (8, 4, 6)),
+              "time": (("time",), np.arange(T, dtype="<i8"), {"units": "days since 2003-01-01", "calendar": "standard"}, None)}
+    p = str(tmp_path / "f.zarr")
+    zarr2.write_store(p, arrays)
+    za = os.path.join(p, "sst", ".zattrs")
+    at = json.load(open(za))
+    del at["_FillValue"]                                 # (write_store also puts it there; xarray does not)
+    json.dump(at, open(za, "w"))
+    assert json.load(open(os.path.join(p, "sst", ".zarray")))["fill_value"] == -999.0
+    gs = ingest.open_series(p)
+    assert gs.values.decode["fill"] == -999.0 and gs.values.decode["out"] == np.dtype(dtype).name
+    got = decode_packed(gs.values)
+    want = x.copy()
+    want[x == -999.0] = np.nan
+    npt.assert_array_equal(got, want)
+    # a NaN fill value (zarr's default for floats) needs no decoding
+    meta = json.load(open(os.path.join(p, "sst", ".zarray")))
+    meta["fill_value"] = "NaN"
+    json.dump(meta, open(os.path.join(p, "sst", ".zarray"), "w"))
+    assert ingest.open_series(p).values.decode["fill"] is None if is_packed(ingest.open_series(p).values) else True

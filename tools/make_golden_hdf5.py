@@ -53,6 +53,35 @@ def main():
     with h5py.File(os.path.join(OUT, "latest_layout4.h5"), "w", libver="latest") as f:
         f.create_dataset("x", data=np.arange(24, dtype="<f4").reshape(2, 3, 4), chunks=(1, 3, 4))
         f.create_dataset("y", data=np.arange(6, dtype="<f4"))
+    # dense attributes and links (new-style object headers, fractal heap + version-2 B-tree name index), then EDITED in
+    # place as ncatted / NCO do: attributes deleted and rewritten with other sizes leave free-space gaps and stale
+    # messages in the heap, and 300 attributes make the name index two levels deep
+    import json
+    fn = os.path.join(OUT, "dense_rewritten.h5")
+    with h5py.File(fn, "w", libver=("v108", "v108")) as f:
+        d = f.create_dataset("sst", data=packed[:20].astype("<i2"), chunks=(10, 8, 4))
+        d.attrs["scale_factor"] = np.float32(0.01)
+        d.attrs["add_offset"] = np.float32(10.0)
+        d.attrs["_FillValue"] = np.int16(-32768)
+        for i in range(300):
+            d.attrs[f"note_{i:03d}"] = np.bytes_(f"attribute number {i}")
+        for i in range(40):
+            f.create_dataset(f"var_{i:02d}", data=np.arange(i + 1, dtype="<f4"))
+    with h5py.File(fn, "r+", libver=("v108", "v108")) as f:
+        d = f["sst"]
+        for i in (3, 150, 299):
+            del d.attrs[f"note_{i:03d}"]
+        d.attrs["note_150"] = np.bytes_("rewritten, and a good deal longer than the message it replaces " * 3)
+        del d.attrs["scale_factor"]
+        d.attrs["scale_factor"] = np.float64(0.01)           # (an edit that changes the type, as ncatted -a does)
+        d.attrs["history"] = np.bytes_("edited in place")
+        del f["var_07"]
+        f.create_dataset("var_07b", data=np.arange(3, dtype="<f4"))
+    with h5py.File(fn, "r") as f:
+        attrs = {}
+        for k, v in f["sst"].attrs.items():
+            attrs[k] = v.decode() if isinstance(v, bytes) else float(v)
+        json.dump({"attrs": attrs, "names": sorted(f.keys())}, open(os.path.join(OUT, "dense_rewritten.json"), "w"), indent=0, sort_keys=True)
     expected["packed"] = packed
     expected["sst"] = sst
     np.savez_compressed(os.path.join(OUT, "expected.npz"), **expected)

@@ -30,6 +30,36 @@ def _recv_exact(conn, n):
     return buf
 
 
+def _bind_address(addr):
+    """The interface rank 0 listens on.  The rendezvous address itself when it is a literal IP or plainly the
+    loopback (`localhost`, 127.x: a single-node job stays off the network); for a HOST NAME only if it resolves to
+    a non-loopback address -- Debian / Ubuntu map a machine's own name to 127.0.1.1 in /etc/hosts, and a server
+    bound there would refuse the ranks of the other nodes, which resolve the routable address -- otherwise every
+    interface."""
+    import ipaddress
+    try:
+        ipaddress.ip_address(addr)
+        return addr                                      # a literal address: exactly that interface
+    except ValueError:
+        pass
+    if addr == "localhost":
+        return "127.0.0.1"
+    try:
+        resolved = socket.gethostbyname(addr)
+        if not ipaddress.ip_address(resolved).is_loopback:
+            probe = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            try:
+                probe.bind((resolved, 0))                # an address of this host?
+                return resolved
+            except OSError:
+                pass
+            finally:
+                probe.close()
+    except OSError:
+        pass
+    return "0.0.0.0"
+
+
 def share_bytes(rank, size, make_payload, addr=None, port=None, timeout=120.0):
     """Rank 0 calls ``make_payload()`` and every rank returns those bytes."""
     if size == 1:
@@ -40,10 +70,7 @@ def share_bytes(rank, size, make_payload, addr=None, port=None, timeout=120.0):
         payload = make_payload()
         srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        try:
-            srv.bind((addr, port))                       # the rendezvous interface only
-        except OSError:
-            srv.bind(("0.0.0.0", port))                  # (addr is a name this host does not own: any interface)
+        srv.bind((_bind_address(addr), port))
         srv.listen(size)
         srv.settimeout(timeout)
         served = 0

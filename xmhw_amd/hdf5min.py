@@ -395,7 +395,7 @@ class File:
             q = p + 2 + (2 if fl & 1 else 0)
             heap = b.off(q)
             if heap != _UNDEF:
-                for pos in self._heap_objects(heap):
+                for pos in self._heap_objects(heap, b.off(q + b.osz)):
                     name, val, _ = self._attribute(pos)
                     if name is not None:
                         obj.attrs[name] = val
@@ -408,7 +408,7 @@ class File:
             q = p + 2 + (8 if fl & 1 else 0)
             heap = b.off(q)
             if heap != _UNDEF:
-                for pos in self._heap_objects(heap):
+                for pos in self._heap_objects(heap, b.off(q + b.osz)):
                     name, addr, _ = self._link(pos)
                     if name is not None:
                         obj.links[name] = addr
@@ -537,9 +537,58 @@ class File:
             q += ksz + b.osz
 
     # ---- fractal heaps (dense links / attributes): every managed object, in storage order ----------------
-    def _heap_objects(self, heap):
-        """positions of the objects of a fractal heap, found through the heap's own name index where that is one
-        leaf, otherwise by walking the direct blocks (the objects are self-describing messages)"""
+    def _btree2_records(self, addr):
+        """the records of a version-2 B-tree (raw bytes, in key order): the name index of dense attributes (record
+        type 8) or dense links (type 5)"""
+        b = self.b
+        mm = b.mm
+        if mm[addr:addr + 4] != b"BTHD":
+            raise XmhwException(f"{self.path}: bad version-2 B-tree header at {addr}")
+        rtype = mm[addr + 5]
+        node_size, rec_size, depth = b.u(addr + 6, 4), b.u(addr + 10, 2), b.u(addr + 12, 2)
+        root, nroot = b.off(addr + 16), b.u(addr + 16 + b.osz, 2)
+        if root == _UNDEF or nroot == 0:
+            return rtype, []
+        # bytes of the per-child record counts, level by level (H5B2: node_info): a leaf holds max_leaf records, an
+        # internal node of depth d as many as fit beside its child pointers
+        def enc(n):
+            return (max(n, 1).bit_length() - 1) // 8 + 1
+        max_leaf = (node_size - 10) // rec_size
+        nrec_bytes = [enc(max_leaf)]            # [d]: bytes of "records in child" for children of depth d
+        cum = [max_leaf]                        # [d]: most records a subtree of depth d can hold
+        for d in range(1, depth + 1):
+            ptr = b.osz + nrec_bytes[d - 1] + (enc(cum[d - 1]) if d > 1 else 0)
+            max_int = (node_size - 10 - ptr) // (rec_size + ptr)
+            nrec_bytes.append(enc(max_int))
+            cum.append(max_int + (max_int + 1) * cum[d - 1])
+        out = []
+
+        def node(a, n, d):
+            sig = b"BTLF" if d == 0 else b"BTIN"
+            if mm[a:a + 4] != sig:
+                raise XmhwException(f"{self.path}: bad version-2 B-tree node at {a}")
+            q = a + 6
+            recs = [bytes(mm[q + i * rec_size:q + (i + 1) * rec_size]) for i in range(n)]
+            q += n * rec_size
+            if d == 0:
+                out.extend(recs)
+                return
+            for i in range(n + 1):
+                child = b.off(q)
+                cn = b.u(q + b.osz, nrec_bytes[d - 1])
+                q += b.osz + nrec_bytes[d - 1] + (enc(cum[d - 1]) if d > 1 else 0)
+                node(child, cn, d - 1)
+                if i < n:
+                    out.append(recs[i])
+        node(root, nroot, depth)
+        return rtype, out
+
+    def _heap_objects(self, heap, index=_UNDEF):
+        """positions of the objects of a fractal heap: through the heap's name index (a version-2 B-tree whose records
+        carry the heap IDs: offset and length inside the heap's address space) where the object header names one,
+        otherwise by walking the direct blocks (the objects are self-describing messages) -- and then the number found
+        must be the number the heap says it manages: a heap with a free-space gap or a stale rewritten message (files
+        edited with ncatted / NCO / CDO) must not silently lose attributes such as scale_factor or _FillValue."""
         b = self.b
         mm = b.mm
         if mm[heap:heap + 4] != b"FRHP":
@@ -591,10 +640,37 @@ class File:
                             yield from indirect(a, sub)
             yield from indirect(root, nrows)
 
-        found = 0
+        blocks = []
         for addr, size in direct_blocks():
             if mm[addr:addr + 4] != b"FHDB":
                 raise XmhwException(f"{self.path}: bad fractal heap direct block at {addr}")
+            blocks.append((b.u(addr + 5 + b.osz, boff), size, addr))      # (offset in the heap's address space, ...)
+
+        if index != _UNDEF:
+            rtype, recs = self._btree2_records(index)
+            if rtype not in (5, 8):
+                raise XmhwException(f"{self.path}: version-2 B-tree of type {rtype} is not a name index")
+            # a managed heap ID: flags byte (version << 6 | type << 4), offset, length
+            len_bytes = min((maxdirect.bit_length() - 1) // 8 + 1, (max(max_obj, 1).bit_length() - 1) // 8 + 1)
+            for rec in recs:
+                hid = rec[:idlen] if rtype == 8 else rec[4:4 + idlen]
+                kind = (hid[0] >> 4) & 3
+                if kind != 0:
+                    raise XmhwException(f"{self.path}: {'huge' if kind == 1 else 'tiny'} fractal heap objects are not supported")
+                off = int.from_bytes(hid[1:1 + boff], "little")
+                ln = int.from_bytes(hid[1 + boff:1 + boff + len_bytes], "little")
+                for blk_off, size, addr in blocks:
+                    if blk_off <= off and off + ln <= blk_off + size:
+                        yield addr + (off - blk_off)
+                        break
+                else:
+                    raise XmhwException(f"{self.path}: fractal heap object at offset {off} is in no direct block")
+            if len(recs) != nmanaged:
+                raise XmhwException(f"{self.path}: the name index lists {len(recs)} objects, the fractal heap manages {nmanaged}")
+            return
+
+        found = 0
+        for _, size, addr in blocks:
             q, end = addr + hdr, addr + size
             while q + 8 < end and found < nmanaged:
                 ver = mm[q]
@@ -607,6 +683,9 @@ class File:
                 yield q
                 found += 1
                 q += used
+        if found != nmanaged:
+            raise XmhwException(f"{self.path}: {found} objects found in a fractal heap that manages {nmanaged} "
+                                f"(a free-space gap or a rewritten message, and no name index to go by)")
 
     def _try_len(self, q):
         """length of the message body at q: a link message starts with version 1 and a flags byte whose unused

@@ -243,8 +243,19 @@ def make_sharded_grid_compute(transport, dst=0, grid_compute=None):
         lo, hi = bounds[transport.rank]
 
         def local():
-            return inner(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile,
-                         smoothPercentileWidth, tstep, coldSpells, columns=(lo, hi), **extra)
+            res = inner(stacked, doy, anynans, pctile, windowHalfWidth, smoothPercentile,
+                        smoothPercentileWidth, tstep, coldSpells, columns=(lo, hi), **extra)
+            # the block must be as wide as the slab every rank expects from this one: checked HERE, inside the stage
+            # whose outcome all ranks agree on, so that a mismatch raises everywhere instead of leaving the others
+            # inside the gather (gather_columns' own check is local to one rank)
+            _, doys_, th_, _ = res
+            width = (th_.nbytes // (8 * 2 * doys_.shape[0]) if doys_.shape[0] else 0) if isinstance(th_, DeviceBuffer) \
+                else np.asarray(th_).shape[1]
+            if width != hi - lo:
+                if isinstance(th_, DeviceBuffer):
+                    th_.free()
+                raise XmhwException(f"rank {transport.rank}: block of {width} columns for a slab of {hi - lo}")
+            return res
 
         th_r = None
         try:
@@ -264,7 +275,12 @@ def make_sharded_grid_compute(transport, dst=0, grid_compute=None):
         if transport.rank != dst:
             return None, doys, None, None
         th, se = both[:D], both[D:]
-        keep = ~np.isnan(th).all(axis=0)
+        # the surviving cells, read off the gathered blocks: a dropped cell is NaN in every row of thresh AND seas.
+        # (A kept cell can have an all-NaN thresh column -- pools that hold both +inf and -inf interpolate to NaN --
+        # so thresh alone would drop its coordinate line on the root and the N-rank grid would differ from the 1-rank
+        # one; seas of such a cell is NaN as well only if EVERY pool of the year holds both infinities, which a series
+        # with a finite sample somewhere in every 11-day window cannot.)
+        keep = ~(np.isnan(th).all(axis=0) & np.isnan(se).all(axis=0))
         return keep, doys, th, se
 
     return sharded

@@ -112,8 +112,15 @@ def open_series(store, varname=None, tdim=None):
         raise XmhwException(f"{store}: {varname} must have {tdim!r} as its first (slowest) dimension, has {dims}")
     at = dict(var.attrs)
     at.pop("_ARRAY_DIMENSIONS", None)
-    if "_FillValue" not in at and var.dtype.kind == "i" and var.fill_value is not None:
-        at["_FillValue"] = var.fill_value              # xarray writes the CF fill value into .zarray for packed data
+    if "_FillValue" not in at and var.fill_value is not None:
+        # xarray's zarr v2 backend keeps the CF fill value of EVERY dtype in .zarray's fill_value (a float store
+        # written with _FillValue=-999 has it nowhere else): land cells must reach the device as NaN, not as -999.
+        # A NaN fill value needs no decoding.
+        fv = var.fill_value
+        if isinstance(fv, str):                         # zarr's JSON spelling of the non-finite floats
+            fv = {"NaN": float("nan"), "Infinity": float("inf"), "-Infinity": float("-inf")}.get(fv)
+        if fv is not None and not (isinstance(fv, float) and fv != fv):
+            at["_FillValue"] = fv
     for k in ("scale_factor", "add_offset"):
         # JSON has one float type: the packing attributes of a zarr store are float64 unless the store says otherwise
         if k in at and not isinstance(at[k], float):
