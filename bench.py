@@ -245,16 +245,31 @@ def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, c
         th, se = DeviceBuffer(8 * D * C), DeviceBuffer(8 * D * C)
         out = DeviceBuffer(8 * 2 * D * C)
         bufs += [th, se, out]
-        e0, e1 = h.event_create(), h.event_create()
+        # One launch per step.  (Cutting a step into slabs of cells with the memory-bound finish kernel of a slab on a
+        # second stream beside the ring kernel of the next one was measured in round 4 and LOSES: the 6-hourly share
+        # 93.7 -> 103.5 ms per step at 4 slabs -- the ring launches sum to 101.1 ms against 86.3 for one, four tails
+        # and a neighbour that takes CU slots and HBM -- and the headline 57.3 -> 57.4 / 59.8 ms at 2 / 4 slabs:
+        # profiles/r4_micro_experiments.txt.  `nslab` is kept for that experiment.)
+        nslab = int(os.environ.get("XMHW_BENCH_OTHER_SLABS", "1"))
+        edges = [C * i // nslab for i in range(nslab + 1)]
+        fin = h.stream_create() if nslab > 1 else 0
+        evs = [(h.event_create(), h.event_create()) for _ in range(nslab)]
         ring_ms = []
 
         def step():
-            h.event_record(e0, 0)
-            clim_raw(plan, ts, isz, C, pctile / 100.0, False, th, se)
-            h.event_record(e1, 0)
-            clim_finish(plan, th, se, C, not tstep, True, width, out.ptr, out.ptr + 8 * D * C)
+            for i in range(nslab):
+                a, n = edges[i], edges[i + 1] - edges[i]
+                h.event_record(evs[i][0], 0)
+                clim_raw(plan, ts.ptr + isz * a, isz, n, pctile / 100.0, False, th.ptr + 8 * a, se.ptr + 8 * a, ld=C, ldo=C)
+                h.event_record(evs[i][1], 0)
+                if nslab > 1:
+                    h.stream_wait_event(fin, evs[i][1])
+                clim_finish(plan, th.ptr + 8 * a, se.ptr + 8 * a, n, not tstep, True, width, out.ptr + 8 * a,
+                            out.ptr + 8 * D * C + 8 * a, ldo=C, stream=fin)
             h.stream_sync(0)
-            return h.event_elapsed_ms(e0, e1)
+            if nslab > 1:
+                h.stream_sync(fin)
+            return sum(h.event_elapsed_ms(e0_, e1_) for e0_, e1_ in evs)
         step()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -281,6 +296,7 @@ def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, c
         ring_avg = float(np.mean(ring_ms))
         return {"workload": f"{ps['name']}: {C} cells, T={T}, D={D}, nan_frac={ps['nan']}", "dtype": f"{dtype} in / f64 out",
                 "ms_per_step": ms, "cells_per_s": C / (ms * 1e-3), "kernel": kname, "kernel_avg_launch_ms": ring_avg,
+                "slabs": nslab, "finish": "second stream, beside the next slab's ring kernel" if nslab > 1 else "same stream",
                 "algorithmic_bytes_per_cell": bpc, "roofline_frac": C * bpc / (ring_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "parity_cells": int(idx.size), "parity_max_rel_err": err, "parity_ok": bool(err < 1e-6)}
     finally:

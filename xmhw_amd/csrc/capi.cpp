@@ -171,7 +171,16 @@ int32_t auto_chunks(const xmhw_plan* p, int64_t C) {
     {
         // the third-generation kernel runs two waves per SIMD (2,048 at a time) of 16 or 8 cells: twice that many
         // waves in all is enough, and every further chunk costs its warm-up rows (1 degree grid, 64,800 cells: 3.67 ms
-        // with 1 or 2 chunks, 3.87 with 3, 4.16 with 6)
+        // with 1 or 2 chunks, 3.87 with 3, 4.16 with 6).
+        // The model behind it (round 4): a workgroup is 2 waves, a CU holds 4, the chip 1,024 at a time.  With n chunks
+        // a grid is W = n * ceil(C / 32) workgroups of (D / n + 2w) rows each and runs in about
+        // ceil(W / 1024) * (D / n + 2w) row-times.  The 1 degree grid (2,025 workgroups per chunk, D = 366): n = 1
+        // -> 2 rounds x 376 = 752; n = 2 -> 4 x 193 = 772; n = 3 -> 6 x 132 = 792; n = 6 -> 12 x 71 = 852 --
+        // the measured order.  One or two chunks fill the last round to 99 %: there is no tail to remove, and what
+        // keeps this grid at 11 % of the roofline against 15 % for the 40-year one is the record, not the grid:
+        // 30 tracks pad to 32 (6 % idle ring slots) and the per-row costs that do not depend on the number of
+        // tracks (walk, sort, epilogue, row overhead: ~40 % of a row) are spread over 120 bytes of samples per
+        // cell-row instead of 160.
         const int32_t v = ring2_resolved(p);
         if (v >= 20) {
             const int64_t cpw = 64 / xmhw::ring2_subs(v);
