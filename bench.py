@@ -209,7 +209,7 @@ def live_counters(argv, rows_per_wave):
 
 
 def _ring_name(variant):
-    """the kernel a float32 plan runs on, by its layout number (include/xmhw_amd.h: xmhw_plan_set_ring2)"""
+    """the kernel a float32 plan runs on, by its layout number (include/xmhw_amd.h: XMHW_LAYOUT_*)"""
     if variant >= 20:
         return f"clim_ring3_f32 ({ {20: 8, 21: 4, 22: 2}.get(variant, 8) } lanes per cell, layout {variant})"
     return f"clim_ring2_f32 (layout {variant})"
@@ -218,7 +218,7 @@ def _ring_name(variant):
 def _ring_name_f64(layout):
     """the kernel genuinely float64 samples run on (64-bit keys as high / low words), by its layout number"""
     if layout >= 20:
-        return f"clim_ring3_f32<double, 64-bit keys> (8 lanes per cell, layout {layout})"
+        return f"clim_ring3_f32<double, 64-bit keys> ({ {20: 8, 21: 4}.get(layout, 8) } lanes per cell, layout {layout})"
     return f"clim_ring2_f32<double, 64-bit keys> (layout {layout})"
 
 
