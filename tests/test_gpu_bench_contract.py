@@ -24,8 +24,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert k in d, k
     # SURVEY 8(d) "report both f32 and f64" + the other BASELINE configs ride the same line
     oc = d["other_configs"]
-    assert len(oc) == 4 and all("error" not in o for o in oc), oc
-    assert sum(o["dtype"].startswith("f64") for o in oc) == 1
+    # (round 4: six of them -- float64 legs of configs[1] and of the configs[4] share too -- each with its own parity sample)
+    assert len(oc) == 6 and all("error" not in o for o in oc), oc
+    assert sum(o["dtype"].startswith("f64") for o in oc) == 3
+    assert all(o["parity_cells"] >= 16 for o in oc)
     assert all(o["parity_ok"] and o["roofline_frac"] > 0 and o["ms_per_step"] > 0 for o in oc), oc
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["unit"] == "cells/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
@@ -35,6 +37,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # the resource that actually binds the kernel rides next to the HBM fraction (null only without rocprofv3)
+    assert "binding" in r
+    if r["binding"] is not None:
+        b = r["binding"]
+        assert 0.0 < b["frac_of_issue_peak"] <= 1.0 and b["insts_per_wave_row"]["valu"] > 100
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):

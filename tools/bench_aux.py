@@ -1,6 +1,6 @@
 """Timing of the HBM-bound kernels around the ring kernel on one MI355X, each against its ALGORITHMIC
 bytes (what the operation has to read and write once): land_mask, gather_cells, decode (float32 swap,
-int16 unpack), pad_gaps, clim_finish (tiled and untiled), block_time.  One JSON line per kernel:
+int16 unpack), pad_gaps, clim_finish_stream<31, 31> (what width 31 runs on: D = 366 and D = 1460), block_time.  One JSON line per kernel:
 
     python tools/bench_aux.py [--cells 259200] > profiles/r2_aux_kernels.jsonl
     rocprofv3 --kernel-trace --stats --output-format csv -d OUT -- python3 tools/bench_aux.py
@@ -92,8 +92,8 @@ def main():
     line("pad_gaps<float>", 4 * T * C, ms, "interpolate_na(max_gap = 5 days), series read once (already filled after the first pass)")
     d_x.free()
 
-    # clim_finish (tiled: D = 366; untiled: D = 1460): two (D, C) float64 arrays in, two out
-    for label, dd in (("clim_finish_tiled<16> (D = 366)", doy), ("clim_finish (D = 1460)", np.tile(np.arange(1, 1461), 4))):
+    # clim_finish_stream<31, 31> (the default smoothing width; D = 366 and D = 1460): two (D, C) float64 arrays in, two out
+    for label, dd in (("clim_finish_stream<31, 31> (D = 366)", doy), ("clim_finish_stream<31, 31> (D = 1460)", np.tile(np.arange(1, 1461), 4))):
         plan = dev.Plan(dd, 5)
         D = plan.D
         a, b, c_, d_ = (B(8 * D * C) for _ in range(4))
