@@ -349,7 +349,11 @@ def run(args):
         if args.ring2 is not None:
             child_argv += ["--ring2", str(args.ring2)]
         # (a wave runs every row of its chunk: the rows with output plus the 2w warm-up rows; one chunk unless --chunks)
-        traffic, traffic_src, sq = live_counters(child_argv, float(len(np.unique(doy))) / max(args.chunks, 1) + 2 * w)
+        from xmhw_amd.device import Plan as _Plan
+        _p = _Plan(doy, w, kernel=args.kernel, nchunks=args.chunks, ring2=args.ring2)      # (host side only: no GPU touched)
+        _nch = _p.chunks_in_use(int(args.cells) or ps["cells"])
+        _p.destroy()
+        traffic, traffic_src, sq = live_counters(child_argv, float(len(np.unique(doy))) / max(_nch, 1) + 2 * w)
 
     from xmhw_amd._lib import hip
     from xmhw_amd.device import DeviceBuffer, Plan, clim_finish, clim_raw, release_device_cache

@@ -133,6 +133,9 @@ int xmhw_plan_set_kernel(xmhw_plan *plan, int32_t kernel);  /* tests / fallback 
 int xmhw_plan_set_narrowing(xmhw_plan *plan, int32_t enable);
 int xmhw_plan_narrowed(xmhw_plan *plan, int32_t *narrowed_out);
 int xmhw_plan_set_chunks(xmhw_plan *plan, int32_t nchunks); /* 0 = auto         */
+/* how many chunks of the doy axis a launch over C cells is cut into (the automatic choice or the forced one):
+ * every workgroup walks D / nchunks rows with output + 2w warm-up rows (csrc/capi.cpp: auto_chunks)     */
+int xmhw_plan_chunks_in_use(const xmhw_plan *plan, int64_t C, int32_t *nchunks);
 /* host copy of the ring kernel's step table for inspection:
  * table[nsteps][ntracks_padded] (see csrc/plan.h for the encoding)            */
 int xmhw_plan_table(const xmhw_plan *plan, int32_t years_per_lane, uint32_t *table_out,

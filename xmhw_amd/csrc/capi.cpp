@@ -1103,6 +1103,12 @@ int xmhw_plan_set_chunks(xmhw_plan* plan, int32_t nchunks) {
     plan->host.nchunks_req = nchunks;
     return XMHW_OK;
 }
+int xmhw_plan_chunks_in_use(const xmhw_plan* plan, int64_t C, int32_t* nchunks) {
+    if (!plan || !nchunks) return fail(XMHW_ERR_INVALID, "NULL argument");
+    if (C < 0) return fail(XMHW_ERR_INVALID, "bad C");
+    *nchunks = auto_chunks(plan, std::max<int64_t>(C, 1));
+    return XMHW_OK;
+}
 int xmhw_debug_stats_available(void) { return xmhw::ring_stats_built() ? 1 : 0; }
 int xmhw_plan_debug_stats_n(xmhw_plan* plan, int enable, uint64_t* out, int32_t n) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");

@@ -141,6 +141,7 @@ PYBIND11_MODULE(_xmhw_hip, m) {
         check(xmhw_plan_debug_stats_n(pp(p), enable, read ? out.mutable_data() : nullptr, 16));
         return out;
     });
+    m.def("plan_chunks_in_use", [](uintptr_t p, int64_t C) { int32_t v = 0; check(xmhw_plan_chunks_in_use(pp(p), C, &v)); return v; });
     m.def("debug_stats_available", []() { return xmhw_debug_stats_available() != 0; });
     m.def("plan_set_layout", [](uintptr_t p, int layout) { check(xmhw_plan_set_layout(pp(p), layout)); });
     m.def("plan_layout_in_use", [](uintptr_t p) { int32_t v = -1; check(xmhw_plan_layout_in_use(pp(p), &v)); return v; });

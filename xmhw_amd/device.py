@@ -210,6 +210,10 @@ class Plan:
 
     ring2_in_use = layout_in_use        # deprecated name (rounds 2-3)
 
+    def chunks_in_use(self, C):
+        """chunks of the doy axis a launch over C cells is cut into (every workgroup walks D / chunks + 2w rows)"""
+        return int(self._h.plan_chunks_in_use(self.handle, int(C)))
+
     def f64_mode(self):
         """layout variant of the 64-bit mode float64 samples will run on (-1: generic kernel)"""
         return int(self._h.plan_f64_mode(self.handle))
