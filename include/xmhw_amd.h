@@ -167,7 +167,8 @@ int xmhw_plan_debug_stats(xmhw_plan *plan, int enable, uint64_t *out8);
  * The environment variable XMHW_RING2 sets the default of new plans (the same numbers).        */
 enum {
     XMHW_LAYOUT_AUTO = -2,
-    XMHW_LAYOUT_RING1 = -1,          /* round-1 kernel (csrc/kernels_ring.hip): other windows, > 96 or < 9 tracks */
+    XMHW_LAYOUT_RING1 = -1,          /* round-1 kernel (csrc/kernels_ring.hip): other windows, > 96 or < 9 tracks;
+                                      * forced on 9..96 tracks at w = 5 it runs on its 32-lane entries, padded   */
     XMHW_LAYOUT_RING2_8LANE = 8,     /* second generation, lists merged into the cell's 8 nearest keys */
     XMHW_LAYOUT_RING2_4LANE = 10,    /* second generation, 4 lanes per cell, 7 merged keys */
     XMHW_LAYOUT_RING2_16LANE = 12,   /* second generation, 16 lanes per cell: 49..96 tracks */

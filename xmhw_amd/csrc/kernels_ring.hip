@@ -584,9 +584,10 @@ struct RingEntry { int w, yps, subs; RingKernel fn; RingKernelN fn_narrow; };
 // (window half width, tracks per lane, lanes per cell); the ring holds YPS * (2w+1) keys per lane
 // (<= 66 VGPRs), so wide windows trade tracks per lane for lanes per cell
 const RingEntry kRing[] = {
-    // the default window: 8 lanes per cell up to 48 tracks, 16 lanes up to 96
-    XMHW_RK(5, 1, 8), XMHW_RK(5, 2, 8), XMHW_RK(5, 3, 8), XMHW_RK(5, 4, 8), XMHW_RK(5, 5, 8), XMHW_RK(5, 6, 8),
-    XMHW_RK(5, 4, 16), XMHW_RK(5, 5, 16), XMHW_RK(5, 6, 16),
+    // the default window: records of up to 8 tracks on 8 lanes per cell.  (Round 4: the 8- and 16-lane entries for 9..96
+    // tracks are gone -- the third- and second-generation kernels serve those records; a plan that is forced onto this
+    // kernel there, XMHW_LAYOUT_RING1, runs on the 32-lane entries below, padded.)
+    XMHW_RK(5, 1, 8),
     // very long records (e.g. 165-year model runs): 32 lanes per cell, up to 192 tracks
     XMHW_RK(5, 4, 32), XMHW_RK(5, 5, 32), XMHW_RK(5, 6, 32),
     // narrower windows (pentad / coarse-step data)
