@@ -59,7 +59,8 @@ namespace {
 // buckets costs the fourth workgroup (70.7 ms).
 template <int SUBS> struct Cfg3;
 template <> struct Cfg3<4> {   // 16 cells per wave
-    static constexpr int NB = 216, CAP = 8, LW = 24, JM = 7, PS = 16, EDGE_LO = 20, EDGE_HI = 36;
+    // (round 4: 200 buckets instead of 216 pay for the per-cell ring of row sums, 11 float64 per cell -- kRowSum below)
+    static constexpr int NB = 200, CAP = 8, LW = 24, JM = 7, PS = 16, EDGE_LO = 20, EDGE_HI = 36;
 };
 // 2 lanes: 32 cells per wave, a workgroup is ONE wave (32 float32 cells = one 128-byte line): 32 * (NB + 1) + 64 * LW
 // words = 19.6 KB, eight of them per CU.  Records of up to 24 tracks (264 pooled keys: 120 buckets cover them all).
@@ -136,7 +137,15 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
     constexpr int32_t M16_TARGET = PS * 5, M16_HI_TRIG = PS * 11, M16_LO_TRIG = PS * 5 / 2, M16_HI_ADJ = PS * 15 / 2,
                       M16_LO_ADJ = PS * 7 / 2;
 
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kWaves3 * CPWAVE * HS + 64 * kWaves3 * LWL];
+    // Row sums (4 lanes per cell, float32 keys): the cell's sum of the values in ring slot k, for every slot, as float64 in
+    // LDS.  A row then adds (sum of the pushed samples) - (row sum of the slot it overwrites) to the cell's running total:
+    // the evicted samples are not converted and summed again (10 x (key -> float, cvt, add) per lane and row: 45 vector
+    // instructions, 20 of them float64), and the total is the cell's, not the lane's.
+    constexpr bool kRowSum = SUBS == 4 && !X64;
+    constexpr int RSW = kRowSum ? 2 * R : 0;     // words per cell
+    constexpr int kRsBase = kWaves3 * CPWAVE * HS + 64 * kWaves3 * LWL;
+    static_assert(!kRowSum || kRsBase % 2 == 0, "row sums are 8-byte aligned");
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kRsBase + kWaves3 * CPWAVE * RSW];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -177,8 +186,14 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
         if constexpr (X64) return value_of_key64_3(opaque3(ring[y][k]), opaque3(ringlo[y][k]));
         else return value_of_key3(opaque3(ring[y][k]));
     };
-    double lsum = 0.0;
+    double lsum = 0.0;       // (kRowSum: the CELL's running total, uniform over its lanes)
     uint32_t nval = 0;
+    double* const rowsum = reinterpret_cast<double*>(lds + kRsBase) + (kRowSum ? (wave * CPWAVE + cw) * R : 0);
+    if constexpr (kRowSum) {
+#pragma unroll
+        for (int k = sub; k < R; k += SUBS) rowsum[k] = 0.0;     // the rings start invalid: every value is 0
+    }
+    bool rs_stale = false;   // the row sums no longer describe the slots (a held track was rotated): re-sum
 
     uint32_t tix[YPS];
     const uint32_t last_step = padded_last ? 0u : 1u;
@@ -365,6 +380,34 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
         uint32_t dF = 0;
 #pragma unroll
         for (int y = 0; y < YPS; ++y) dF += (kin[y] <= pc ? 1u : 0u) - (kout[y] <= pc ? 1u : 0u);
+        if constexpr (kRowSum) {
+            // the sum of what this lane pushes (an invalid key counts 0; a held track pushes the key it evicts) ...
+            double din;
+            if (fast) {
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) {
+                    uint32_t bi = __float_as_uint(x_raw[y]);
+                    if (y == YPS - 1) bi &= ~padmask;
+                    const double di = static_cast<double>(__uint_as_float(bi));
+                    din = y == 0 ? di : din + di;
+                }
+                din = negate ? -din : din;
+            } else {
+                din = 0.0;
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) {
+                    din += value_of_key3(kin[y]);
+                    nval += (kin[y] != kInv3 ? 1u : 0u) - (kout[y] != kInv3 ? 1u : 0u);
+                }
+                rotate = wave_hold;
+                clean = !__any(nval != full_valid);
+            }
+            // ... replaces the cell's row sum of slot m
+            const double cell_in = csum<SUBS>(din);
+            const double cell_out = rowsum[m];
+            rowsum[m] = cell_in;
+            lsum += cell_in - cell_out;
+        } else
         if (fast) {
             // (the pushed samples are summed as they are, the sum changes sign for cold spells: one instruction
             // instead of one per sample)
@@ -422,7 +465,8 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
             double total;
             if (wallc) {
                 n = csum<SUBS>(nval);
-                total = csum<SUBS>(lsum);
+                if constexpr (kRowSum) total = lsum;
+                else total = csum<SUBS>(lsum);
             } else {
                 uint32_t nl = 0;
                 double tl = 0.0;
@@ -453,8 +497,25 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
                     t += ty;
                     tl += ((cmask >> y) & 1u) ? ty : 0.0;
                 }
+                if constexpr (kRowSum) {
+                    // (a non-finite total: an infinity in the ring, or one that has just left it -- the cell's total and
+                    // its row sums are taken from the rings again)
+                    double tc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int y = 0; y < YPS; ++y) v = opaque3d(v + val_at(y, k));
+                        v = csum<SUBS>(v);
+                        rowsum[k] = v;
+                        tc += v;
+                    }
+                    lsum = tc;
+                    total = wallc ? tc : csum<SUBS>(tl);
+                } else {
                 lsum = t;
                 total = csum<SUBS>(tl);
+                }
             }
             Fc += csum<SUBS>(dF);
 
@@ -1051,6 +1112,7 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
         sf_cur = sf_nxt;
         sf_nxt = sf_nn;
     }
+    if (rotate) rs_stale = true;
     if (rotate) {
 #pragma unroll
         for (int y = 0; y < YPS; ++y) {
@@ -1079,6 +1141,24 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
                 ring_sel3(l0, lastl, hy);
                 ringlo[y][0] = l0;
             }
+        }
+    }
+    if constexpr (kRowSum) {
+        if (rs_stale) {
+            // the held tracks' keys have moved one slot up: the row sums (and, from them, the total) are taken from the
+            // rings again
+            double tc = 0.0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                double v = 0.0;
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) v = opaque3d(v + val_at(y, k));
+                v = csum<SUBS>(v);
+                rowsum[k] = v;
+                tc += v;
+            }
+            lsum = tc;
+            rs_stale = false;
         }
     }
     }
