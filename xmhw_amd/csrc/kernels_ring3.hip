@@ -67,7 +67,8 @@ template <> struct Cfg3<4> {   // 16 cells per wave
 template <> struct Cfg3<2> {
     // (bands three quarters as populous as on 4 lanes -- PS = 12 -- because a lane holds half of a cell's band and sorts
     // at most 8 keys: 6-hourly share of 405,000 cells 56.9 ms at PS = 16, 48.1 at 12, 49.8 at 11, 56.7 at 10)
-    static constexpr int NB = 120, CAP = 8, LW = 16, JM = 7, PS = 12, EDGE_LO = 14, EDGE_HI = 22;
+    // (round 4: 96 buckets instead of 120 pay for the ring of row sums: eight workgroups per CU still fit)
+    static constexpr int NB = 96, CAP = 8, LW = 16, JM = 7, PS = 12, EDGE_LO = 14, EDGE_HI = 22;
 };
 template <> struct Cfg3<8> {   // 8 cells per wave
     // (208 buckets and lists of 20 entries instead of 128 / 16: float64 configs[2] 103.8 -> 97.7 ms, fewer window
@@ -137,11 +138,11 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
     constexpr int32_t M16_TARGET = PS * 5, M16_HI_TRIG = PS * 11, M16_LO_TRIG = PS * 5 / 2, M16_HI_ADJ = PS * 15 / 2,
                       M16_LO_ADJ = PS * 7 / 2;
 
-    // Row sums (4 lanes per cell, float32 keys): the cell's sum of the values in ring slot k, for every slot, as float64 in
+    // Row sums (float32 keys, every lane layout): the cell's sum of the values in ring slot k, for every slot, as float64 in
     // LDS.  A row then adds (sum of the pushed samples) - (row sum of the slot it overwrites) to the cell's running total:
     // the evicted samples are not converted and summed again (10 x (key -> float, cvt, add) per lane and row: 45 vector
     // instructions, 20 of them float64), and the total is the cell's, not the lane's.
-    constexpr bool kRowSum = SUBS == 4 && !X64;
+    constexpr bool kRowSum = !X64;
     constexpr int RSW = kRowSum ? 2 * R : 0;     // words per cell
     constexpr int kRsBase = kWaves3 * CPWAVE * HS + 64 * kWaves3 * LWL;
     static_assert(!kRowSum || kRsBase % 2 == 0, "row sums are 8-byte aligned");
