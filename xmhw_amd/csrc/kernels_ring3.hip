@@ -138,11 +138,11 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
     constexpr int32_t M16_TARGET = PS * 5, M16_HI_TRIG = PS * 11, M16_LO_TRIG = PS * 5 / 2, M16_HI_ADJ = PS * 15 / 2,
                       M16_LO_ADJ = PS * 7 / 2;
 
-    // Row sums (float32 keys, every lane layout): the cell's sum of the values in ring slot k, for every slot, as float64 in
+    // Row sums (every layout, float32 keys and the 64-bit mode): the cell's sum of the values in ring slot k, for every slot, as float64 in
     // LDS.  A row then adds (sum of the pushed samples) - (row sum of the slot it overwrites) to the cell's running total:
     // the evicted samples are not converted and summed again (10 x (key -> float, cvt, add) per lane and row: 45 vector
     // instructions, 20 of them float64), and the total is the cell's, not the lane's.
-    constexpr bool kRowSum = !X64;
+    constexpr bool kRowSum = true;
     constexpr int RSW = kRowSum ? 2 * R : 0;     // words per cell
     constexpr int kRsBase = kWaves3 * CPWAVE * HS + 64 * kWaves3 * LWL;
     static_assert(!kRowSum || kRsBase % 2 == 0, "row sums are 8-byte aligned");
@@ -387,17 +387,24 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
             if (fast) {
 #pragma unroll
                 for (int y = 0; y < YPS; ++y) {
-                    uint32_t bi = __float_as_uint(x_raw[y]);
-                    if (y == YPS - 1) bi &= ~padmask;
-                    const double di = static_cast<double>(__uint_as_float(bi));
+                    double di;
+                    if constexpr (X64) {
+                        // (from the key words: the samples themselves are not kept; a padded track's key is invalid = 0)
+                        di = value_of_key64_3(kin[y], kin_lo[y]);
+                    } else {
+                        uint32_t bi = __float_as_uint(x_raw[y]);
+                        if (y == YPS - 1) bi &= ~padmask;
+                        di = static_cast<double>(__uint_as_float(bi));
+                    }
                     din = y == 0 ? di : din + di;
                 }
-                din = negate ? -din : din;
+                din = (negate && !X64) ? -din : din;
             } else {
                 din = 0.0;
 #pragma unroll
                 for (int y = 0; y < YPS; ++y) {
-                    din += value_of_key3(kin[y]);
+                    if constexpr (X64) din += value_of_key64_3(kin[y], kin_lo[y]);
+                    else din += value_of_key3(kin[y]);
                     nval += (kin[y] != kInv3 ? 1u : 0u) - (kout[y] != kInv3 ? 1u : 0u);
                 }
                 rotate = wave_hold;
