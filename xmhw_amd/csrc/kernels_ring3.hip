@@ -1118,8 +1118,23 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
                 const uint32_t An = can ? tag_of(alo) : 0u;
                 const uint32_t pn = hbase + (An << hshift) - 1u;
                 const bool okA = can && An >= 1u && An + 16u < static_cast<uint32_t>(NB);
-                const uint32_t Fn = count_le(okA ? pn : 0u);
-                if constexpr (STATS) ++st_count;
+                // The count of keys at or below the new pivot.  A cell the band path settled on this row has it without a
+                // pass over its keys (round 4): its window is centred on the answer, so the pivot is alo - 1; Fc counts
+                // the keys below the band and the band's keys are still in the lanes' lists.
+                const bool shortc = !X64 && band_done && okA && pn == alo - 1u;
+                uint32_t Fn;
+                if (__all(shortc || !okA)) {
+                    uint32_t below = 0;
+#pragma unroll
+                    for (int i = 0; i < CAP; i += 4) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(list + i);
+                        below += (v.x < alo ? 1u : 0u) + (v.y < alo ? 1u : 0u) + (v.z < alo ? 1u : 0u) + (v.w < alo ? 1u : 0u);
+                    }
+                    Fn = Fc + csum<SUBS>(below);
+                } else {
+                    Fn = count_le(okA ? pn : 0u);
+                    if constexpr (STATS) ++st_count;
+                }
                 if (okA) {
                     A = An;
                     pc = pn;
