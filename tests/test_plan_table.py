@@ -150,6 +150,13 @@ def test_ring2_layout_choice():
     assert Plan(t40, 5, layout="ring3_2lane").layout_in_use() == -1      # 40 tracks do not fit 2 lanes per cell
     with pytest.raises(Exception):
         Plan(t40, 5, layout=14)
+    # xmhw_plan_chunks_in_use: the automatic cut of the doy axis (csrc/capi.cpp: auto_chunks) -- one chunk for the
+    # 0.25 degree grid, two for the 1 degree grid, more for small batches; a forced count wins
+    p = Plan(t40, 5)
+    assert p.chunks_in_use(1036800) == 1 and p.chunks_in_use(64800) == 2 and p.chunks_in_use(20000) == 4
+    assert Plan(t40, 5, nchunks=3).chunks_in_use(1036800) == 3
+    from xmhw_amd._lib import hip
+    assert hip().debug_stats_available() in (False, True)        # (False in the product build: no counter twins)
 
 
 def test_bad_arguments():
