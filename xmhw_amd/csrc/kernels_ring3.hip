@@ -196,30 +196,45 @@ __global__ __launch_bounds__(64 * waves3(SUBS, X64 ? 8 : 4), 2) void clim_ring3_
     }
     bool rs_stale = false;   // the row sums no longer describe the slots (a held track was rotated): re-sum
 
-    uint32_t tix[YPS];
+    // The address of every track's next sample.  kPtr (float32 input, up to 11 tracks per lane -- where 10 more registers do
+    // not spill): a 64-bit pointer per track; a row that follows its predecessor adds the row stride, two full-rate
+    // additions instead of one v_mad_u64_u32 (configs[2] 53.0 -> 52.4 ms).  Otherwise a 32-bit time index per track and one
+    // v_mad_u64_u32 per load (12 tracks per lane: 31.1 -> 33.3 ms with the pointers, they spill).
+    constexpr bool kPtr = !X64 && sizeof(TI) == 4 && YPS <= 11;
+    const char* ap[kPtr ? YPS : 1];
+    uint32_t tix[kPtr ? 1 : YPS];
     const uint32_t last_step = padded_last ? 0u : 1u;
     auto entries_of = [&](int32_t step, uint32_t (&e)[YPS]) {
         const uint32_t* p = tab + static_cast<int64_t>(step - step_min) * NTP;
 #pragma unroll
         for (int y = 0; y < YPS; ++y) e[y] = p[y * SUBS];
     };
+    // (the row stride in BYTES as a 32-bit number -- the launcher refuses ld >= 2^30 -- so that a sample address is ONE
+    // v_mad_u64_u32 with the column pointer as its addend)
+    const uint32_t ld4 = static_cast<uint32_t>(ld) * static_cast<uint32_t>(sizeof(TI));
     auto point_at = [&](int32_t step) {
         uint32_t e[YPS];
         entries_of(step, e);
 #pragma unroll
-        for (int y = 0; y < YPS; ++y) tix[y] = minu3((e[y] >> 1) - 2u, tmax);
+        for (int y = 0; y < YPS; ++y) {
+            const uint32_t t = minu3((e[y] >> 1) - 2u, tmax);
+            if constexpr (kPtr) ap[y] = reinterpret_cast<const char*>(col) + static_cast<uint64_t>(t) * ld4;
+            else tix[y] = t;
+        }
     };
     auto advance = [&]() {
 #pragma unroll
-        for (int y = 0; y < YPS; ++y) tix[y] += (y == YPS - 1) ? last_step : 1u;
+        for (int y = 0; y < YPS; ++y) {
+            if constexpr (kPtr) ap[y] += (y == YPS - 1) ? static_cast<uint64_t>(last_step * ld4) : static_cast<uint64_t>(ld4);
+            else tix[y] += (y == YPS - 1) ? last_step : 1u;
+        }
     };
-    // (the row stride in BYTES as a 32-bit number -- the launcher refuses ld >= 2^30 -- so that a sample address is ONE
-    // v_mad_u64_u32 with the column pointer as its addend)
-    const uint32_t ld4 = static_cast<uint32_t>(ld) * static_cast<uint32_t>(sizeof(TI));
     auto request = [&](TI (&x)[YPS]) {
 #pragma unroll
-        for (int y = 0; y < YPS; ++y)
-            x[y] = *reinterpret_cast<const TI*>(reinterpret_cast<const char*>(col) + static_cast<uint64_t>(tix[y]) * ld4);
+        for (int y = 0; y < YPS; ++y) {
+            if constexpr (kPtr) x[y] = *reinterpret_cast<const TI*>(ap[y]);
+            else x[y] = *reinterpret_cast<const TI*>(reinterpret_cast<const char*>(col) + static_cast<uint64_t>(tix[y]) * ld4);
+        }
     };
 
     TI x_in[YPS];           // the samples as requested (one row ahead)
