@@ -174,7 +174,12 @@ enum {
     XMHW_LAYOUT_RING2_16LANE = 12,   /* second generation, 16 lanes per cell: 49..96 tracks */
     XMHW_LAYOUT_RING3_8LANE = 20,    /* third generation, 8 cells per wave */
     XMHW_LAYOUT_RING3_4LANE = 21,    /* third generation, 16 cells per wave: the headline layout (40 tracks) */
-    XMHW_LAYOUT_RING3_2LANE = 22     /* third generation, 32 cells per wave */
+    XMHW_LAYOUT_RING3_2LANE = 22,    /* third generation, 32 cells per wave */
+    XMHW_LAYOUT_SORTED = 40          /* round 5 (csrc/kernels_sorted.hip): sorted row-lists in LDS + a pointer walk, 32
+                                        cells per wave, on the rows that pool every track at every step; the other
+                                        rows (around doy 60, around the ends of partial years) on the automatic ring
+                                        layout; cell-rows whose lists are too short on the generic kernel.  float32,
+                                        w = 5, quantiles >= 0.75 */
 };
 int xmhw_plan_set_layout(xmhw_plan *plan, int32_t layout);
 /* the layout float32 input of this plan will run on (XMHW_LAYOUT_RING1 if the round-1 / generic kernel) */

@@ -1,0 +1,199 @@
+"""Sorted-list kernel (kernels_sorted.hip, XMHW_LAYOUT_SORTED = 40): the K largest keys of every row-list sorted in
+LDS, a pointer per list, a walk of the pointers per row.  It serves the regular rows of a plan; the rows around a held
+step (doy 60) and around the ends of partial years stay on the ring kernel, and cell-rows whose lists are too short are
+flagged and recomputed by the generic kernel.  Whatever the split, raw thresh must be bit-identical to the generic
+kernel (an independent algorithm) and to the oracle; seas is a float64 sum of the same samples in another order.
+"""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+import xmhw_oracle as ora
+import oracle_fast as fast
+
+pytestmark = pytest.mark.gpu
+
+SORTED = 40
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from xmhw_amd._lib import require_gpu
+    require_gpu()
+    import xmhw_amd.device as d
+    return d
+
+
+def _series(T, C, seed, nanfrac=0.0, quant=None, base=15.0, amp=(2, 10)):
+    rng = np.random.default_rng(seed)
+    t = np.arange(T)[:, None]
+    x = base + rng.uniform(*amp, C) * np.sin(2 * np.pi * (t - rng.uniform(0, 365, C)) / 365.25) \
+        + 0.0005 * t * rng.uniform(-1, 1, C) + rng.normal(size=(T, C))
+    if quant:
+        x = np.round(x / quant) * quant
+    x = x.astype(np.float32)
+    if nanfrac:
+        x[rng.random((T, C)) < nanfrac] = np.nan
+    return x
+
+
+def _daily(y0, y1, start=None, stop=None):
+    time = np.arange(start or f"{y0}-01-01", stop or f"{y1 + 1}-01-01", dtype="datetime64[D]")
+    return ora.add_doy(time)
+
+
+def _raw(dev, x, doy, q=0.9, negate=False, nchunks=0, kernel="auto", layout=None):
+    h = dev.hip()
+    T, C = x.shape
+    plan = dev.Plan(doy, 5, kernel=kernel, nchunks=nchunks, layout=layout)
+    bufs = []
+    try:
+        use = plan.layout_in_use()
+        d_ts = dev.DeviceBuffer.from_array(x); bufs.append(d_ts)
+        th, se = dev.DeviceBuffer(8 * plan.D * C), dev.DeviceBuffer(8 * plan.D * C)
+        bufs += [th, se]
+        h.plan_debug_stats(plan.handle, 1, False)
+        dev.clim_raw(plan, d_ts, 4, C, q, negate, th, se)
+        h.stream_sync(0)
+        st = h.plan_debug_stats(plan.handle, 1, True)
+        return th.to_array((plan.D, C), np.float64), se.to_array((plan.D, C), np.float64), st, use
+    finally:
+        for b in bufs:
+            b.free()
+        plan.destroy()
+
+
+def _check(dev, x, doy, q=0.9, negate=False, nchunks=0, max_flag=None):
+    tg, sg, _, _ = _raw(dev, x, doy, q, negate, kernel="generic")
+    t1, s1, st, use = _raw(dev, x, doy, q, negate, nchunks, layout="sorted")
+    assert use == SORTED
+    npt.assert_array_equal(t1, tg)
+    npt.assert_allclose(s1, sg, rtol=1e-12, atol=1e-300, equal_nan=True)
+    if dev.hip().debug_stats_available():           # counter twins: make STATS=1
+        assert st[0] > 0, "the sorted kernel did not run"
+        if max_flag is not None:
+            rows = x.shape[1] * len(np.unique(doy))
+            assert int(st[2]) <= max_flag * rows, (st, rows)
+    return tg, sg, st
+
+
+def test_sorted_is_the_default_on_the_headline_shape(dev):
+    plan = dev.Plan(_daily(1982, 2021), 5)
+    try:
+        assert plan.layout_in_use() == SORTED
+    finally:
+        plan.destroy()
+
+
+@pytest.mark.parametrize("C", [1, 31, 32, 33, 77, 200])
+def test_daily_40_years_equals_generic_and_oracle(dev, C):
+    doy = _daily(1982, 2021)
+    x = _series(doy.shape[0], C, 11 + C)
+    tg, sg, _ = _check(dev, x, doy, max_flag=0.02)
+    _, th, se = fast.raw_clim(x.astype(np.float64), doy, 0.9, 5)
+    npt.assert_array_equal(tg, th)
+    npt.assert_allclose(sg, se, rtol=1e-13)
+
+
+@pytest.mark.parametrize("q", [0.75, 0.8, 0.9, 0.95, 0.99, 1.0])
+def test_high_percentiles(dev, q):
+    doy = _daily(1982, 2021)
+    x = _series(doy.shape[0], 40, 3)
+    _check(dev, x, doy, q=q)
+
+
+@pytest.mark.parametrize("q", [0.0, 0.1, 0.5])
+def test_low_percentiles_stay_on_the_ring_kernel(dev, q):
+    """below 0.75 the call runs on the ring layout; the result is the same"""
+    doy = _daily(1982, 2021)
+    x = _series(doy.shape[0], 40, 4)
+    _check(dev, x, doy, q=q)
+
+
+def test_cold_spells(dev):
+    doy = _daily(1982, 2021)
+    x = _series(doy.shape[0], 50, 5)
+    _check(dev, x, doy, q=0.9, negate=True)
+
+
+def test_nan_holes_and_all_nan_cell(dev):
+    doy = _daily(1982, 2021)
+    x = _series(doy.shape[0], 70, 7, nanfrac=0.05)
+    x[:, 3] = np.nan
+    x[100:4000, 5] = np.nan
+    x[:, 40] = np.nan
+    x[5000, 40] = 3.0
+    _check(dev, x, doy)
+
+
+def test_ties_quantised_constant_and_sea_ice_cells(dev):
+    """0.01 degree data, a constant cell, a cell with two distinct values, a cell held at -1.8 for 120 days a year"""
+    doy = _daily(1982, 2021)
+    x = _series(doy.shape[0], 64, 9, quant=0.01)
+    x[:, 0] = 7.0
+    x[:, 1] = np.where(np.arange(x.shape[0]) % 3 == 0, 1.0, 2.0)
+    ice = (doy >= 200) & (doy < 320)
+    x[ice, 2] = -1.8
+    x[ice, 35] = -1.8
+    _check(dev, x, doy)
+
+
+def test_steep_seasonal_cycle_overflows_lists_and_is_still_exact(dev):
+    """amplitude 30: a row-list holds far more than K of the pool's largest keys; the flagged cell-rows come back from
+    the generic kernel"""
+    doy = _daily(1982, 2021)
+    x = _series(doy.shape[0], 48, 13, amp=(20, 30))
+    _check(dev, x, doy)
+
+
+def test_infinities_and_extremes(dev):
+    doy = _daily(1982, 2021)
+    x = _series(doy.shape[0], 40, 17)
+    x[1000:1020, 0] = np.inf
+    x[2000:2003, 1] = -np.inf
+    x[3000, 2] = np.inf
+    x[3001, 2] = -np.inf
+    x[:, 3] = 0.0
+    x[::2, 3] = -0.0
+    x[:, 4] = 1e-45
+    x[::7, 4] = 3.4e38
+    with np.errstate(invalid="ignore"):
+        _check(dev, x, doy)
+
+
+def test_chunked_equals_unchunked(dev):
+    doy = _daily(1982, 2021)
+    x = _series(doy.shape[0], 45, 19, nanfrac=0.01)
+    a = _raw(dev, x, doy, nchunks=1, layout="sorted")
+    b = _raw(dev, x, doy, nchunks=5, layout="sorted")
+    npt.assert_array_equal(a[0], b[0])
+    npt.assert_allclose(a[1], b[1], rtol=1e-12, equal_nan=True)
+
+
+def test_partial_first_and_last_year(dev):
+    """a record that starts in September and ends in March: the rows next to the ends of the partial tracks are not
+    regular and stay on the ring kernel"""
+    doy = _daily(0, 0, start="1982-09-01", stop="2021-03-15")
+    x = _series(doy.shape[0], 40, 23)
+    _check(dev, x, doy)
+
+
+def test_no_leap_calendar_has_one_segment(dev):
+    """a 365-day calendar: no held step, every row regular"""
+    T = 40 * 365
+    doy = (np.arange(T) % 365 + 1).astype(np.int64)
+    doy = np.where(doy >= 60, doy + 1, doy)
+    x = _series(T, 40, 29)
+    _check(dev, x, doy)
+
+
+def test_random_cases_equal_generic_kernel(dev):
+    rng = np.random.default_rng(2026)
+    for it in range(12):
+        years = 39 + int(rng.integers(0, 2))
+        y0 = int(rng.integers(1950, 1990))
+        doy = _daily(y0, y0 + years - 1)
+        C = int(rng.integers(1, 90))
+        x = _series(doy.shape[0], C, 100 + it, nanfrac=float(rng.choice([0.0, 0.02, 0.3])),
+                    quant=float(rng.choice([0.0, 0.01, 0.5])) or None, amp=(0.1, float(rng.choice([3, 10, 25]))))
+        _check(dev, x, doy, q=float(rng.choice([0.9, 0.8, 0.97])), negate=bool(rng.integers(0, 2)))

@@ -105,7 +105,9 @@ def test_ring2_layout_choice():
         t = np.arange("1982-01-01", f"{1982 + n}-01-01", dtype="datetime64[D]")
         return Plan(ora.add_doy(t), w, ring2=ring2)
 
-    assert years(40).ring2_in_use() == 21                     # 4 x 10 = 40 tracks: ring3
+    assert years(40).ring2_in_use() == 40                     # 40 tracks: the sorted-list kernel (round 5) ...
+    assert years(39).ring2_in_use() == 40
+    assert years(40, ring2=21).ring2_in_use() == 21           # ... 4 x 10 = 40 tracks on ring3 when forced
     assert years(30).ring2_in_use() == 21                     # 4 x 8 (2 padded)
     assert years(25).ring2_in_use() == 21 and years(48).ring2_in_use() == 21      # 7 .. 12 tracks per lane
     assert years(24).ring2_in_use() == 22 and years(13).ring2_in_use() == 22      # 2 lanes per cell up to 24 tracks
@@ -140,9 +142,10 @@ def test_ring2_layout_choice():
     # the round-4 names: xmhw_plan_set_layout / xmhw_plan_layout_in_use with the XMHW_LAYOUT_* constants
     from xmhw_amd.device import LAYOUTS
     assert LAYOUTS == {"auto": -2, "ring1": -1, "ring2_8lane": 8, "ring2_4lane": 10, "ring2_16lane": 12,
-                       "ring3_8lane": 20, "ring3_4lane": 21, "ring3_2lane": 22}
+                       "ring3_8lane": 20, "ring3_4lane": 21, "ring3_2lane": 22, "sorted": 40}
     t40 = ora.add_doy(np.arange("1982-01-01", "2022-01-01", dtype="datetime64[D]"))
-    assert Plan(t40, 5).layout_in_use() == LAYOUTS["ring3_4lane"]
+    assert Plan(t40, 5).layout_in_use() == LAYOUTS["sorted"]
+    assert Plan(t40, 5, layout="ring3_4lane").layout_in_use() == LAYOUTS["ring3_4lane"]
     assert Plan(t40, 5, layout="ring3_8lane").layout_in_use() == 20
     assert Plan(t40, 5, layout="ring2_8lane").layout_in_use() == 8
     assert Plan(t40, 5, layout="ring2_4lane").layout_in_use() == 10

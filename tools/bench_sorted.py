@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Time the sorted-list kernel (layout 40) beside a ring layout on one BASELINE shape, device-resident synthetic input.
+   python tools/bench_sorted.py [--config 0.25deg|1deg|0.25deg_nan] [--cells N] [--layouts 40 21] [--reps 5]
+One JSON line per layout: ms of the whole clim_raw call (HIP events, median), bit-identity of thresh against the first
+layout on a column sample, and -- in `make STATS=1` builds -- the sorted kernel's counters: walk iterations per wave-row,
+steps per cell-row, flagged cell-rows, shader-clock ticks per section and wave-row."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="0.25deg")
+    ap.add_argument("--cells", type=int, default=0)
+    ap.add_argument("--layouts", type=int, nargs="*", default=[40, 21])
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--chunks", type=int, default=0)
+    ap.add_argument("--q", type=float, default=0.9)
+    args = ap.parse_args()
+    import xmhw_amd.device as dev
+    from xmhw_amd.calendar import add_doy
+    h = dev.hip()
+    presets = {"0.25deg": (1440 * 720, (1982, 2021), 0.0), "1deg": (360 * 180, (1991, 2020), 0.0),
+               "0.25deg_nan": (1440 * 720, (1982, 2021), 0.05)}
+    C, years, nan = presets[args.config]
+    C = args.cells or C
+    doy = add_doy(np.arange(f"{years[0]}-01-01", f"{years[1] + 1}-01-01", dtype="datetime64[D]"))
+    T = doy.shape[0]
+    ts = dev.DeviceBuffer(4 * T * C)
+    h.synth_sst(ts.ptr, 4, T, C, C, 0, 20260103, nan, 0)
+    ref = None
+    idx = np.unique(np.linspace(0, C - 1, 2048).astype(np.int64))
+    d_idx = dev.DeviceBuffer.from_array(idx)
+    for v in args.layouts:
+        plan = dev.Plan(doy, 5, nchunks=args.chunks, layout=v)
+        if plan.layout_in_use() != v:
+            print(json.dumps({"layout": v, "skipped": f"not instantiated for {plan.ntracks} tracks"}), flush=True)
+            plan.destroy()
+            continue
+        D = plan.D
+        th, se = dev.DeviceBuffer(8 * D * C), dev.DeviceBuffer(8 * D * C)
+        e0, e1 = h.event_create(), h.event_create()
+        dev.clim_raw(plan, ts, 4, C, args.q, False, th, se)      # warm-up (plan upload)
+        h.stream_sync(0)
+        h.plan_debug_stats(plan.handle, 1, False)
+        ms = []
+        for _ in range(args.reps):
+            h.event_record(e0, 0)
+            dev.clim_raw(plan, ts, 4, C, args.q, False, th, se)
+            h.event_record(e1, 0)
+            ms.append(h.event_elapsed_ms(e0, e1))
+        st = h.plan_debug_stats(plan.handle, 1, True)
+        sub = dev.DeviceBuffer(8 * D * idx.size)
+        h.gather_cells(th.ptr, 8, D, C, d_idx.ptr, idx.size, sub.ptr, idx.size)
+        h.stream_sync(0)
+        got = sub.to_array((D, idx.size), np.float64)
+        if ref is None:
+            ref = got
+        med = float(np.median(ms))
+        out = {"layout": v, "config": args.config, "cells": C, "ms": round(med, 3), "ms_all": [round(m, 3) for m in ms],
+               "frac_of_8TBs": round(C * (T * 4 + 2 * D * 8) / med / 1e6 / 8000, 4),
+               "thresh_bit_identical_to_first": bool(np.array_equal(got, ref, equal_nan=True))}
+        if v == 40 and h.debug_stats_available() and int(st[0]) > 0:
+            rows = float(st[0])
+            cellrows = float(C) * D * args.reps
+            out["sorted"] = {"wave_rows": int(st[0]), "walk_iterations_per_wave_row": round(float(st[1]) / rows, 2),
+                             "walk_steps_per_cell_row": round(float(st[3]) / cellrows, 3),
+                             "flagged_cell_rows_frac": float(st[2]) / cellrows,
+                             "ticks_per_wave_row_push_sort_book_walk_epilogue": [round(float(x) / rows, 1) for x in st[8:13]]}
+        print(json.dumps(out), flush=True)
+        for b in (th, se, sub):
+            b.free()
+        plan.destroy()
+    ts.free()
+    dev.release_device_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -50,6 +50,8 @@ namespace {
     } while (0)
 
 constexpr int kSubs = 8;
+// the sorted-list kernel keeps the K largest keys of a row-list: quantiles from here up
+constexpr double kSortedMinQ = 0.75;
 
 }  // namespace
 
@@ -77,9 +79,23 @@ struct xmhw_plan {
     int32_t ypsx = 0, subsx = 0;
     uint32_t* d_narrow_flag = nullptr;      // float64 input: set when a sample is not float32-representable
     bool narrowing = true;                  // xmhw_plan_set_narrowing
+    // sorted-list kernel (kernels_sorted.hip): its table (2 lanes per cell), the chunks of the regular rows it serves,
+    // the chunks of the other rows (they stay on the ring kernel), the bitmap of cell-rows it hands to the generic kernel
+    int32_t yps_s = 0;
+    uint32_t* d_table_s = nullptr;
+    xmhw::DevChunk* d_chunks_s = nullptr;
+    xmhw::DevChunk* d_chunks_i = nullptr;
+    int32_t nchunks_s = 0, nchunks_i = 0;
+    int64_t sorted_waves = -1;              // the grid width the sorted chunks were cut for
+    uint32_t* d_redo = nullptr;
+    size_t redo_words = 0;
 
     ~xmhw_plan() {
         if (d_stats) (void)hipFree(d_stats);
+        if (d_table_s) (void)hipFree(d_table_s);
+        if (d_chunks_s) (void)hipFree(d_chunks_s);
+        if (d_chunks_i) (void)hipFree(d_chunks_i);
+        if (d_redo) (void)hipFree(d_redo);
         if (d_narrow_flag) (void)hipFree(d_narrow_flag);
         if (d_tablex) (void)hipFree(d_tablex);
         if (d_table) (void)hipFree(d_table);
@@ -205,7 +221,7 @@ int32_t ring2_legacy(const xmhw_plan* p) {
 }
 
 int32_t ring2_resolved(const xmhw_plan* p) {
-    if (p->ring2_variant != -2) return p->ring2_variant;
+    if (p->ring2_variant != -2 && p->ring2_variant != XMHW_LAYOUT_SORTED) return p->ring2_variant;
     // the third-generation kernel (kernels_ring3.hip) on 4 lanes per cell where a lane holds at least 4 tracks
     // (w = 5, 13..48 tracks).  1,036,800 cells, daily (tools/bench_ring2.py --years, counters on): 40 tracks 57.6 ms
     // against 80 ms for the second-generation layouts, 24 tracks 41.8 against 59.8, 20 tracks 38.3 against 44.0,
@@ -258,8 +274,80 @@ NarrowChoice narrow_choice(const xmhw_plan* p) {
     return c;
 }
 
+// The sorted-list kernel serves float32 input of plans with w = 5 whose record it is instantiated for, under the
+// automatic layout choice or XMHW_LAYOUT_SORTED (environment XMHW_SORTED=0 turns it off); the rows it cannot serve
+// (plan.h: sorted_segments) need the ring kernel.
+bool sorted_usable(const xmhw_plan* p) {
+    static const bool on = [] { const char* v = std::getenv("XMHW_SORTED"); return !(v && v[0] == '0'); }();
+    if (!on && p->ring2_variant != XMHW_LAYOUT_SORTED) return false;
+    if (p->ring2_variant != -2 && p->ring2_variant != XMHW_LAYOUT_SORTED) return false;
+    if (p->host.kernel_choice == XMHW_KERNEL_GENERIC) return false;
+    if (xmhw::sorted_pick_yps(p->host.w, p->host.ntracks) == 0) return false;
+    return resolve_kernel(p, 4) == XMHW_KERNEL_RING;
+}
+
+// tables, chunks and the redo bitmap of the sorted-list kernel (under the plan's lock)
+int upload_sorted(xmhw_plan* p, int64_t C) {
+    const xmhw::Plan& h = p->host;
+    if (!sorted_usable(p)) { p->nchunks_s = 0; return XMHW_OK; }
+    const int32_t yps = xmhw::sorted_pick_yps(h.w, h.ntracks);
+    if (!p->d_table_s || p->yps_s != yps) {
+        if (p->d_table_s) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p->d_table_s)); p->d_table_s = nullptr; }
+        const std::vector<uint32_t> t = h.ring_table(2, yps);
+        HIP_TRY(hipMalloc(&p->d_table_s, sizeof(uint32_t) * t.size()));
+        HIP_TRY(hipMemcpy(p->d_table_s, t.data(), sizeof(uint32_t) * t.size(), hipMemcpyHostToDevice));
+        p->yps_s = yps;
+        p->sorted_waves = -1;
+    }
+    const int64_t waves = (C + 31) / 32;
+    if (p->sorted_waves != waves) {
+        // regular runs -> chunks of the sorted kernel (cut so that a small grid still fills the chip: 6 waves per CU,
+        // every piece pays R - 1 warm-up rows); the other runs -> chunks of the ring kernel
+        const std::vector<xmhw::Plan::Segment> segs = h.sorted_segments();
+        std::vector<xmhw::DevChunk> cs, ci;
+        for (const auto& sg : segs) {
+            if (sg.regular) {
+                const int32_t len = sg.end - sg.begin;
+                int64_t pieces = h.nchunks_req > 0 ? h.nchunks_req : (1536 + waves - 1) / std::max<int64_t>(waves, 1);
+                pieces = std::max<int64_t>(1, std::min<int64_t>(pieces, len / 24));
+                for (int64_t j = 0; j < pieces; ++j) {
+                    const int32_t b = sg.begin + static_cast<int32_t>(len * j / pieces);
+                    const int32_t e = sg.begin + static_cast<int32_t>(len * (j + 1) / pieces);
+                    if (e > b) cs.push_back({b - (h.R - 1), b, e});
+                }
+            } else {
+                ci.push_back({h.warm_start_for(sg.begin), sg.begin, sg.end});
+            }
+        }
+        auto put = [](xmhw::DevChunk** dst, const std::vector<xmhw::DevChunk>& v) -> hipError_t {
+            if (*dst) { hipError_t e = hipFree(*dst); *dst = nullptr; if (e != hipSuccess) return e; }
+            if (v.empty()) return hipSuccess;
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), sizeof(xmhw::DevChunk) * v.size());
+            if (e != hipSuccess) { *dst = nullptr; return e; }
+            return hipMemcpy(*dst, v.data(), sizeof(xmhw::DevChunk) * v.size(), hipMemcpyHostToDevice);
+        };
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(put(&p->d_chunks_s, cs));
+        HIP_TRY(put(&p->d_chunks_i, ci));
+        p->nchunks_s = static_cast<int32_t>(cs.size());
+        p->nchunks_i = static_cast<int32_t>(ci.size());
+        p->sorted_waves = waves;
+    }
+    const size_t words = static_cast<size_t>(h.D) * static_cast<size_t>(waves);
+    if (p->nchunks_s > 0 && words > p->redo_words) {
+        if (p->d_redo) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p->d_redo)); p->d_redo = nullptr; p->redo_words = 0; }
+        HIP_TRY(hipMalloc(&p->d_redo, sizeof(uint32_t) * words));
+        p->redo_words = words;
+    }
+    return XMHW_OK;
+}
+
 int upload(xmhw_plan* p, int64_t C) {
     std::lock_guard<std::mutex> lock(p->mu);
+    {
+        const int rc = upload_sorted(p, C);
+        if (rc != XMHW_OK) return rc;
+    }
     const int32_t nchunks = auto_chunks(p, C);
     const X64Choice xc0 = x64_choice(p);
     const int32_t xsubs0 = xc0.variant == 21 ? 4 : 8;
@@ -357,14 +445,39 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
     hipError_t e;
     if (kernel == XMHW_KERNEL_RING) {
         if constexpr (sizeof(T) == 4) {
+            // float32: the sorted-list kernel on the regular rows (high percentiles: a list keeps its K largest keys),
+            // the ring kernel on the others, the generic kernel on the cell-rows the sorted kernel flagged
+            const bool sorted = plan->nchunks_s > 0 && q >= kSortedMinQ;
+            const xmhw::DevChunk* rchunks = sorted ? plan->d_chunks_i : plan->d_chunks;
+            const int32_t rn = sorted ? plan->nchunks_i : plan->nchunks;
+            unsigned long long* rstats = sorted ? nullptr : plan->d_stats;
+            e = hipSuccess;
+            const int64_t redo_ld = (C + 31) / 32;
+            if (sorted) {
+                e = hipMemsetAsync(plan->d_redo, 0, sizeof(uint32_t) * static_cast<size_t>(h.D) * static_cast<size_t>(redo_ld), st);
+                if (e == hipSuccess)
+                    e = xmhw::launch_sorted_f32(reinterpret_cast<const float*>(ts), C, ld, h.T, plan->d_table_s,
+                                                plan->d_sflags, h.step_min, plan->d_chunks_s, plan->nchunks_s, h.w,
+                                                plan->yps_s, h.ntracks, q, negate, thresh, seas, ldo, plan->d_redo, redo_ld,
+                                                st, plan->d_stats);
+            }
+            if (e != hipSuccess) {
+            } else if (rn == 0) {
+            } else
             if (plan->yps2 && ring2_resolved(plan) >= 0 && xmhw::ring2_f32_supported(h.w, plan->yps2, ring2_resolved(plan)))
                 e = xmhw::launch_ring2_f32(reinterpret_cast<const float*>(ts), C, ld, h.T, plan->d_table2, plan->d_sflags,
-                                           h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps2, h.ntracks,
-                                           ring2_resolved(plan), q, negate, thresh, seas, ldo, st, plan->d_stats);
+                                           h.step_min, rchunks, rn, h.w, plan->yps2, h.ntracks,
+                                           ring2_resolved(plan), q, negate, thresh, seas, ldo, st, rstats);
             else
             e = xmhw::launch_ring_f32(reinterpret_cast<const float*>(ts), C, ld, plan->d_table,
-                                      h.step_min, plan->d_chunks, plan->nchunks, h.w, plan->yps, plan->subs, q,
-                                      negate, thresh, seas, ldo, st, plan->d_stats);
+                                      h.step_min, rchunks, rn, h.w, plan->yps, plan->subs, q,
+                                      negate, thresh, seas, ldo, st, rstats);
+            // (XMHW_SORTED_NOREDO=1: timing experiments only -- flagged cell-rows keep the sorted kernel's own answer)
+            static const bool noredo = [] { const char* v = std::getenv("XMHW_SORTED_NOREDO"); return v && v[0] == '1'; }();
+            if (e == hipSuccess && sorted && !noredo)
+                e = xmhw::launch_generic_flagged<float>(reinterpret_cast<const float*>(ts), h.T, C, ld, plan->d_row_ptr,
+                                                        plan->d_centres, 0, h.D, h.w, q, negate, thresh, seas, ldo,
+                                                        plan->d_redo, redo_ld, st);
         } else {
             // float64 input: if every sample is float32-representable (decoded int16 / float32
             // archives) the float32 kernel gives the same pools at 2.7x the rate.  All decisions are
@@ -1036,13 +1149,21 @@ int xmhw_plan_create(const int32_t* doy_host, int64_t T, int32_t window_half_wid
 }
 int xmhw_plan_set_layout(xmhw_plan* plan, int32_t layout) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
-    if (layout < -2 || (layout > 12 && !(layout >= 20 && layout <= 22) && !(layout >= 30 && layout <= 32)))
-        return fail(XMHW_ERR_INVALID, "layout must be one of the XMHW_LAYOUT_* constants (-2, -1, 8, 10, 12, 20..22)");
+    if (layout < -2 || (layout > 12 && !(layout >= 20 && layout <= 22) && !(layout >= 30 && layout <= 32) &&
+                        layout != XMHW_LAYOUT_SORTED))
+        return fail(XMHW_ERR_INVALID, "layout must be one of the XMHW_LAYOUT_* constants (-2, -1, 8, 10, 12, 20..22, 40)");
+    if (layout == XMHW_LAYOUT_SORTED && xmhw::sorted_pick_yps(plan->host.w, plan->host.ntracks) == 0)
+        return fail(XMHW_ERR_UNSUPPORTED, "the sorted-list kernel is not instantiated for this window / record length");
     plan->ring2_variant = layout;
     return XMHW_OK;
 }
 int xmhw_plan_layout_in_use(const xmhw_plan* plan, int32_t* layout) {
     if (!plan || !layout) return fail(XMHW_ERR_INVALID, "NULL argument");
+    if (sorted_usable(plan)) {
+        bool any = false;
+        for (const auto& sg : plan->host.sorted_segments()) any = any || sg.regular;
+        if (any) { *layout = XMHW_LAYOUT_SORTED; return XMHW_OK; }
+    }
     const int32_t v2 = ring2_resolved(plan);
     const bool ring = resolve_kernel(plan, 4) == XMHW_KERNEL_RING;
     const int32_t y2 = v2 >= 0 ? xmhw::ring2_pick_yps(plan->host.w, plan->host.ntracks, v2) : 0;

@@ -59,6 +59,21 @@ hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
                             double* thresh, double* seas, int64_t ldo, hipStream_t stream,
                             unsigned long long* stats = nullptr);
 
+// fifth generation (kernels_sorted.hip): sorted row-lists in LDS + a pointer walk; 2 lanes per cell, w = 5, float32,
+// REGULAR rows only (plan.h: sorted_segments); cell-rows it cannot settle are flagged in redo_bits
+// [row * redo_ld + (cell >> 5)] for launch_generic_flagged
+int32_t sorted_pick_yps(int32_t w, int32_t ntracks);     // tracks per lane, 0 if not instantiated
+hipError_t launch_sorted_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
+                             const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,
+                             int32_t w, int32_t yps, int32_t ntracks, double q, int negate, double* thresh, double* seas,
+                             int64_t ldo, uint32_t* redo_bits, int64_t redo_ld, hipStream_t stream,
+                             unsigned long long* stats = nullptr);
+template <typename T>
+hipError_t launch_generic_flagged(const T* ts, int64_t Tn, int64_t C, int64_t ld, const int32_t* row_ptr,
+                                  const int32_t* centres, int32_t row0, int32_t nrows, int32_t w, double q, int negate,
+                                  double* thresh, double* seas, int64_t ldo, const uint32_t* bits, int64_t ldb,
+                                  hipStream_t stream);
+
 // fourth-generation float32 ring kernel (kernels_ring4.hip): a windowed key store in LDS instead of histogram + band
 // compaction; same lane layouts and step tables as the third generation (ring2 variants 30 / 31 / 32 = 8 / 4 / 2 lanes)
 int32_t ring4_pick_yps(int32_t w, int32_t ntracks, int32_t subs);

@@ -19,21 +19,14 @@ namespace xmhw {
 // one pass over the pool per bit; a final pass finds the next order statistic.
 // The pool is re-read from L2 for every pass (lanes of a block share rows).
 // ---------------------------------------------------------------------------
+// one (cell, row): col = the cell's column of the series
 template <typename T>
-__global__ __launch_bounds__(256) void clim_generic(const T* __restrict__ ts, int64_t Tn, int64_t C,
-                                                    int64_t ld, const int32_t* __restrict__ row_ptr,
-                                                    const int32_t* __restrict__ centres, int32_t w,
-                                                    double q, int negate, double* __restrict__ thresh,
-                                                    double* __restrict__ seas, int64_t ldo,
-                                                    const uint32_t* __restrict__ run_flag) {
-    // queued behind the narrowing float32 ring kernel (capi.cpp): nothing to do unless that one gave up
-    if (run_flag != nullptr && *run_flag == 0) return;
+__device__ __forceinline__ void generic_cell_row(const T* __restrict__ col, int64_t Tn, int64_t ld,
+                                                 const int32_t* __restrict__ row_ptr,
+                                                 const int32_t* __restrict__ centres, int32_t row, int32_t w, double q,
+                                                 int negate, double& th_out, double& se_out) {
     using K = typename KeyOf<T>::type;
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const int32_t row = blockIdx.y;
-    if (c >= C) return;
     const int32_t cb = row_ptr[row], ce = row_ptr[row + 1];
-    const T* col = ts + c;
 
     uint32_t n = 0;
     double sum = 0.0;
@@ -90,6 +83,46 @@ __global__ __launch_bounds__(256) void clim_generic(const T* __restrict__ ts, in
         th = numpy_lerp(KeyOf<T>::value(v), KeyOf<T>::value(vhi), g);
         se = sum / static_cast<double>(n);
     }
+    th_out = th;
+    se_out = se;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void clim_generic(const T* __restrict__ ts, int64_t Tn, int64_t C,
+                                                    int64_t ld, const int32_t* __restrict__ row_ptr,
+                                                    const int32_t* __restrict__ centres, int32_t w,
+                                                    double q, int negate, double* __restrict__ thresh,
+                                                    double* __restrict__ seas, int64_t ldo,
+                                                    const uint32_t* __restrict__ run_flag) {
+    // queued behind the narrowing float32 ring kernel (capi.cpp): nothing to do unless that one gave up
+    if (run_flag != nullptr && *run_flag == 0) return;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int32_t row = blockIdx.y;
+    if (c >= C) return;
+    double th, se;
+    generic_cell_row<T>(ts + c, Tn, ld, row_ptr, centres, row, w, q, negate, th, se);
+    thresh[static_cast<int64_t>(row) * ldo + c] = th;
+    seas[static_cast<int64_t>(row) * ldo + c] = se;
+}
+
+// The same for the cell-rows FLAGGED by the sorted-list kernel (kernels_sorted.hip: a list too short for the row):
+// bits[row * ldb + (c >> 5)] bit (c & 31).  A wave looks at its 64 cells' two words and leaves unless one is set;
+// rows [row0, row0 + gridDim.y).
+template <typename T>
+__global__ __launch_bounds__(256) void clim_generic_flagged(const T* __restrict__ ts, int64_t Tn, int64_t C,
+                                                            int64_t ld, const int32_t* __restrict__ row_ptr,
+                                                            const int32_t* __restrict__ centres, int32_t w,
+                                                            double q, int negate, double* __restrict__ thresh,
+                                                            double* __restrict__ seas, int64_t ldo,
+                                                            const uint32_t* __restrict__ bits, int64_t ldb,
+                                                            int32_t row0) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int32_t row = row0 + static_cast<int32_t>(blockIdx.y);
+    if (c >= C) return;
+    const uint32_t word = bits[static_cast<int64_t>(row) * ldb + (c >> 5)];
+    if (((word >> (c & 31)) & 1u) == 0u) return;
+    double th, se;
+    generic_cell_row<T>(ts + c, Tn, ld, row_ptr, centres, row, w, q, negate, th, se);
     thresh[static_cast<int64_t>(row) * ldo + c] = th;
     seas[static_cast<int64_t>(row) * ldo + c] = se;
 }
@@ -105,6 +138,20 @@ hipError_t launch_generic(const T* ts, int64_t Tn, int64_t C, int64_t ld, const 
                        q, negate, thresh, seas, ldo, run_flag);
     return hipGetLastError();
 }
+template <typename T>
+hipError_t launch_generic_flagged(const T* ts, int64_t Tn, int64_t C, int64_t ld, const int32_t* row_ptr,
+                                  const int32_t* centres, int32_t row0, int32_t nrows, int32_t w, double q, int negate,
+                                  double* thresh, double* seas, int64_t ldo, const uint32_t* bits, int64_t ldb,
+                                  hipStream_t stream) {
+    if (C <= 0 || nrows <= 0) return hipSuccess;
+    dim3 grid(static_cast<unsigned>((C + 255) / 256), static_cast<unsigned>(nrows));
+    hipLaunchKernelGGL(clim_generic_flagged<T>, grid, dim3(256), 0, stream, ts, Tn, C, ld, row_ptr, centres, w, q,
+                       negate, thresh, seas, ldo, bits, ldb, row0);
+    return hipGetLastError();
+}
+template hipError_t launch_generic_flagged<float>(const float*, int64_t, int64_t, int64_t, const int32_t*,
+                                                  const int32_t*, int32_t, int32_t, int32_t, double, int, double*,
+                                                  double*, int64_t, const uint32_t*, int64_t, hipStream_t);
 template hipError_t launch_generic<float>(const float*, int64_t, int64_t, int64_t, const int32_t*,
                                           const int32_t*, int32_t, int32_t, double, int, double*,
                                           double*, int64_t, hipStream_t, const uint32_t*);

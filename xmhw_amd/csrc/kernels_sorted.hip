@@ -1,0 +1,555 @@
+// kernels_sorted.hip -- fifth-generation climatology kernel (round 5): selection on SORTED ROW-LISTS in LDS.
+//
+// What the ring kernels (kernels_ring*.hip) keep in registers -- the R = 2w+1 last samples of every track -- is not
+// kept at all here.  The pool of a row is the union of the R last ROW-LISTS (the samples all tracks push at one step),
+// and a row-list is evicted WHOLE when its slot is overwritten, so nothing is ever needed per key after its push:
+//
+//   * per step the 2 lanes of a cell sort the cell's new samples (a network in registers per lane, one bitonic
+//     exchange between the lanes) and write the K largest keys, descending, into the slot of the evicted list:
+//     lists[slot][1 + k][cell] in LDS, cell-minor, so that per-lane dynamic positions never meet on a bank; word 0 of a
+//     list is +inf, word K + 1 is 0 (an invalid key) -- sentinels;
+//   * per list a POINTER P_i = the position of its first key outside the TOP SET (the Cs largest keys of the pool,
+//     Cs = n - 1 - lo, lo = floor((n - 1) q)): order statistic lo of numpy's linear quantile is the largest key outside
+//     the top set (max over the lists of key[P_i]), lo + 1 the smallest inside (min of key[P_i - 1]);
+//   * a row changes the top set by the evicted list's share and the new list's (counted against the carried boundary
+//     value); the pointers are then WALKED one key at a time -- the list whose head is the largest key outside (the
+//     smallest inside) moves by one -- until the top set has Cs keys again: |c_new - c_evicted| steps, 4 on average.
+//   * `seas` = running float64 total +- per-list sums, as in kernels_ring3.hip.
+//
+// Everything is exact.  What can fail is the capacity of a list: a list whose K stored keys are all inside the top set
+// while it holds more valid keys than K (a steep seasonal slope puts up to ~20 of a list's 40 keys among the 44
+// largest of the pool).  Such cell-rows are FLAGGED in a bitmap and recomputed by clim_generic_flagged
+// (kernels_generic.hip); the list state stays consistent (the hidden keys are all below the stored ones) and the cell
+// carries on by itself once the boundary has moved back.
+//
+// The kernel runs on REGULAR rows only (plan.cpp: sorted_segments): every real track pushes at each of the R steps that
+// feed the row and is part of the row's pool.  The rows around a held step (doy 60) and around the ends of partial
+// tracks stay on kernels_ring3.hip.
+//
+// Lane layout: lane = 2 * cell_in_wave + sub; a wave is 32 cells = one 128-byte line of a float32 sample row; a
+// workgroup is one wave.  Track k of the plan sits in lane sub = k % 2, slot k / 2 (the y-major table of the ring
+// kernels, subs = 2).
+//
+// Reference semantics restated: window_roll() (identify.py:184-209), calculate_thresh() / calculate_seas() without
+// the Feb-29 step (identify.py:233-235, :263), coldSpells negation (xmhw.py:153-154).
+#include "device_common.h"
+#include "kernels.h"
+#include "plan.h"
+#include "sortnet_gen.h"
+
+namespace xmhw {
+namespace {
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_ld(uint32_t a) { return *reinterpret_cast<lds_u32*>(static_cast<uintptr_t>(a)); }
+__device__ __forceinline__ void lds_st(uint32_t a, uint32_t v) { *reinterpret_cast<lds_u32*>(static_cast<uintptr_t>(a)) = v; }
+
+constexpr int kSwap1 = 0xB1;      // quad_perm [1, 0, 3, 2]: the other lane of the cell
+__device__ __forceinline__ uint32_t swp(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), kSwap1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double swp(double v) {
+    const uint64_t b = static_cast<uint64_t>(__double_as_longlong(v));
+    const uint32_t lo = swp(static_cast<uint32_t>(b)), hi = swp(static_cast<uint32_t>(b >> 32));
+    return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
+}
+__device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int32_t med3i(int32_t a, int32_t b, int32_t c) {
+    int32_t r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+typedef uint32_t V8 __attribute__((ext_vector_type(8)));
+
+}  // namespace
+
+// stats (STATS builds): [0] wave-rows, [1] walk iterations (what the wave pays), [2] flagged cell-rows, [3] walk steps
+// summed over cells, [8..15] shader-clock ticks per section (push, sort, bookkeeping, walk, epilogue)
+template <int YPS, int K, bool STATS>
+__global__ __launch_bounds__(64) void clim_sorted_f32(
+    const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
+    const uint32_t* __restrict__ sflags, int32_t step_min, const DevChunk* __restrict__ chunks, double q, int negate,
+    int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
+    uint32_t* __restrict__ redo_bits, int64_t redo_ld, unsigned long long* __restrict__ stats) {
+    constexpr int R = 11;                        // w = 5
+    constexpr int NL = 6;                        // list slots per lane (lane 1 owns 5 and a dummy)
+    constexpr int HE = (YPS + 1) / 2 * 2;        // keys per lane, padded to an even count
+    constexpr int HH = HE / 2;                   // sorted keys per lane after the exchange
+    constexpr int KW = K + 2;                    // words per list and cell: +inf, K keys, 0
+    constexpr int NTP = 2 * YPS;
+    constexpr uint32_t LSTRIDE = 32 * 4;         // bytes between consecutive positions of a list
+    constexpr uint32_t LBYTES = KW * LSTRIDE;    // bytes per list (32 cells)
+    static_assert(K <= HE, "a list cannot store more keys than a cell pushes");
+    __shared__ __attribute__((aligned(16))) uint32_t lds[R * KW * 32 + 64];
+
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 1;
+    const int cw = lane >> 1;
+    const int64_t cell = static_cast<int64_t>(blockIdx.x) * 32 + cw;
+    const bool cell_ok = cell < C;
+    const DevChunk ch = chunks[blockIdx.y];
+    const float* col = ts + (cell_ok ? cell : C - 1);
+    const uint32_t sgnflip = negate ? 0x80000000u : 0u;
+    const uint32_t tmax = static_cast<uint32_t>(Tn - 1);
+    const bool padded_last = (YPS - 1) * 2 + sub >= ntracks;
+    const uint32_t* tab = table + sub;
+
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u32*)lds));
+    const uint32_t lcell = lds0 + static_cast<uint32_t>(cw) * 4u;              // word 0 of list 0 of this cell
+    const uint32_t ldummy = lds0 + R * LBYTES + static_cast<uint32_t>(cw) * 4u; // [+inf][0], LSTRIDE apart
+    // ---- LDS: every list empty (keys 0 = invalid), sentinels in place ------------------------------------
+    for (int i = lane; i < R * KW * 32 + 64; i += 64) {
+        const int pos = (i / 32) % KW;
+        lds[i] = (i < R * KW * 32) ? (pos == 0 ? 0xFFFFFFFFu : 0u) : (i < R * KW * 32 + 32 ? 0xFFFFFFFFu : 0u);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    // own list slots: global slot g = sub * NL + j; P[j] = byte address of the first key OUTSIDE the top set
+    V8 P;
+    uint32_t ltop[NL];                           // address of the list's upper sentinel (word 0)
+    double rsum[NL];
+    uint32_t nvl[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int g = sub * NL + j;
+        ltop[j] = (g < R) ? lcell + static_cast<uint32_t>(g) * LBYTES : ldummy;
+        P[j] = (g < R) ? ltop[j] + LSTRIDE : ldummy + LSTRIDE;
+        rsum[j] = 0.0;
+        nvl[j] = 0;
+    }
+    P[6] = 0;
+    P[7] = 0;
+    // (the lower sentinel of the last own list: lane 1's is the dummy's, right behind its upper one)
+    const uint32_t lbot_last = (sub * NL + NL - 1 < R) ? ltop[NL - 1] + (K + 1) * LSTRIDE : ldummy + LSTRIDE;
+    uint32_t truncmask = 0;
+    // cell-level state, the same in both lanes
+    uint32_t Ctop = 0, n = 0, B = 0;
+    double total = 0.0;
+
+    // ---- sample addresses: a 64-bit pointer per track ------------------------------------------------------
+    const uint32_t ld4 = static_cast<uint32_t>(ld) * 4u;
+    const char* ap[YPS];
+    auto entries_of = [&](int32_t step, uint32_t (&e)[YPS]) {
+        const uint32_t* p = tab + static_cast<int64_t>(step - step_min) * NTP;
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) e[y] = p[y * 2];
+    };
+    auto point_at = [&](int32_t step) {
+        uint32_t e[YPS];
+        entries_of(step, e);
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) {
+            const uint32_t t = umin((e[y] >> 1) - 2u, tmax);
+            ap[y] = reinterpret_cast<const char*>(col) + static_cast<uint64_t>(t) * ld4;
+        }
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) ap[y] += (y == YPS - 1 && padded_last) ? 0u : ld4;
+    };
+    float x_in[YPS];
+    auto request = [&]() {
+#pragma unroll
+        for (int y = 0; y < YPS; ++y) x_in[y] = *reinterpret_cast<const float*>(ap[y]);
+    };
+    point_at(ch.warm_start);
+    request();
+
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0};
+    unsigned long long tlast = 0;
+    if constexpr (STATS) tlast = __builtin_amdgcn_s_memtime();
+    auto tick = [&](int idx) {
+        if constexpr (STATS) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tacc[idx] += now - tlast;
+            tlast = now;
+        }
+    };
+    uint32_t st_rows = 0, st_iter = 0, st_flag = 0, st_steps = 0;
+
+    int m = (ch.warm_start - step_min) % R;
+    uint32_t sf_cur = __builtin_amdgcn_readfirstlane(sflags[ch.warm_start - step_min]);
+    for (int32_t s = ch.warm_start; s < ch.end; ++s) {
+        const uint32_t sf = sf_cur;
+        const uint32_t sf_nxt = s + 1 < ch.end ? __builtin_amdgcn_readfirstlane(sflags[s + 1 - step_min]) : 0u;
+        // ---- 1. this row's samples -> keys (0 = invalid: NaN, outside [0, T), padding), their sum and count --------
+        uint32_t k[HE];
+        double din = 0.0;
+        uint32_t nvin = 0;
+        if (sf & 1u) {
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) {
+                const float xv = __uint_as_float(__float_as_uint(x_in[y]) ^ sgnflip);
+                const bool ok = xv == xv && !(y == YPS - 1 && padded_last);
+                k[y] = ok ? f32_key(xv) : 0u;
+                din += ok ? static_cast<double>(xv) : 0.0;
+                nvin += ok ? 1u : 0u;
+            }
+        } else {
+            uint32_t e[YPS];
+            entries_of(s, e);
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) {
+                const float xv = __uint_as_float(__float_as_uint(x_in[y]) ^ sgnflip);
+                const bool ok = xv == xv && (e[y] >> 1) >= 2u;
+                k[y] = ok ? f32_key(xv) : 0u;
+                din += ok ? static_cast<double>(xv) : 0.0;
+                nvin += ok ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int y = YPS; y < HE; ++y) k[y] = 0u;
+        // prefetch: the samples of step s + 1, into the same registers
+        if (s + 1 < ch.end) {
+            if (sf_nxt & 2u) advance();
+            else point_at(s + 1);
+            request();
+        }
+        tick(0);
+
+        // ---- 2. sort: descending inside the lane, then one bitonic exchange between the two lanes of the cell ------
+        sortnet::Desc<HE>::run(k);
+        uint32_t t[HE];
+#pragma unroll
+        for (int i = 0; i < HE; ++i) t[i] = umax(k[i], swp(k[HE - 1 - i]));      // the HE largest of the cell (bitonic)
+        uint32_t u[HH];
+        {
+            const uint32_t bnd = sub ? 0u : 0xFFFFFFFFu;                          // lane 0 keeps the larger half
+#pragma unroll
+            for (int i = 0; i < HH; ++i) u[i] = med3u(t[i], t[i + HH], bnd);
+        }
+        sortnet::Desc<HH>::run(u);           // lane 0: positions 0..HH-1, lane 1: HH..HE-1 of the cell's sorted keys
+        tick(1);
+
+        // ---- 3. the new list replaces the list in slot m ----------------------------------------------------------
+        const int m_sub = m >= NL ? 1 : 0;
+        const int mj = __builtin_amdgcn_readfirstlane(m - m_sub * NL);
+        const bool own_m = sub == m_sub;
+        const uint32_t base_m = lcell + static_cast<uint32_t>(m) * LBYTES;
+#pragma unroll
+        for (int i = 0; i < HH; ++i) {
+            // (position sub * HH + i of the list; positions >= K are not stored)
+            if (i < K - HH) lds_st(base_m + static_cast<uint32_t>(1 + sub * HH + i) * LSTRIDE, u[i]);
+            else if (i < K && sub == 0) lds_st(base_m + static_cast<uint32_t>(1 + i) * LSTRIDE, u[i]);
+        }
+        // what leaves: the evicted list's share of the top set, its valid keys, its sum
+        uint32_t c_old = 0, nv_old = 0;
+        double rs_old = 0.0;
+        {
+            const uint32_t Pm = P[mj];
+            uint32_t nvm = 0;
+            double rsm = 0.0;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                nvm = (j == mj) ? nvl[j] : nvm;
+                rsm = (j == mj) ? rsum[j] : rsm;
+            }
+            if (own_m) {
+                c_old = ((Pm - base_m) >> 7) - 1u;
+                nv_old = nvm;
+                rs_old = rsm;
+            }
+        }
+        // what comes: keys above the carried boundary join the top set
+        uint32_t c_new = 0;
+#pragma unroll
+        for (int i = 0; i < HH; ++i) c_new += (u[i] > B) ? 1u : 0u;
+        {
+            uint32_t pk = (c_new << 16) | nvin;
+            uint32_t po = (c_old << 16) | nv_old;
+            pk += swp(pk);
+            po += swp(po);
+            c_new = umin(pk >> 16, static_cast<uint32_t>(K));
+            nvin = pk & 0xFFFFu;
+            c_old = po >> 16;
+            nv_old = po & 0xFFFFu;
+        }
+        din += swp(din);
+        rs_old += swp(rs_old);
+        Ctop += c_new - c_old;
+        n += nvin - nv_old;
+        total += din - rs_old;
+        P[mj] = own_m ? base_m + (1u + c_new) * LSTRIDE : P[mj];
+        if (own_m) truncmask = (truncmask & ~(1u << mj)) | ((nvin > static_cast<uint32_t>(K) ? 1u : 0u) << mj);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            nvl[j] = (own_m && j == mj) ? nvin : nvl[j];
+            rsum[j] = (own_m && j == mj) ? din : rsum[j];
+        }
+        if (!(fabs(total) <= 1.7976931348623157e308)) {
+            // an infinity in the pool, or one that has just left it: the total is taken from the list sums again
+            double tsum = 0.0;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) tsum += rsum[j];
+            total = tsum + swp(tsum);
+        }
+        m = (m + 1 == R) ? 0 : m + 1;
+        tick(2);
+
+        // ---- 4. move the pointers until the top set holds Cs keys: a parallel merge-select ------------------------
+        const uint32_t nn = n ? n : 1u;
+        const double vi = static_cast<double>(nn - 1) * q;
+        const double fl = floor(vi);
+        const double g = vi - fl;
+        const uint32_t lo = static_cast<uint32_t>(fl);
+        const bool need2 = lo + 1 < nn;
+        const uint32_t Cs = n ? n - 1u - lo : 0u;
+        // Direction of the cell: GROW (keys join the top set, largest first) or SHRINK (keys leave it, smallest first).
+        // Shrinking cells work on COMPLEMENTED keys, so that "the key that moves next" is the largest one for everybody.
+        // (a cell whose top set is right already counts as growing by 0)
+        const bool grow = Ctop <= Cs;
+        uint32_t rem = grow ? Cs - Ctop : Ctop - Cs;
+        const uint32_t steps0 = rem;
+        const uint32_t cm = grow ? 0u : 0xFFFFFFFFu;
+        const int32_t dstep = grow ? static_cast<int32_t>(LSTRIDE) : -static_cast<int32_t>(LSTRIDE);
+        // min over the lists of the smallest key INSIDE the top set (the cells that move nowhere need both sides)
+        uint32_t um = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) um = umin(um, lds_ld(P[j] - LSTRIDE));
+        um = umin(um, swp(um));
+        uint32_t TL = 0, TN = 0;       // complemented space: the last key that moved, the key that would move next
+        bool flag = false;
+        bool pending = true;
+        while (__any(pending)) {
+            if constexpr (STATS) ++st_iter;
+            const uint32_t d = umin(rem, 11u);
+            // -- the W = 4 next keys of every own list, in the order they would move (addresses clamped to the
+            //    list's sentinels: +inf above, 0 below -- both the LOWEST key in the cell's own order)
+            uint32_t a[NL][4];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const int32_t topj = static_cast<int32_t>(ltop[j]);
+                const int32_t botj = j == NL - 1 ? static_cast<int32_t>(lbot_last) : topj + static_cast<int32_t>((K + 1) * LSTRIDE);
+                const int32_t A0 = static_cast<int32_t>(P[j]) - (grow ? 0 : static_cast<int32_t>(LSTRIDE));
+                a[j][0] = lds_ld(static_cast<uint32_t>(A0)) ^ cm;
+#pragma unroll
+                for (int i = 1; i < 4; ++i)
+                    a[j][i] = lds_ld(static_cast<uint32_t>(med3i(A0 + i * dstep, topj, botj))) ^ cm;
+            }
+            // -- the lane's 12 largest of its 24, sorted: a tree of merges of sorted runs
+            uint32_t s12[12];
+            {
+                uint32_t r01[8], r23[8], r45[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    r01[i] = a[0][i]; r01[4 + i] = a[1][i];
+                    r23[i] = a[2][i]; r23[4 + i] = a[3][i];
+                    r45[i] = a[4][i]; r45[4 + i] = a[5][i];
+                }
+                sortnet::MergeTop<4, 4, 8>::run(r01);
+                sortnet::MergeTop<4, 4, 8>::run(r23);
+                sortnet::MergeTop<4, 4, 8>::run(r45);
+                uint32_t r4[16];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { r4[i] = r01[i]; r4[8 + i] = r23[i]; }
+                sortnet::MergeTop<8, 8, 12>::run(r4);
+                uint32_t r6[20];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) r6[i] = r4[i];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) r6[12 + i] = r45[i];
+                sortnet::MergeTop<12, 8, 12>::run(r6);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) s12[i] = r6[i];
+            }
+            // -- the cell's 12 largest, sorted: lane 0 ends with ranks 0..5, lane 1 with ranks 6..11
+            uint32_t u6[6];
+            {
+                uint32_t t12[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) t12[i] = umax(s12[i], swp(s12[11 - i]));
+                const uint32_t lb = sub ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) u6[i] = med3u(t12[i], t12[i + 6], lb);
+                sortnet::BitonicDesc<6>::run(u6);
+            }
+            auto rank_of = [&](uint32_t r) -> uint32_t {       // the cell's key of rank r (0..11), 0 outside
+                const uint32_t idx = r - (sub ? 6u : 0u);
+                const uint32_t x01 = (idx & 1u) ? u6[1] : u6[0];
+                const uint32_t x23 = (idx & 1u) ? u6[3] : u6[2];
+                const uint32_t x45 = (idx & 1u) ? u6[5] : u6[4];
+                const uint32_t y = (idx & 2u) ? x23 : x01;
+                uint32_t z = (idx & 4u) ? x45 : y;
+                z = idx < 6u ? z : 0u;
+                return z | swp(z);
+            };
+            const uint32_t tl = rank_of(d - 1u);               // (d == 0: rank 0xFFFFFFFF is outside: 0)
+            const uint32_t tn = rank_of(d);
+            // -- how far the windows can be trusted: a key is SAFE if it is not below the largest fourth key
+            //    (whatever a list holds beyond its window is not above its fourth key)
+            uint32_t F = a[0][3];
+#pragma unroll
+            for (int j = 1; j < NL; ++j) F = umax(F, a[j][3]);
+            F = umax(F, swp(F));
+            const bool act = pending && d != 0u;
+            const bool unsafe = act && tl < F;                 // move only the safe keys this round, look again
+            const bool dry = act && !unsafe && tl == 0u;       // fewer than d keys left in the lists: give up
+            const bool tie = act && !unsafe && !dry && tl == tn;
+            const uint32_t th = unsafe ? F : tl;
+            uint32_t pj[NL];
+            uint32_t psum = 0;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                uint32_t c = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c += a[j][i] >= th ? 1u : 0u;
+                pj[j] = c;
+                psum += c;
+            }
+            if (__any(tie)) {
+                // the d-th and the (d+1)-th key are equal: of the keys equal to tl only d - #{keys above tl} move, lists in
+                // order (lane 0 first)
+                uint32_t gj[NL];
+                uint32_t gsum = 0;
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+                    uint32_t c = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) c += a[j][i] > tl ? 1u : 0u;
+                    gj[j] = c;
+                    gsum += c;
+                }
+                const uint32_t G = gsum + swp(gsum);
+                const uint32_t e_mine = psum - gsum;
+                const uint32_t e_other = swp(e_mine);
+                int32_t room = static_cast<int32_t>(d - G) - static_cast<int32_t>(sub ? e_other : 0u);   // ties this lane may still move
+                uint32_t ps2 = 0;
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+                    const int32_t ej = static_cast<int32_t>(pj[j] - gj[j]);
+                    const int32_t take = room < 0 ? 0 : (room < ej ? room : ej);
+                    room -= ej;
+                    const uint32_t pt = gj[j] + static_cast<uint32_t>(take);
+                    pj[j] = tie ? pt : pj[j];
+                    ps2 += pt;
+                }
+                psum = tie ? ps2 : psum;
+            }
+            const bool move = act && !dry;
+            uint32_t moved = move ? psum : 0u;
+            moved += swp(moved);
+#pragma unroll
+            for (int j = 0; j < NL; ++j)
+                P[j] = static_cast<uint32_t>(static_cast<int32_t>(P[j]) + (move ? static_cast<int32_t>(pj[j]) * dstep : 0));
+            rem -= moved;
+            if (dry) {
+                flag = true;
+                Ctop = grow ? Cs - rem : Cs + rem;
+                rem = 0;
+            }
+            if (pending) {
+                TL = (move && !unsafe) ? tl : TL;
+                // the key that would move next is known when this round moved everything that had to move and that
+                // key is safe; a round that moved keys looks again otherwise (with d = 0)
+                const bool done = dry || (rem == 0u && !unsafe && (d == 0u || tn >= F));
+                TN = tn;
+                pending = !done;
+            }
+        }
+        if (!flag) Ctop = Cs;
+        const uint32_t kl = TL ^ cm, kn = TN ^ cm;
+        const uint32_t a_lo = grow ? kn : kl;
+        uint32_t a_hi = grow ? (steps0 != 0u ? kl : um) : kn;
+        a_hi = need2 ? a_hi : a_lo;
+        B = a_lo;
+        {
+#pragma unroll
+            for (int j = 0; j < NL; ++j)
+                // a list stored to its last key, all of it inside the top set, with keys that were not stored
+                flag = flag || (P[j] == ltop[j] + (K + 1) * LSTRIDE && ((truncmask >> j) & 1u));     // (never the dummy: no bit)
+        }
+        flag = flag || swp(flag ? 1u : 0u) != 0u;
+        tick(3);
+
+        // ---- 5. output ---------------------------------------------------------------------------------------------
+        if (s >= ch.begin) {
+            if constexpr (STATS) {
+                ++st_rows;
+                st_steps += (sub == 0 && cell_ok) ? steps0 : 0u;
+                st_flag += (sub == 0 && cell_ok && flag) ? 1u : 0u;
+            }
+            double th = make_nan(), se = make_nan();
+            if (n > 0) {
+                const double v_lo = static_cast<double>(key_f32(a_lo));
+                const double v_hi = static_cast<double>(key_f32(a_hi));
+                th = numpy_lerp(v_lo, v_hi, g);
+                se = total / static_cast<double>(n);
+            }
+            if (sub == 0 && cell_ok) {
+                thresh[static_cast<int64_t>(s) * ldo + cell] = th;
+                seas[static_cast<int64_t>(s) * ldo + cell] = se;
+                if (flag && n > 0)
+                    atomicOr(&redo_bits[static_cast<int64_t>(s) * redo_ld + (cell >> 5)], 1u << (cell & 31));
+            }
+        }
+        tick(4);
+        sf_cur = sf_nxt;
+    }
+    if (STATS && stats != nullptr) {
+        if (lane == 0) {
+            atomicAdd(&stats[0], static_cast<unsigned long long>(st_rows));
+            atomicAdd(&stats[1], static_cast<unsigned long long>(st_iter));
+#pragma unroll
+            for (int i = 0; i < 5; ++i) atomicAdd(&stats[8 + i], tacc[i]);
+        }
+        if (sub == 0) {
+            atomicAdd(&stats[2], static_cast<unsigned long long>(st_flag));
+            atomicAdd(&stats[3], static_cast<unsigned long long>(st_steps));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+namespace {
+typedef void (*SortedKernel)(const float*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*, int32_t,
+                             const DevChunk*, double, int, int32_t, double*, double*, int64_t, uint32_t*, int64_t,
+                             unsigned long long*);
+struct SortedEntry { int yps, k; SortedKernel fn, fn_stats; };
+#ifdef XMHW_RING_STATS
+#define XMHW_SS(Y, K) clim_sorted_f32<Y, K, true>
+#else
+#define XMHW_SS(Y, K) nullptr
+#endif
+#define XMHW_S(Y, K) {Y, K, clim_sorted_f32<Y, K, false>, XMHW_SS(Y, K)}
+const SortedEntry kSorted[] = {
+    XMHW_S(20, 16),
+};
+#undef XMHW_S
+#undef XMHW_SS
+const SortedEntry* find_sorted(int32_t yps) {
+    for (const auto& e : kSorted)
+        if (e.yps == yps) return &e;
+    return nullptr;
+}
+}  // namespace
+
+int32_t sorted_pick_yps(int32_t w, int32_t ntracks) {
+    if (w != 5) return 0;
+    const int32_t yps = (ntracks + 1) / 2;
+    return find_sorted(yps) ? yps : 0;
+}
+
+hipError_t launch_sorted_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
+                             const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,
+                             int32_t w, int32_t yps, int32_t ntracks, double q, int negate, double* thresh, double* seas,
+                             int64_t ldo, uint32_t* redo_bits, int64_t redo_ld, hipStream_t stream,
+                             unsigned long long* stats) {
+    const SortedEntry* e = w == 5 ? find_sorted(yps) : nullptr;
+    if (!e || ld >= (int64_t(1) << 30) || !redo_bits) return hipErrorInvalidValue;
+    if (C <= 0 || nchunks <= 0) return hipSuccess;
+    dim3 grid(static_cast<unsigned>((C + 31) / 32), static_cast<unsigned>(nchunks));
+    const bool twin = stats != nullptr && e->fn_stats != nullptr;
+    hipLaunchKernelGGL(twin ? e->fn_stats : e->fn, grid, dim3(64), 0, stream, ts, C, ld, Tn, table, sflags, step_min,
+                       chunks, q, negate, ntracks, thresh, seas, ldo, redo_bits, redo_ld, twin ? stats : nullptr);
+    return hipGetLastError();
+}
+
+}  // namespace xmhw

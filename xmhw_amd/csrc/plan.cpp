@@ -102,36 +102,63 @@ std::vector<uint32_t> Plan::ring_table(int32_t subs, int32_t yps) const {
     return tab;
 }
 
-std::vector<Chunk> Plan::make_chunks(int32_t nchunks) const {
-    nchunks = std::max(1, std::min(nchunks, D));
-    // per (row, track) hold flags decide how far back a chunk must warm up:
-    // every track needs R-1 PUSH steps before the chunk's first row.
-    std::vector<std::vector<uint8_t>> hold(ntracks, std::vector<uint8_t>(D, 0));
+int32_t Plan::warm_start_for(int32_t begin) const {
+    if (R == 1) return begin;
+    int32_t ws = begin;
     for (int32_t k = 0; k < ntracks; ++k) {
         const int64_t tb = track_begin[k], te = track_end[k];
         const int32_t f = row_of_t[tb], l = row_of_t[te - 1];
-        std::vector<uint8_t> present(D, 0);
-        for (int64_t t = tb; t < te; ++t) present[row_of_t[t]] = 1;
-        for (int32_t r = f; r <= l; ++r) hold[k][r] = !present[r];
+        // rows of [f, l] at which the track has no centre are HOLD steps: they push nothing
+        std::vector<uint8_t> present(static_cast<size_t>(std::max(l - f + 1, 0)), 0);
+        for (int64_t t = tb; t < te; ++t) present[row_of_t[t] - f] = 1;
+        int32_t pushes = 0, s = begin;
+        while (pushes < R - 1 && s > step_min) {
+            --s;
+            const bool hold = s >= f && s <= l && !present[s - f];
+            if (!hold) ++pushes;
+        }
+        ws = std::min(ws, s);
     }
+    return std::max(ws, step_min);
+}
+
+std::vector<Chunk> Plan::make_chunks(int32_t nchunks) const {
+    nchunks = std::max(1, std::min(nchunks, D));
     std::vector<Chunk> out;
     for (int32_t j = 0; j < nchunks; ++j) {
         Chunk c;
         c.begin = static_cast<int32_t>(int64_t(D) * j / nchunks);
         c.end = static_cast<int32_t>(int64_t(D) * (j + 1) / nchunks);
         if (c.end <= c.begin) continue;
-        int32_t ws = c.begin;
-        for (int32_t k = 0; k < ntracks; ++k) {
-            int32_t pushes = 0, s = c.begin;
-            while (pushes < R - 1 && s > step_min) {
-                --s;
-                if (s < 0 || !hold[k][s]) ++pushes;
-            }
-            ws = std::min(ws, s);
-        }
-        if (R == 1) ws = c.begin;
-        c.warm_start = std::max(ws, step_min);
+        c.warm_start = warm_start_for(c.begin);
         out.push_back(c);
+    }
+    return out;
+}
+
+std::vector<Plan::Segment> Plan::sorted_segments() const {
+    const std::vector<uint32_t> tab = ring_table(1, ntracks);      // [step][track]
+    std::vector<uint8_t> regular(static_cast<size_t>(D), 1);
+    for (int32_t s = 0; s < D; ++s) {
+        bool ok = true;
+        for (int32_t k = 0; k < ntracks && ok; ++k) {
+            bool any_valid = false;
+            for (int32_t j = s - (R - 1); j <= s; ++j) {
+                const uint32_t e = tab[static_cast<size_t>(j - step_min) * ntracks + k];
+                if ((e >> 1) == kCodeHold) ok = false;
+                any_valid = any_valid || (e >> 1) >= 2u;
+            }
+            const uint32_t es = tab[static_cast<size_t>(s - step_min) * ntracks + k];
+            if (any_valid && !(es & 1u)) ok = false;
+        }
+        regular[s] = ok ? 1 : 0;
+    }
+    std::vector<Segment> out;
+    for (int32_t s = 0; s < D;) {
+        int32_t e = s;
+        while (e < D && regular[e] == regular[s]) ++e;
+        out.push_back({s, e, regular[s] != 0});
+        s = e;
     }
     return out;
 }

@@ -63,6 +63,14 @@ struct Plan {
     // bit 1 = CONSEC (every real track pushes the sample following the one it pushed at the previous step)
     std::vector<uint32_t> step_flags() const;
     std::vector<Chunk> make_chunks(int32_t nchunks) const;
+    // first step a ring kernel must execute so that every track has pushed R-1 samples before row `begin`
+    int32_t warm_start_for(int32_t begin) const;
+    // Rows the sorted-list kernel (kernels_sorted.hip) can serve.  Its pool is the union of the R last ROW-LISTS
+    // (what all tracks pushed at one step), so row s is REGULAR iff for every real track no step in [s-R+1, s] is a
+    // HOLD and a track that pushed a valid sample in that span is part of the row's pool.  Returns the maximal runs
+    // of rows, alternating, in ascending order.
+    struct Segment { int32_t begin, end; bool regular; };
+    std::vector<Segment> sorted_segments() const;
 };
 
 }  // namespace xmhw

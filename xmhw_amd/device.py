@@ -174,7 +174,7 @@ class DeviceBuffer:
 
 # include/xmhw_amd.h: XMHW_LAYOUT_*
 LAYOUTS = {"auto": -2, "ring1": -1, "ring2_8lane": 8, "ring2_4lane": 10, "ring2_16lane": 12,
-           "ring3_8lane": 20, "ring3_4lane": 21, "ring3_2lane": 22}
+           "ring3_8lane": 20, "ring3_4lane": 21, "ring3_2lane": 22, "sorted": 40}
 
 
 class Plan:
