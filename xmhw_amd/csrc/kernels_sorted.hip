@@ -66,6 +66,13 @@ __device__ __forceinline__ int32_t med3i(int32_t a, int32_t b, int32_t c) {
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
+// key of a non-NaN float in two instructions (v_ashrrev, v_bitop3: (sign | 0x80000000) ^ bits)
+__device__ __forceinline__ uint32_t key_fast(uint32_t b) {
+    int32_t sg;
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(sg) : "v"(b));
+    return static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(sg, static_cast<int32_t>(b), static_cast<int32_t>(0x80000000u), 0x36));
+}
+
 typedef uint32_t V8 __attribute__((ext_vector_type(8)));
 
 }  // namespace
@@ -82,11 +89,12 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
     constexpr int NL = 6;                        // list slots per lane (lane 1 owns 5 and a dummy)
     constexpr int HE = (YPS + 1) / 2 * 2;        // keys per lane, padded to an even count
     constexpr int HH = HE / 2;                   // sorted keys per lane after the exchange
+    constexpr int KH = K / 2;                    // keys of the new list a lane ends with
     constexpr int KW = K + 2;                    // words per list and cell: +inf, K keys, 0
     constexpr int NTP = 2 * YPS;
     constexpr uint32_t LSTRIDE = 32 * 4;         // bytes between consecutive positions of a list
     constexpr uint32_t LBYTES = KW * LSTRIDE;    // bytes per list (32 cells)
-    static_assert(K <= HE, "a list cannot store more keys than a cell pushes");
+    static_assert(K <= HE && K % 2 == 0, "a list stores an even number of keys, at most what a lane holds");
     __shared__ __attribute__((aligned(16))) uint32_t lds[R * KW * 32 + 64];
 
     const int lane = threadIdx.x & 63;
@@ -99,6 +107,7 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
     const uint32_t sgnflip = negate ? 0x80000000u : 0u;
     const uint32_t tmax = static_cast<uint32_t>(Tn - 1);
     const bool padded_last = (YPS - 1) * 2 + sub >= ntracks;
+    const uint32_t padmask = padded_last ? 0xFFFFFFFFu : 0u;
     const uint32_t* tab = table + sub;
 
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u32*)lds));
@@ -168,9 +177,12 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
     if constexpr (STATS) tlast = __builtin_amdgcn_s_memtime();
     auto tick = [&](int idx) {
         if constexpr (STATS) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             tacc[idx] += now - tlast;
             tlast = now;
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     uint32_t st_rows = 0, st_iter = 0, st_flag = 0, st_steps = 0;
@@ -184,18 +196,35 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
         uint32_t k[HE];
         double din = 0.0;
         uint32_t nvin = 0;
-        if (sf & 1u) {
+        bool slow = !(sf & 1u);
+        if (!slow) {
+            // a plain row: every real track pushes a sample; NaN shows in the sum (so does +inf next to -inf: those
+            // rows take the general path below, which gives the same keys)
 #pragma unroll
             for (int y = 0; y < YPS; ++y) {
-                const float xv = __uint_as_float(__float_as_uint(x_in[y]) ^ sgnflip);
-                const bool ok = xv == xv && !(y == YPS - 1 && padded_last);
-                k[y] = ok ? f32_key(xv) : 0u;
-                din += ok ? static_cast<double>(xv) : 0.0;
-                nvin += ok ? 1u : 0u;
+                uint32_t xb = __float_as_uint(x_in[y]) ^ sgnflip;
+                uint32_t ky = key_fast(xb);
+                if (y == YPS - 1) {
+                    xb &= ~padmask;
+                    ky &= ~padmask;
+                }
+                k[y] = ky;
+                const double dv = static_cast<double>(__uint_as_float(xb));
+                din = y == 0 ? dv : din + dv;
             }
-        } else {
+            nvin = padded_last ? YPS - 1 : YPS;
+            slow = __any(din != din);
+        }
+        if (slow) {
             uint32_t e[YPS];
-            entries_of(s, e);
+            if (sf & 1u) {
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) e[y] = (y == YPS - 1 && padded_last) ? 2u : 4u;
+            } else {
+                entries_of(s, e);
+            }
+            din = 0.0;
+            nvin = 0;
 #pragma unroll
             for (int y = 0; y < YPS; ++y) {
                 const float xv = __uint_as_float(__float_as_uint(x_in[y]) ^ sgnflip);
@@ -215,18 +244,29 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
         }
         tick(0);
 
-        // ---- 2. sort: descending inside the lane, then one bitonic exchange between the two lanes of the cell ------
-        sortnet::Desc<HE>::run(k);
-        uint32_t t[HE];
-#pragma unroll
-        for (int i = 0; i < HE; ++i) t[i] = umax(k[i], swp(k[HE - 1 - i]));      // the HE largest of the cell (bitonic)
-        uint32_t u[HH];
+        // ---- 2. sort: the lane's K largest keys (two sorted halves, merged), then one bitonic exchange between the
+        // two lanes of the cell: lane 0 ends with ranks 0..K/2-1 of the cell's keys, lane 1 with ranks K/2..K-1
+        uint32_t u[KH];
         {
-            const uint32_t bnd = sub ? 0u : 0xFFFFFFFFu;                          // lane 0 keeps the larger half
+            uint32_t ka[HE];
+            {
+                uint32_t h0[HH], h1[HH];
 #pragma unroll
-            for (int i = 0; i < HH; ++i) u[i] = med3u(t[i], t[i + HH], bnd);
+                for (int i = 0; i < HH; ++i) { h0[i] = k[i]; h1[i] = k[HH + i]; }
+                sortnet::Desc<HH>::run(h0);
+                sortnet::Desc<HH>::run(h1);
+#pragma unroll
+                for (int i = 0; i < HH; ++i) { ka[i] = h0[i]; ka[HH + i] = h1[i]; }
+            }
+            sortnet::MergeTop<HH, HH, K>::run(ka);
+            uint32_t t[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) t[i] = umax(ka[i], swp(ka[K - 1 - i]));   // the K largest of the cell (bitonic)
+            const uint32_t lb = sub ? 0u : 0xFFFFFFFFu;                         // lane 0 keeps the larger half
+#pragma unroll
+            for (int i = 0; i < KH; ++i) u[i] = med3u(t[i], t[i + KH], lb);
+            sortnet::BitonicDesc<KH>::run(u);
         }
-        sortnet::Desc<HH>::run(u);           // lane 0: positions 0..HH-1, lane 1: HH..HE-1 of the cell's sorted keys
         tick(1);
 
         // ---- 3. the new list replaces the list in slot m ----------------------------------------------------------
@@ -235,11 +275,7 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
         const bool own_m = sub == m_sub;
         const uint32_t base_m = lcell + static_cast<uint32_t>(m) * LBYTES;
 #pragma unroll
-        for (int i = 0; i < HH; ++i) {
-            // (position sub * HH + i of the list; positions >= K are not stored)
-            if (i < K - HH) lds_st(base_m + static_cast<uint32_t>(1 + sub * HH + i) * LSTRIDE, u[i]);
-            else if (i < K && sub == 0) lds_st(base_m + static_cast<uint32_t>(1 + i) * LSTRIDE, u[i]);
-        }
+        for (int i = 0; i < KH; ++i) lds_st(base_m + static_cast<uint32_t>(1 + sub * KH + i) * LSTRIDE, u[i]);
         // what leaves: the evicted list's share of the top set, its valid keys, its sum
         uint32_t c_old = 0, nv_old = 0;
         double rs_old = 0.0;
@@ -261,7 +297,7 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
         // what comes: keys above the carried boundary join the top set
         uint32_t c_new = 0;
 #pragma unroll
-        for (int i = 0; i < HH; ++i) c_new += (u[i] > B) ? 1u : 0u;
+        for (int i = 0; i < KH; ++i) c_new += (u[i] > B) ? 1u : 0u;
         {
             uint32_t pk = (c_new << 16) | nvin;
             uint32_t po = (c_old << 16) | nv_old;
@@ -317,7 +353,7 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
         um = umin(um, swp(um));
         uint32_t TL = 0, TN = 0;       // complemented space: the last key that moved, the key that would move next
         bool flag = false;
-        bool pending = true;
+        bool pending = true, tn_ok = true;
         while (__any(pending)) {
             if constexpr (STATS) ++st_iter;
             const uint32_t d = umin(rem, 11u);
@@ -447,12 +483,19 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
             }
             if (pending) {
                 TL = (move && !unsafe) ? tl : TL;
-                // the key that would move next is known when this round moved everything that had to move and that
-                // key is safe; a round that moved keys looks again otherwise (with d = 0)
-                const bool done = dry || (rem == 0u && !unsafe && (d == 0u || tn >= F));
                 TN = tn;
-                pending = !done;
+                // (the key of rank d is the key that would move next unless a list has moved its whole window)
+                tn_ok = dry || d == 0u || tn >= F;
+                pending = !(dry || (rem == 0u && !unsafe));
             }
+        }
+        if (__any(!tn_ok)) {
+            // the key that would move next, from the lists' heads
+            uint32_t hx = 0;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) hx = umax(hx, lds_ld(P[j] - (grow ? 0u : LSTRIDE)) ^ cm);
+            hx = umax(hx, swp(hx));
+            TN = tn_ok ? TN : hx;
         }
         if (!flag) Ctop = Cs;
         const uint32_t kl = TL ^ cm, kn = TN ^ cm;
