@@ -187,11 +187,18 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
     };
     uint32_t st_rows = 0, st_iter = 0, st_flag = 0, st_steps = 0;
 
+    // inputs of the epilogue of the row this lane finishes
+    uint32_t e_alo = 0, e_ahi = 0, e_n = 0;
+    double e_total = 0.0, e_g = 0.0;
+    uint32_t e_flag = 0;
+
     int m = (ch.warm_start - step_min) % R;
     uint32_t sf_cur = __builtin_amdgcn_readfirstlane(sflags[ch.warm_start - step_min]);
+    uint32_t sf_nxt = ch.warm_start + 1 < ch.end ? __builtin_amdgcn_readfirstlane(sflags[ch.warm_start + 1 - step_min]) : 0u;
     for (int32_t s = ch.warm_start; s < ch.end; ++s) {
         const uint32_t sf = sf_cur;
-        const uint32_t sf_nxt = s + 1 < ch.end ? __builtin_amdgcn_readfirstlane(sflags[s + 1 - step_min]) : 0u;
+        // (the flags of step s + 2 are asked for a row ahead: nothing waits for them)
+        const uint32_t sf_nn = s + 2 < ch.end ? sflags[s + 2 - step_min] : 0u;
         // ---- 1. this row's samples -> keys (0 = invalid: NaN, outside [0, T), padding), their sum and count --------
         uint32_t k[HE];
         double din = 0.0;
@@ -519,22 +526,37 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
                 st_steps += (sub == 0 && cell_ok) ? steps0 : 0u;
                 st_flag += (sub == 0 && cell_ok && flag) ? 1u : 0u;
             }
-            double th = make_nan(), se = make_nan();
-            if (n > 0) {
-                const double v_lo = static_cast<double>(key_f32(a_lo));
-                const double v_hi = static_cast<double>(key_f32(a_hi));
-                th = numpy_lerp(v_lo, v_hi, g);
-                se = total / static_cast<double>(n);
+            // The epilogue (key -> value, numpy's lerp, the float64 division, the stores) is the same ~60 instructions for
+            // both lanes of a cell: they take turns -- lane `sub` keeps the inputs of the rows with (s - begin) % 2 == sub
+            // and every second row (and at the end of the chunk) each lane finishes ITS row.
+            const uint32_t eph = static_cast<uint32_t>(s - ch.begin) & 1u;
+            if (static_cast<uint32_t>(sub) == eph) {
+                e_alo = a_lo;
+                e_ahi = a_hi;
+                e_n = n;
+                e_total = total;
+                e_g = g;
+                e_flag = flag ? 1u : 0u;
             }
-            if (sub == 0 && cell_ok) {
-                thresh[static_cast<int64_t>(s) * ldo + cell] = th;
-                seas[static_cast<int64_t>(s) * ldo + cell] = se;
-                if (flag && n > 0)
-                    atomicOr(&redo_bits[static_cast<int64_t>(s) * redo_ld + (cell >> 5)], 1u << (cell & 31));
+            if (eph == 1u || s + 1 == ch.end) {
+                double th = make_nan(), se = make_nan();
+                if (e_n > 0) {
+                    const double v_lo = static_cast<double>(key_f32(e_alo));
+                    const double v_hi = static_cast<double>(key_f32(e_ahi));
+                    th = numpy_lerp(v_lo, v_hi, e_g);
+                    se = e_total / static_cast<double>(e_n);
+                }
+                if (static_cast<uint32_t>(sub) <= eph && cell_ok) {
+                    const int64_t row = static_cast<int64_t>(s) - static_cast<int64_t>(eph) + sub;
+                    thresh[row * ldo + cell] = th;
+                    seas[row * ldo + cell] = se;
+                    if (e_flag != 0u && e_n > 0) atomicOr(&redo_bits[row * redo_ld + (cell >> 5)], 1u << (cell & 31));
+                }
             }
         }
         tick(4);
         sf_cur = sf_nxt;
+        sf_nxt = __builtin_amdgcn_readfirstlane(sf_nn);
     }
     if (STATS && stats != nullptr) {
         if (lane == 0) {
