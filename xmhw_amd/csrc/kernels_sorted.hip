@@ -363,10 +363,11 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
         bool pending = true, tn_ok = true;
         while (__any(pending)) {
             if constexpr (STATS) ++st_iter;
-            const uint32_t d = umin(rem, 11u);
+            const uint32_t d = umin(rem, 15u);
             // -- the W = 4 next keys of every own list, in the order they would move (addresses clamped to the
             //    list's sentinels: +inf above, 0 below -- both the LOWEST key in the cell's own order)
             uint32_t a[NL][4];
+            uint32_t F = 0;            // the largest FIFTH key: whatever the lists hold beyond the windows is not above it
 #pragma unroll
             for (int j = 0; j < NL; ++j) {
                 const int32_t topj = static_cast<int32_t>(ltop[j]);
@@ -376,9 +377,10 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
 #pragma unroll
                 for (int i = 1; i < 4; ++i)
                     a[j][i] = lds_ld(static_cast<uint32_t>(med3i(A0 + i * dstep, topj, botj))) ^ cm;
+                F = umax(F, lds_ld(static_cast<uint32_t>(med3i(A0 + 4 * dstep, topj, botj))) ^ cm);
             }
-            // -- the lane's 12 largest of its 24, sorted: a tree of merges of sorted runs
-            uint32_t s12[12];
+            // -- the lane's 16 largest of its 24, sorted: a tree of merges of sorted runs
+            uint32_t s16[16];
             {
                 uint32_t r01[8], r23[8], r45[8];
 #pragma unroll
@@ -393,44 +395,42 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
                 uint32_t r4[16];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { r4[i] = r01[i]; r4[8 + i] = r23[i]; }
-                sortnet::MergeTop<8, 8, 12>::run(r4);
-                uint32_t r6[20];
+                sortnet::MergeTop<8, 8, 16>::run(r4);
+                uint32_t r6[24];
 #pragma unroll
-                for (int i = 0; i < 12; ++i) r6[i] = r4[i];
+                for (int i = 0; i < 16; ++i) r6[i] = r4[i];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) r6[12 + i] = r45[i];
-                sortnet::MergeTop<12, 8, 12>::run(r6);
+                for (int i = 0; i < 8; ++i) r6[16 + i] = r45[i];
+                sortnet::MergeTop<16, 8, 16>::run(r6);
 #pragma unroll
-                for (int i = 0; i < 12; ++i) s12[i] = r6[i];
+                for (int i = 0; i < 16; ++i) s16[i] = r6[i];
             }
-            // -- the cell's 12 largest, sorted: lane 0 ends with ranks 0..5, lane 1 with ranks 6..11
-            uint32_t u6[6];
+            // -- the cell's 16 largest, sorted: lane 0 ends with ranks 0..7, lane 1 with ranks 8..15
+            uint32_t u8[8];
             {
-                uint32_t t12[12];
+                uint32_t t16[16];
 #pragma unroll
-                for (int i = 0; i < 12; ++i) t12[i] = umax(s12[i], swp(s12[11 - i]));
+                for (int i = 0; i < 16; ++i) t16[i] = umax(s16[i], swp(s16[15 - i]));
                 const uint32_t lb = sub ? 0u : 0xFFFFFFFFu;
 #pragma unroll
-                for (int i = 0; i < 6; ++i) u6[i] = med3u(t12[i], t12[i + 6], lb);
-                sortnet::BitonicDesc<6>::run(u6);
+                for (int i = 0; i < 8; ++i) u8[i] = med3u(t16[i], t16[i + 8], lb);
+                sortnet::BitonicDesc<8>::run(u8);
             }
-            auto rank_of = [&](uint32_t r) -> uint32_t {       // the cell's key of rank r (0..11), 0 outside
-                const uint32_t idx = r - (sub ? 6u : 0u);
-                const uint32_t x01 = (idx & 1u) ? u6[1] : u6[0];
-                const uint32_t x23 = (idx & 1u) ? u6[3] : u6[2];
-                const uint32_t x45 = (idx & 1u) ? u6[5] : u6[4];
-                const uint32_t y = (idx & 2u) ? x23 : x01;
-                uint32_t z = (idx & 4u) ? x45 : y;
-                z = idx < 6u ? z : 0u;
+            auto rank_of = [&](uint32_t r) -> uint32_t {       // the cell's key of rank r (0..15), 0 outside
+                const uint32_t idx = r - (sub ? 8u : 0u);
+                const uint32_t x01 = (idx & 1u) ? u8[1] : u8[0];
+                const uint32_t x23 = (idx & 1u) ? u8[3] : u8[2];
+                const uint32_t x45 = (idx & 1u) ? u8[5] : u8[4];
+                const uint32_t x67 = (idx & 1u) ? u8[7] : u8[6];
+                const uint32_t y0 = (idx & 2u) ? x23 : x01;
+                const uint32_t y1 = (idx & 2u) ? x67 : x45;
+                uint32_t z = (idx & 4u) ? y1 : y0;
+                z = idx < 8u ? z : 0u;
                 return z | swp(z);
             };
             const uint32_t tl = rank_of(d - 1u);               // (d == 0: rank 0xFFFFFFFF is outside: 0)
             const uint32_t tn = rank_of(d);
-            // -- how far the windows can be trusted: a key is SAFE if it is not below the largest fourth key
-            //    (whatever a list holds beyond its window is not above its fourth key)
-            uint32_t F = a[0][3];
-#pragma unroll
-            for (int j = 1; j < NL; ++j) F = umax(F, a[j][3]);
+            // -- how far the windows can be trusted: a key is SAFE if it is not below the largest fifth key
             F = umax(F, swp(F));
             const bool act = pending && d != 0u;
             const bool unsafe = act && tl < F;                 // move only the safe keys this round, look again
