@@ -89,6 +89,9 @@ struct xmhw_plan {
     int64_t sorted_waves = -1;              // the grid width the sorted chunks were cut for
     uint32_t* d_redo = nullptr;
     size_t redo_words = 0;
+    unsigned long long* d_redo_list = nullptr;   // (row, cell) entries of the flagged cell-rows + their counter
+    uint32_t* d_redo_count = nullptr;
+    uint32_t redo_cap = 0;
 
     ~xmhw_plan() {
         if (d_stats) (void)hipFree(d_stats);
@@ -96,6 +99,8 @@ struct xmhw_plan {
         if (d_chunks_s) (void)hipFree(d_chunks_s);
         if (d_chunks_i) (void)hipFree(d_chunks_i);
         if (d_redo) (void)hipFree(d_redo);
+        if (d_redo_list) (void)hipFree(d_redo_list);
+        if (d_redo_count) (void)hipFree(d_redo_count);
         if (d_narrow_flag) (void)hipFree(d_narrow_flag);
         if (d_tablex) (void)hipFree(d_tablex);
         if (d_table) (void)hipFree(d_table);
@@ -339,6 +344,18 @@ int upload_sorted(xmhw_plan* p, int64_t C) {
         HIP_TRY(hipMalloc(&p->d_redo, sizeof(uint32_t) * words));
         p->redo_words = words;
     }
+    if (p->nchunks_s > 0) {
+        // the work list of the flagged cell-rows: one entry per 64 cell-rows (the sorted kernel flags well under 0.1 %
+        // of them on SST-like data; what does not fit goes the slow way, kernels_redo.hip)
+        if (!p->d_redo_count) HIP_TRY(hipMalloc(&p->d_redo_count, sizeof(uint32_t)));
+        const size_t want = std::max<size_t>(4096, static_cast<size_t>(h.D) * static_cast<size_t>(C) / 64);
+        const uint32_t cap = static_cast<uint32_t>(std::min<size_t>(want, size_t(1) << 28));
+        if (cap > p->redo_cap) {
+            if (p->d_redo_list) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p->d_redo_list)); p->d_redo_list = nullptr; p->redo_cap = 0; }
+            HIP_TRY(hipMalloc(&p->d_redo_list, sizeof(unsigned long long) * cap));
+            p->redo_cap = cap;
+        }
+    }
     return XMHW_OK;
 }
 
@@ -475,9 +492,9 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
             // (XMHW_SORTED_NOREDO=1: timing experiments only -- flagged cell-rows keep the sorted kernel's own answer)
             static const bool noredo = [] { const char* v = std::getenv("XMHW_SORTED_NOREDO"); return v && v[0] == '1'; }();
             if (e == hipSuccess && sorted && !noredo)
-                e = xmhw::launch_generic_flagged<float>(reinterpret_cast<const float*>(ts), h.T, C, ld, plan->d_row_ptr,
-                                                        plan->d_centres, 0, h.D, h.w, q, negate, thresh, seas, ldo,
-                                                        plan->d_redo, redo_ld, st);
+                e = xmhw::launch_redo(reinterpret_cast<const float*>(ts), h.T, C, ld, plan->d_row_ptr, plan->d_centres, h.D,
+                                      h.w, q, negate, thresh, seas, ldo, plan->d_redo, redo_ld, plan->d_redo_list,
+                                      plan->d_redo_count, plan->redo_cap, st);
         } else {
             // float64 input: if every sample is float32-representable (decoded int16 / float32
             // archives) the float32 kernel gives the same pools at 2.7x the rate.  All decisions are

@@ -74,6 +74,12 @@ hipError_t launch_generic_flagged(const T* ts, int64_t Tn, int64_t C, int64_t ld
                                   double* thresh, double* seas, int64_t ldo, const uint32_t* bits, int64_t ldb,
                                   hipStream_t stream);
 
+// the cell-rows flagged in `bits` recomputed exactly (kernels_redo.hip): work list (cap entries) + counter are scratch
+hipError_t launch_redo(const float* ts, int64_t Tn, int64_t C, int64_t ld, const int32_t* row_ptr, const int32_t* centres,
+                       int32_t D, int32_t w, double q, int negate, double* thresh, double* seas, int64_t ldo,
+                       uint32_t* bits, int64_t ldb, unsigned long long* list, uint32_t* count, uint32_t cap,
+                       hipStream_t stream);
+
 // fourth-generation float32 ring kernel (kernels_ring4.hip): a windowed key store in LDS instead of histogram + band
 // compaction; same lane layouts and step tables as the third generation (ring2 variants 30 / 31 / 32 = 8 / 4 / 2 lanes)
 int32_t ring4_pick_yps(int32_t w, int32_t ntracks, int32_t subs);

@@ -105,9 +105,9 @@ __global__ __launch_bounds__(256) void clim_generic(const T* __restrict__ ts, in
     seas[static_cast<int64_t>(row) * ldo + c] = se;
 }
 
-// The same for the cell-rows FLAGGED by the sorted-list kernel (kernels_sorted.hip: a list too short for the row):
-// bits[row * ldb + (c >> 5)] bit (c & 31).  A wave looks at its 64 cells' two words and leaves unless one is set;
-// rows [row0, row0 + gridDim.y).
+// The same for the cell-rows still FLAGGED in the sorted-list kernel's bitmap after kernels_redo.hip has taken what
+// fits its work list: bits[row * ldb + (c >> 5)] bit (c & 31).  Thread per bitmap WORD (the bitmap is nearly always
+// empty by now: the launch costs one read of it); a thread walks the set bits of its word one cell-row after the other.
 template <typename T>
 __global__ __launch_bounds__(256) void clim_generic_flagged(const T* __restrict__ ts, int64_t Tn, int64_t C,
                                                             int64_t ld, const int32_t* __restrict__ row_ptr,
@@ -115,16 +115,21 @@ __global__ __launch_bounds__(256) void clim_generic_flagged(const T* __restrict_
                                                             double q, int negate, double* __restrict__ thresh,
                                                             double* __restrict__ seas, int64_t ldo,
                                                             const uint32_t* __restrict__ bits, int64_t ldb,
-                                                            int32_t row0) {
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const int32_t row = row0 + static_cast<int32_t>(blockIdx.y);
-    if (c >= C) return;
-    const uint32_t word = bits[static_cast<int64_t>(row) * ldb + (c >> 5)];
-    if (((word >> (c & 31)) & 1u) == 0u) return;
-    double th, se;
-    generic_cell_row<T>(ts + c, Tn, ld, row_ptr, centres, row, w, q, negate, th, se);
-    thresh[static_cast<int64_t>(row) * ldo + c] = th;
-    seas[static_cast<int64_t>(row) * ldo + c] = se;
+                                                            int64_t nwords) {
+    const int64_t wi = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (wi >= nwords) return;
+    uint32_t word = bits[wi];
+    const int32_t row = static_cast<int32_t>(wi / ldb);
+    const int64_t c0 = (wi % ldb) * 32;
+    while (word != 0u) {
+        const int64_t c = c0 + __builtin_ctz(word);
+        word &= word - 1u;
+        if (c >= C) break;
+        double th, se;
+        generic_cell_row<T>(ts + c, Tn, ld, row_ptr, centres, row, w, q, negate, th, se);
+        thresh[static_cast<int64_t>(row) * ldo + c] = th;
+        seas[static_cast<int64_t>(row) * ldo + c] = se;
+    }
 }
 
 template <typename T>
@@ -144,9 +149,10 @@ hipError_t launch_generic_flagged(const T* ts, int64_t Tn, int64_t C, int64_t ld
                                   double* thresh, double* seas, int64_t ldo, const uint32_t* bits, int64_t ldb,
                                   hipStream_t stream) {
     if (C <= 0 || nrows <= 0) return hipSuccess;
-    dim3 grid(static_cast<unsigned>((C + 255) / 256), static_cast<unsigned>(nrows));
-    hipLaunchKernelGGL(clim_generic_flagged<T>, grid, dim3(256), 0, stream, ts, Tn, C, ld, row_ptr, centres, w, q,
-                       negate, thresh, seas, ldo, bits, ldb, row0);
+    (void)row0;      // (the bitmap covers rows [0, nrows))
+    const int64_t nwords = static_cast<int64_t>(nrows) * ldb;
+    hipLaunchKernelGGL(clim_generic_flagged<T>, dim3(static_cast<unsigned>((nwords + 255) / 256)), dim3(256), 0, stream, ts,
+                       Tn, C, ld, row_ptr, centres, w, q, negate, thresh, seas, ldo, bits, ldb, nwords);
     return hipGetLastError();
 }
 template hipError_t launch_generic_flagged<float>(const float*, int64_t, int64_t, int64_t, const int32_t*,

@@ -1,0 +1,136 @@
+// kernels_redo.hip -- the cell-rows the sorted-list kernel (kernels_sorted.hip) could not settle, recomputed exactly.
+//
+// The sorted kernel flags a cell-row in a bitmap (bits[row * ldb + (cell >> 5)], bit cell & 31) when a row-list was too
+// short for the row; its `seas` is right (sums do not depend on the lists), its `thresh` is not.  Three launches, no
+// host round trip:
+//   redo_collect   thread per bitmap word: every set bit becomes an entry (row, cell) of a work list (an atomic counter
+//                  hands out the slots) and is cleared; bits that do not fit the list stay set;
+//   redo_run       ONE WAVE per entry, a fixed grid striding over the list: the wave loads the row's pool (the samples
+//                  at centre +- w of every centre of the row: window_roll(), identify.py:184-209) -- seven keys per
+//                  lane --, builds the key of order statistic lo bit by bit with wave-wide counts (ballot + popcount:
+//                  the counts and every decision are scalar) and finds its successor; numpy's linear interpolation
+//                  (identify.py:233-235);
+//   clim_generic_flagged (kernels_generic.hip) on whatever is still set: only when the list overflowed.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace xmhw {
+
+__global__ __launch_bounds__(256) void redo_collect(uint32_t* __restrict__ bits, int64_t nwords, int64_t ldb,
+                                                    unsigned long long* __restrict__ list, uint32_t* __restrict__ count,
+                                                    uint32_t cap) {
+    const int64_t w = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    uint32_t word = bits[w];
+    if (word == 0u) return;
+    const uint64_t row = static_cast<uint64_t>(w / ldb);
+    const uint64_t cell0 = static_cast<uint64_t>(w % ldb) * 32u;
+    uint32_t left = word;
+    while (word != 0u) {
+        const uint32_t b = static_cast<uint32_t>(__builtin_ctz(word));
+        word &= word - 1u;
+        const uint32_t idx = atomicAdd(count, 1u);
+        if (idx < cap) {
+            list[idx] = (row << 40) | (cell0 + b);
+            left &= ~(1u << b);
+        }
+    }
+    bits[w] = left;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void redo_run(const T* __restrict__ ts, int64_t Tn, int64_t ld,
+                                                const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ centres,
+                                                int32_t w, double q, int negate, double* __restrict__ thresh, int64_t ldo,
+                                                const unsigned long long* __restrict__ list,
+                                                const uint32_t* __restrict__ count, uint32_t cap) {
+    using K = typename KeyOf<T>::type;
+    constexpr int KPL = 8;                      // keys per lane: pools of up to 512 samples
+    const int lane = threadIdx.x & 63;
+    const uint32_t nent = min(*count, cap);
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const int R = 2 * w + 1;
+    for (uint32_t e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); e < nent; e += nwaves) {
+        const unsigned long long ent = list[e];
+        const int32_t row = static_cast<int32_t>(ent >> 40);
+        const int64_t c = static_cast<int64_t>(ent & ((1ull << 40) - 1ull));
+        const int32_t cb = row_ptr[row], ce = row_ptr[row + 1];
+        const int32_t npool = (ce - cb) * R;
+        const T* col = ts + c;
+        K key[KPL];
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const int32_t p = lane + 64 * i;
+            K kk = 0;
+            if (p < npool) {
+                const int64_t t = static_cast<int64_t>(centres[cb + p / R]) + (p % R - w);
+                if (t >= 0 && t < Tn) {
+                    T v = col[t * ld];
+                    if (negate) v = -v;
+                    kk = KeyOf<T>::key(v);
+                }
+            }
+            key[i] = kk;
+        }
+        // (pools beyond KPL * 64 samples do not occur on plans the sorted kernel serves; such an entry is left alone)
+        if (npool > KPL * 64) continue;
+        uint32_t n = 0;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) n += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(key[i] != 0)));
+        double th = make_nan();
+        if (n > 0) {
+            const double vi = static_cast<double>(n - 1) * q;
+            const double fl = floor(vi);
+            const uint32_t lo = static_cast<uint32_t>(fl);
+            const double g = vi - fl;
+            K v = 0;
+            for (int bit = KeyOf<T>::bits - 1; bit >= 0; --bit) {
+                const K cand = v | (static_cast<K>(1) << bit);
+                uint32_t cnt = 0;       // valid keys < cand   (key 0 = invalid: (0 - 1) wraps high)
+#pragma unroll
+                for (int i = 0; i < KPL; ++i)
+                    cnt += static_cast<uint32_t>(__builtin_popcountll(
+                        __builtin_amdgcn_ballot_w64(static_cast<K>(key[i] - 1) < static_cast<K>(cand - 1))));
+                if (cnt <= lo) v = cand;
+            }
+            // v = key of a[lo]; a[lo + 1]: v again if it is duplicated past lo, else the smallest key above v
+            uint32_t cle = 0;
+            K mn = ~static_cast<K>(0);
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) {
+                cle += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(key[i] != 0 && key[i] <= v)));
+                if (key[i] > v && key[i] < mn) mn = key[i];
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const K o = static_cast<K>(__shfl_xor(static_cast<unsigned long long>(mn), off, 64));
+                mn = o < mn ? o : mn;
+            }
+            K vhi = v;
+            if (lo + 1 < n && cle < lo + 2) vhi = mn;
+            th = numpy_lerp(KeyOf<T>::value(v), KeyOf<T>::value(vhi), g);
+        }
+        if (lane == 0) thresh[static_cast<int64_t>(row) * ldo + c] = th;
+    }
+}
+
+hipError_t launch_redo(const float* ts, int64_t Tn, int64_t C, int64_t ld, const int32_t* row_ptr, const int32_t* centres,
+                       int32_t D, int32_t w, double q, int negate, double* thresh, double* seas, int64_t ldo,
+                       uint32_t* bits, int64_t ldb, unsigned long long* list, uint32_t* count, uint32_t cap,
+                       hipStream_t stream) {
+    if (C <= 0 || D <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const int64_t nwords = static_cast<int64_t>(D) * ldb;
+    hipLaunchKernelGGL(redo_collect, dim3(static_cast<unsigned>((nwords + 255) / 256)), dim3(256), 0, stream, bits, nwords,
+                       ldb, list, count, cap);
+    hipLaunchKernelGGL(redo_run<float>, dim3(2048), dim3(256), 0, stream, ts, Tn, ld, row_ptr, centres, w, q, negate,
+                       thresh, ldo, list, count, cap);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // whatever did not fit the list (bits still set): the thread-per-cell-row kernel
+    return launch_generic_flagged<float>(ts, Tn, C, ld, row_ptr, centres, 0, D, w, q, negate, thresh, seas, ldo, bits, ldb,
+                                         stream);
+}
+
+}  // namespace xmhw
