@@ -197,8 +197,8 @@ def test_float64_input_holding_float32_values_narrows_onto_the_ring3_kernel(dev)
     D = 366
 
     def run(arr, narrowing, neg=False, nchunks=0):
-        plan = Plan(doy, 5, kernel="ring", narrowing=narrowing, nchunks=nchunks)
-        assert plan.ring2_in_use() == 21
+        plan = Plan(doy, 5, kernel="ring", narrowing=narrowing, nchunks=nchunks, layout=21)     # (the ring3 kernel: the default
+        assert plan.ring2_in_use() == 21                                                        # float32 layout of this shape is 40)
         d_ts = DeviceBuffer.from_array(np.ascontiguousarray(arr))
         th, se = DeviceBuffer(8 * D * C), DeviceBuffer(8 * D * C)
         try:
