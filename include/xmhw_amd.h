@@ -140,6 +140,15 @@ int xmhw_plan_chunks_in_use(const xmhw_plan *plan, int64_t C, int32_t *nchunks);
  * table[nsteps][ntracks_padded] (see csrc/plan.h for the encoding)            */
 int xmhw_plan_table(const xmhw_plan *plan, int32_t years_per_lane, uint32_t *table_out,
                     int32_t *ntracks_padded);
+/* host copy of the sorted-list kernel's chunks and step table (XMHW_LAYOUT_SORTED; csrc/plan.h: sorted_plan) for
+ * inspection: the row axis cut wherever the set of pooled tracks changes (doy 60, the ends of partial years), every
+ * chunk with its own table rows -- what window_roll() + groupby("doy") pool (xmhw/identify.py:184-209, :233) restated
+ * per chunk.  `pieces` = how many pieces the whole row axis is cut into at least (1: only the cuts the calendar asks
+ * for).  Call with NULL outputs for the sizes: nchunks, nrows (table / flag rows), ntp (entries per row, track k at
+ * index k); then chunks_out[nchunks][4] = {warm_start, begin, end, trow0}, table_out[nrows][ntp], flags_out[nrows].
+ * XMHW_ERR_UNSUPPORTED if the kernel is not instantiated for this plan.                                          */
+int xmhw_plan_sorted_table(const xmhw_plan *plan, int32_t pieces, int32_t *nchunks, int32_t *nrows, int32_t *ntp,
+                           int32_t *chunks_out, uint32_t *table_out, uint32_t *flags_out);
 
 /* debug: ring-kernel pass counters {rows, 32-bit count passes, extractions, cold starts,
  * fast steps, 8-bit probes, code-ring rebuilds} per wave, then count passes summed over CELLS (what

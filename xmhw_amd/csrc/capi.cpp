@@ -83,7 +83,8 @@ struct xmhw_plan {
     // the chunks of the other rows (they stay on the ring kernel), the bitmap of cell-rows it hands to the generic kernel
     int32_t yps_s = 0;
     uint32_t* d_table_s = nullptr;
-    xmhw::DevChunk* d_chunks_s = nullptr;
+    xmhw::DevSortedChunk* d_chunks_s = nullptr;
+    uint32_t* d_sflags_s = nullptr;
     xmhw::DevChunk* d_chunks_i = nullptr;
     int32_t nchunks_s = 0, nchunks_i = 0;
     int64_t sorted_waves = -1;              // the grid width the sorted chunks were cut for
@@ -97,6 +98,7 @@ struct xmhw_plan {
         if (d_stats) (void)hipFree(d_stats);
         if (d_table_s) (void)hipFree(d_table_s);
         if (d_chunks_s) (void)hipFree(d_chunks_s);
+        if (d_sflags_s) (void)hipFree(d_sflags_s);
         if (d_chunks_i) (void)hipFree(d_chunks_i);
         if (d_redo) (void)hipFree(d_redo);
         if (d_redo_list) (void)hipFree(d_redo_list);
@@ -296,46 +298,30 @@ int upload_sorted(xmhw_plan* p, int64_t C) {
     const xmhw::Plan& h = p->host;
     if (!sorted_usable(p)) { p->nchunks_s = 0; return XMHW_OK; }
     const int32_t yps = xmhw::sorted_pick_yps(h.w, h.ntracks);
-    if (!p->d_table_s || p->yps_s != yps) {
-        if (p->d_table_s) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p->d_table_s)); p->d_table_s = nullptr; }
-        const std::vector<uint32_t> t = h.ring_table(2, yps);
-        HIP_TRY(hipMalloc(&p->d_table_s, sizeof(uint32_t) * t.size()));
-        HIP_TRY(hipMemcpy(p->d_table_s, t.data(), sizeof(uint32_t) * t.size(), hipMemcpyHostToDevice));
-        p->yps_s = yps;
-        p->sorted_waves = -1;
-    }
     const int64_t waves = (C + 31) / 32;
-    if (p->sorted_waves != waves) {
-        // regular runs -> chunks of the sorted kernel (cut so that a small grid still fills the chip: 6 waves per CU,
-        // every piece pays R - 1 warm-up rows); the other runs -> chunks of the ring kernel
-        const std::vector<xmhw::Plan::Segment> segs = h.sorted_segments();
-        std::vector<xmhw::DevChunk> cs, ci;
-        for (const auto& sg : segs) {
-            if (sg.regular) {
-                const int32_t len = sg.end - sg.begin;
-                int64_t pieces = h.nchunks_req > 0 ? h.nchunks_req : (1536 + waves - 1) / std::max<int64_t>(waves, 1);
-                pieces = std::max<int64_t>(1, std::min<int64_t>(pieces, len / 24));
-                for (int64_t j = 0; j < pieces; ++j) {
-                    const int32_t b = sg.begin + static_cast<int32_t>(len * j / pieces);
-                    const int32_t e = sg.begin + static_cast<int32_t>(len * (j + 1) / pieces);
-                    if (e > b) cs.push_back({b - (h.R - 1), b, e});
-                }
-            } else {
-                ci.push_back({h.warm_start_for(sg.begin), sg.begin, sg.end});
-            }
-        }
-        auto put = [](xmhw::DevChunk** dst, const std::vector<xmhw::DevChunk>& v) -> hipError_t {
-            if (*dst) { hipError_t e = hipFree(*dst); *dst = nullptr; if (e != hipSuccess) return e; }
-            if (v.empty()) return hipSuccess;
-            hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), sizeof(xmhw::DevChunk) * v.size());
-            if (e != hipSuccess) { *dst = nullptr; return e; }
-            return hipMemcpy(*dst, v.data(), sizeof(xmhw::DevChunk) * v.size(), hipMemcpyHostToDevice);
-        };
+    if (!p->d_table_s || p->yps_s != yps || p->sorted_waves != waves) {
+        // the kernel's own chunks and table rows (plan.h: sorted_plan); a small grid is cut into more pieces so that it
+        // still fills the chip (6 waves per CU; every piece pays R - 1 warm-up rows)
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(put(&p->d_chunks_s, cs));
-        HIP_TRY(put(&p->d_chunks_i, ci));
-        p->nchunks_s = static_cast<int32_t>(cs.size());
-        p->nchunks_i = static_cast<int32_t>(ci.size());
+        for (void** q : {reinterpret_cast<void**>(&p->d_table_s), reinterpret_cast<void**>(&p->d_sflags_s),
+                         reinterpret_cast<void**>(&p->d_chunks_s), reinterpret_cast<void**>(&p->d_chunks_i)})
+            if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
+        const int64_t pieces = h.nchunks_req > 0 ? h.nchunks_req : (1536 + waves - 1) / std::max<int64_t>(waves, 1);
+        const xmhw::Plan::SortedPlan sp = h.sorted_plan(2 * yps, 24, pieces);
+        p->nchunks_s = 0;
+        p->nchunks_i = 0;
+        if (!sp.chunks.empty()) {
+            std::vector<xmhw::DevSortedChunk> cs(sp.chunks.size());
+            for (size_t i = 0; i < cs.size(); ++i) cs[i] = {sp.chunks[i].warm_start, sp.chunks[i].begin, sp.chunks[i].end, sp.chunks[i].trow0};
+            HIP_TRY(hipMalloc(&p->d_table_s, sizeof(uint32_t) * sp.table.size()));
+            HIP_TRY(hipMemcpy(p->d_table_s, sp.table.data(), sizeof(uint32_t) * sp.table.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc(&p->d_sflags_s, sizeof(uint32_t) * sp.flags.size()));
+            HIP_TRY(hipMemcpy(p->d_sflags_s, sp.flags.data(), sizeof(uint32_t) * sp.flags.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc(&p->d_chunks_s, sizeof(xmhw::DevSortedChunk) * cs.size()));
+            HIP_TRY(hipMemcpy(p->d_chunks_s, cs.data(), sizeof(xmhw::DevSortedChunk) * cs.size(), hipMemcpyHostToDevice));
+            p->nchunks_s = static_cast<int32_t>(cs.size());
+        }
+        p->yps_s = yps;
         p->sorted_waves = waves;
     }
     const size_t words = static_cast<size_t>(h.D) * static_cast<size_t>(waves);
@@ -474,7 +460,7 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
                 e = hipMemsetAsync(plan->d_redo, 0, sizeof(uint32_t) * static_cast<size_t>(h.D) * static_cast<size_t>(redo_ld), st);
                 if (e == hipSuccess)
                     e = xmhw::launch_sorted_f32(reinterpret_cast<const float*>(ts), C, ld, h.T, plan->d_table_s,
-                                                plan->d_sflags, h.step_min, plan->d_chunks_s, plan->nchunks_s, h.w,
+                                                plan->d_sflags_s, plan->d_chunks_s, plan->nchunks_s, h.w,
                                                 plan->yps_s, h.ntracks, q, negate, thresh, seas, ldo, plan->d_redo, redo_ld,
                                                 st, plan->d_stats);
             }
@@ -1176,11 +1162,7 @@ int xmhw_plan_set_layout(xmhw_plan* plan, int32_t layout) {
 }
 int xmhw_plan_layout_in_use(const xmhw_plan* plan, int32_t* layout) {
     if (!plan || !layout) return fail(XMHW_ERR_INVALID, "NULL argument");
-    if (sorted_usable(plan)) {
-        bool any = false;
-        for (const auto& sg : plan->host.sorted_segments()) any = any || sg.regular;
-        if (any) { *layout = XMHW_LAYOUT_SORTED; return XMHW_OK; }
-    }
+    if (sorted_usable(plan)) { *layout = XMHW_LAYOUT_SORTED; return XMHW_OK; }
     const int32_t v2 = ring2_resolved(plan);
     const bool ring = resolve_kernel(plan, 4) == XMHW_KERNEL_RING;
     const int32_t y2 = v2 >= 0 ? xmhw::ring2_pick_yps(plan->host.w, plan->host.ntracks, v2) : 0;
@@ -1280,6 +1262,27 @@ int xmhw_plan_table(const xmhw_plan* plan, int32_t years_per_lane, uint32_t* tab
         std::vector<uint32_t> tab = plan->host.ring_table(kSubs, years_per_lane);
         std::memcpy(table_out, tab.data(), sizeof(uint32_t) * tab.size());
     }
+    return XMHW_OK;
+}
+
+int xmhw_plan_sorted_table(const xmhw_plan* plan, int32_t pieces, int32_t* nchunks, int32_t* nrows, int32_t* ntp,
+                           int32_t* chunks_out, uint32_t* table_out, uint32_t* flags_out) {
+    if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
+    const int32_t yps = xmhw::sorted_pick_yps(plan->host.w, plan->host.ntracks);
+    if (yps == 0) return fail(XMHW_ERR_UNSUPPORTED, "the sorted-list kernel is not instantiated for this window / record length");
+    const xmhw::Plan::SortedPlan sp = plan->host.sorted_plan(2 * yps, 24, std::max(pieces, 1));
+    if (nchunks) *nchunks = static_cast<int32_t>(sp.chunks.size());
+    if (nrows) *nrows = static_cast<int32_t>(sp.flags.size());
+    if (ntp) *ntp = 2 * yps;
+    if (chunks_out)
+        for (size_t i = 0; i < sp.chunks.size(); ++i) {
+            chunks_out[4 * i + 0] = sp.chunks[i].warm_start;
+            chunks_out[4 * i + 1] = sp.chunks[i].begin;
+            chunks_out[4 * i + 2] = sp.chunks[i].end;
+            chunks_out[4 * i + 3] = sp.chunks[i].trow0;
+        }
+    if (table_out) std::memcpy(table_out, sp.table.data(), sizeof(uint32_t) * sp.table.size());
+    if (flags_out) std::memcpy(flags_out, sp.flags.data(), sizeof(uint32_t) * sp.flags.size());
     return XMHW_OK;
 }
 

@@ -6,6 +6,8 @@
 namespace xmhw {
 
 struct DevChunk { int32_t warm_start, begin, end; };
+// a chunk of the sorted-list kernel: its table / flag rows start at trow0 (row of step warm_start)
+struct DevSortedChunk { int32_t warm_start, begin, end, trow0; };
 
 // generic kernel (any plan): thread per (cell, row)
 template <typename T>
@@ -60,11 +62,11 @@ hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
                             unsigned long long* stats = nullptr);
 
 // fifth generation (kernels_sorted.hip): sorted row-lists in LDS + a pointer walk; 2 lanes per cell, w = 5, float32,
-// REGULAR rows only (plan.h: sorted_segments); cell-rows it cannot settle are flagged in redo_bits
+// on its own chunks and table rows (plan.h: sorted_plan); cell-rows it cannot settle are flagged in redo_bits
 // [row * redo_ld + (cell >> 5)] for launch_generic_flagged
 int32_t sorted_pick_yps(int32_t w, int32_t ntracks);     // tracks per lane, 0 if not instantiated
 hipError_t launch_sorted_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
-                             const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,
+                             const uint32_t* sflags, const DevSortedChunk* chunks, int32_t nchunks,
                              int32_t w, int32_t yps, int32_t ntracks, double q, int negate, double* thresh, double* seas,
                              int64_t ldo, uint32_t* redo_bits, int64_t redo_ld, hipStream_t stream,
                              unsigned long long* stats = nullptr);

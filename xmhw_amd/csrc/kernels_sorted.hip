@@ -22,9 +22,9 @@
 // (kernels_generic.hip); the list state stays consistent (the hidden keys are all below the stored ones) and the cell
 // carries on by itself once the boundary has moved back.
 //
-// The kernel runs on REGULAR rows only (plan.cpp: sorted_segments): every real track pushes at each of the R steps that
-// feed the row and is part of the row's pool.  The rows around a held step (doy 60) and around the ends of partial
-// tracks stay on kernels_ring3.hip.
+// The kernel runs on its OWN chunks and step-table rows (plan.cpp: sorted_plan): the row axis is cut wherever the set
+// of pooled tracks changes (a held step -- doy 60 --, the ends of partial years); inside a chunk every pooled track
+// pushes at every row, warms up with its R-1 last pushes before the chunk, and the other tracks push nothing.
 //
 // Lane layout: lane = 2 * cell_in_wave + sub; a wave is 32 cells = one 128-byte line of a float32 sample row; a
 // workgroup is one wave.  Track k of the plan sits in lane sub = k % 2, slot k / 2 (the y-major table of the ring
@@ -82,7 +82,7 @@ typedef uint32_t V8 __attribute__((ext_vector_type(8)));
 template <int YPS, int K, bool STATS>
 __global__ __launch_bounds__(64) void clim_sorted_f32(
     const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
-    const uint32_t* __restrict__ sflags, int32_t step_min, const DevChunk* __restrict__ chunks, double q, int negate,
+    const uint32_t* __restrict__ sflags, const DevSortedChunk* __restrict__ chunks, double q, int negate,
     int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
     uint32_t* __restrict__ redo_bits, int64_t redo_ld, unsigned long long* __restrict__ stats) {
     constexpr int R = 11;                        // w = 5
@@ -102,7 +102,9 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
     const int cw = lane >> 1;
     const int64_t cell = static_cast<int64_t>(blockIdx.x) * 32 + cw;
     const bool cell_ok = cell < C;
-    const DevChunk ch = chunks[blockIdx.y];
+    const DevSortedChunk ch = chunks[blockIdx.y];
+    // (the chunk's own table and flag rows: row of step s = trow0 + s - warm_start)
+    const int32_t step_min = ch.warm_start - ch.trow0;
     const float* col = ts + (cell_ok ? cell : C - 1);
     const uint32_t sgnflip = negate ? 0x80000000u : 0u;
     const uint32_t tmax = static_cast<uint32_t>(Tn - 1);
@@ -574,8 +576,8 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
 
 // ---------------------------------------------------------------------------
 namespace {
-typedef void (*SortedKernel)(const float*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*, int32_t,
-                             const DevChunk*, double, int, int32_t, double*, double*, int64_t, uint32_t*, int64_t,
+typedef void (*SortedKernel)(const float*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*,
+                             const DevSortedChunk*, double, int, int32_t, double*, double*, int64_t, uint32_t*, int64_t,
                              unsigned long long*);
 struct SortedEntry { int yps, k; SortedKernel fn, fn_stats; };
 #ifdef XMHW_RING_STATS
@@ -603,7 +605,7 @@ int32_t sorted_pick_yps(int32_t w, int32_t ntracks) {
 }
 
 hipError_t launch_sorted_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
-                             const uint32_t* sflags, int32_t step_min, const DevChunk* chunks, int32_t nchunks,
+                             const uint32_t* sflags, const DevSortedChunk* chunks, int32_t nchunks,
                              int32_t w, int32_t yps, int32_t ntracks, double q, int negate, double* thresh, double* seas,
                              int64_t ldo, uint32_t* redo_bits, int64_t redo_ld, hipStream_t stream,
                              unsigned long long* stats) {
@@ -612,8 +614,8 @@ hipError_t launch_sorted_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn,
     if (C <= 0 || nchunks <= 0) return hipSuccess;
     dim3 grid(static_cast<unsigned>((C + 31) / 32), static_cast<unsigned>(nchunks));
     const bool twin = stats != nullptr && e->fn_stats != nullptr;
-    hipLaunchKernelGGL(twin ? e->fn_stats : e->fn, grid, dim3(64), 0, stream, ts, C, ld, Tn, table, sflags, step_min,
-                       chunks, q, negate, ntracks, thresh, seas, ldo, redo_bits, redo_ld, twin ? stats : nullptr);
+    hipLaunchKernelGGL(twin ? e->fn_stats : e->fn, grid, dim3(64), 0, stream, ts, C, ld, Tn, table, sflags, chunks, q,
+                       negate, ntracks, thresh, seas, ldo, redo_bits, redo_ld, twin ? stats : nullptr);
     return hipGetLastError();
 }
 

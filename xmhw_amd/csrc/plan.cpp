@@ -163,4 +163,76 @@ std::vector<Plan::Segment> Plan::sorted_segments() const {
     return out;
 }
 
+Plan::SortedPlan Plan::sorted_plan(int32_t ntp, int32_t min_rows_per_piece, int64_t pieces_wanted) const {
+    SortedPlan out;
+    if (ntracks > ntp || D <= 0) return out;
+    const std::vector<uint32_t> tab = ring_table(1, ntracks);      // [step][track]
+    auto orig = [&](int32_t step, int32_t k) -> uint32_t {
+        return tab[static_cast<size_t>(step - step_min) * ntracks + k];
+    };
+    // the tracks that are part of row s
+    auto counted = [&](int32_t s, int32_t k) -> bool { return (orig(s, k) & 1u) != 0; };
+    std::vector<int32_t> cuts;                                     // first rows of the chunks
+    for (int32_t s = 0; s < D; ++s) {
+        bool cut = s == 0;
+        for (int32_t k = 0; k < ntracks && !cut; ++k) cut = counted(s, k) != counted(s - 1, k);
+        if (cut) cuts.push_back(s);
+    }
+    cuts.push_back(D);
+    const int64_t total_rows = D;
+    for (size_t ci = 0; ci + 1 < cuts.size(); ++ci) {
+        const int32_t cb = cuts[ci], ce = cuts[ci + 1];
+        std::vector<uint8_t> inS(static_cast<size_t>(ntracks));
+        for (int32_t k = 0; k < ntracks; ++k) inS[k] = counted(cb, k) ? 1 : 0;
+        // (a track of S pushes at every row of the chunk: it has a centre there)
+        const int32_t len = ce - cb;
+        int64_t pieces = std::max<int64_t>(1, pieces_wanted * len / std::max<int64_t>(total_rows, 1));
+        pieces = std::max<int64_t>(1, std::min<int64_t>(pieces, len / std::max(min_rows_per_piece, 1)));
+        for (int64_t pj = 0; pj < pieces; ++pj) {
+            const int32_t b = cb + static_cast<int32_t>(len * pj / pieces);
+            const int32_t e = cb + static_cast<int32_t>(len * (pj + 1) / pieces);
+            if (e <= b) continue;
+            SortedChunk ch;
+            ch.warm_start = b - (R - 1);
+            ch.begin = b;
+            ch.end = e;
+            ch.trow0 = static_cast<int32_t>(out.flags.size());
+            const int32_t nrows = e - ch.warm_start;
+            const size_t base = out.table.size();
+            out.table.resize(base + static_cast<size_t>(nrows) * ntp, make_entry(kCodeInvalid, true));
+            for (int32_t k = 0; k < ntracks; ++k) {
+                if (!inS[k]) continue;
+                // output rows: the plan's own entries
+                for (int32_t s = b; s < e; ++s)
+                    out.table[base + static_cast<size_t>(s - ch.warm_start) * ntp + k] = orig(s, k);
+                // warm-up: the R-1 last pushes before row b, held steps skipped
+                int32_t src = b;
+                for (int32_t i = 1; i <= R - 1; ++i) {
+                    uint32_t ent = make_entry(kCodeInvalid, true);      // (nothing left before the table: pushes nothing)
+                    while (src > step_min) {
+                        --src;
+                        const uint32_t o = orig(src, k);
+                        if ((o >> 1) != kCodeHold) { ent = o | 1u; break; }
+                    }
+                    out.table[base + static_cast<size_t>(b - i - ch.warm_start) * ntp + k] = ent;
+                }
+            }
+            for (int32_t v = 0; v < nrows; ++v) {
+                bool simple = true, consec = v > 0;
+                for (int32_t k = 0; k < ntracks; ++k) {
+                    const uint32_t en = out.table[base + static_cast<size_t>(v) * ntp + k];
+                    simple = simple && (en >> 1) >= 2u;
+                    if (v > 0) {
+                        const uint32_t pr = out.table[base + static_cast<size_t>(v - 1) * ntp + k];
+                        consec = consec && (en >> 1) >= 2u && (pr >> 1) >= 2u && (en >> 1) == (pr >> 1) + 1u;
+                    }
+                }
+                out.flags.push_back((simple ? 1u : 0u) | (consec ? 2u : 0u));
+            }
+            out.chunks.push_back(ch);
+        }
+    }
+    return out;
+}
+
 }  // namespace xmhw

@@ -71,6 +71,19 @@ struct Plan {
     // of rows, alternating, in ascending order.
     struct Segment { int32_t begin, end; bool regular; };
     std::vector<Segment> sorted_segments() const;
+    // The sorted-list kernel's own chunks and step table.  The row axis is cut wherever the set of tracks that are part
+    // of the pool changes (a held step -- doy 60 in the non-leap years --, the first / last centre of a partial year);
+    // inside a chunk that set S is constant and every track of S pushes at every row.  A chunk gets its OWN table rows
+    // (warm-up + output rows): a track of S warms up with its R-1 last pushes before the chunk (held steps skipped, so
+    // that its window is what the reference pools), a track outside S pushes nothing.  Every row of the plan is served.
+    // `pieces` > 1 cuts long chunks further (small grids).  table: [rows][ntp] entries (track k at index k), flags: [rows]
+    // (bit 0 SIMPLE, bit 1 CONSEC as step_flags()), chunk.trow0 = the chunk's first table row (that of its warm_start).
+    struct SortedChunk { int32_t warm_start, begin, end, trow0; };
+    struct SortedPlan {
+        std::vector<SortedChunk> chunks;
+        std::vector<uint32_t> table, flags;
+    };
+    SortedPlan sorted_plan(int32_t ntp, int32_t min_rows_per_piece, int64_t pieces_wanted) const;
 };
 
 }  // namespace xmhw

@@ -135,6 +135,17 @@ PYBIND11_MODULE(_xmhw_hip, m) {
         return out;
     });
 
+    m.def("plan_sorted_table", [](uintptr_t p, int pieces) {
+        int32_t nc = 0, nr = 0, ntp = 0;
+        check(xmhw_plan_sorted_table(pp(p), pieces, &nc, &nr, &ntp, nullptr, nullptr, nullptr));
+        py::array_t<int32_t> chunks({static_cast<py::ssize_t>(nc), static_cast<py::ssize_t>(4)});
+        py::array_t<uint32_t> table({static_cast<py::ssize_t>(nr), static_cast<py::ssize_t>(ntp)});
+        py::array_t<uint32_t> flags(static_cast<py::ssize_t>(nr));
+        check(xmhw_plan_sorted_table(pp(p), pieces, &nc, &nr, &ntp, chunks.mutable_data(), table.mutable_data(),
+                                     flags.mutable_data()));
+        return py::make_tuple(chunks, table, flags);
+    });
+
     m.def("plan_debug_stats", [](uintptr_t p, int enable, bool read) {
         py::array_t<uint64_t> out(16);
         std::fill(out.mutable_data(), out.mutable_data() + 16, uint64_t(0));
