@@ -188,7 +188,8 @@ enum {
                                         cells per wave, on the rows that pool every track at every step; the other
                                         rows (around doy 60, around the ends of partial years) on the automatic ring
                                         layout; cell-rows whose lists are too short on the generic kernel.  float32,
-                                        w = 5, quantiles >= 0.75 */
+                                        w = 5, 9..48 tracks,
+                                        quantiles >= 0.85 (others run on the ring layout) */
 };
 int xmhw_plan_set_layout(xmhw_plan *plan, int32_t layout);
 /* the layout float32 input of this plan will run on (XMHW_LAYOUT_RING1 if the round-1 / generic kernel) */

@@ -105,24 +105,26 @@ def test_ring2_layout_choice():
         t = np.arange("1982-01-01", f"{1982 + n}-01-01", dtype="datetime64[D]")
         return Plan(ora.add_doy(t), w, ring2=ring2)
 
-    assert years(40).ring2_in_use() == 40                     # 40 tracks: the sorted-list kernel (round 5) ...
-    assert years(39).ring2_in_use() == 40
+    # round 5: records of 9..48 tracks run on the sorted-list kernel (layout 40); the ring layouts below are what the same
+    # plans run on for quantiles below 0.75, for float64 input and when forced (XMHW_SORTED=0 / layout=...)
+    assert years(40).ring2_in_use() == 40 and years(39).ring2_in_use() == 40 and years(9).ring2_in_use() == 40
+    assert years(48).ring2_in_use() == 40 and years(20).ring2_in_use() == 40
+    assert Plan(np.tile(np.arange(1, 1461), 20), 5).ring2_in_use() == 40     # config 5's tstep axis
     assert years(40, ring2=21).ring2_in_use() == 21           # ... 4 x 10 = 40 tracks on ring3 when forced
-    assert years(30).ring2_in_use() == 21                     # 4 x 8 (2 padded)
-    assert years(25).ring2_in_use() == 21 and years(48).ring2_in_use() == 21      # 7 .. 12 tracks per lane
-    assert years(24).ring2_in_use() == 22 and years(13).ring2_in_use() == 22      # 2 lanes per cell up to 24 tracks
+    assert years(30, ring2=21).ring2_in_use() == 21           # 4 x 8 (2 padded)
+    assert years(25, ring2=21).ring2_in_use() == 21 and years(48, ring2=21).ring2_in_use() == 21      # 7 .. 12 tracks per lane
+    assert years(24, ring2=22).ring2_in_use() == 22 and years(13, ring2=22).ring2_in_use() == 22      # 2 lanes per cell up to 24 tracks
     assert years(24, ring2=21).ring2_in_use() == 21                                 # (forced)
     assert years(40, ring2=8).ring2_in_use() == 8 and years(40, ring2=20).ring2_in_use() == 20      # forced
-    assert years(20).ring2_in_use() == 22                     # 2 x 10 = 20 tracks
-    assert Plan(np.tile(np.arange(1, 1461), 20), 5).ring2_in_use() == 22     # config 5's tstep axis
-    assert years(12).ring2_in_use() == 22 and years(9).ring2_in_use() == 22
+    assert years(20, ring2=22).ring2_in_use() == 22           # 2 x 10 = 20 tracks
+    assert years(12, ring2=22).ring2_in_use() == 22 and years(9, ring2=22).ring2_in_use() == 22
     assert years(20, ring2=0).ring2_in_use() == -1            # (0 / 7: the plain second-generation layouts left the default build in round 4)
     assert years(40, ring2=7).ring2_in_use() == -1
     assert years(40, ring2=-1).ring2_in_use() == -1           # round-1 kernel
-    assert years(10).ring2_in_use() == 22 and years(10, ring2=10).ring2_in_use() == 10
-    assert years(16).ring2_in_use() == 22                     # 16 tracks: 2 x 8
+    assert years(10, ring2=22).ring2_in_use() == 22 and years(10, ring2=10).ring2_in_use() == 10
+    assert years(16, ring2=22).ring2_in_use() == 22           # 16 tracks: 2 x 8
     assert years(16, ring2=8).ring2_in_use() == 8             # (8 x 2 = 4 x 4 exactly: the second generation's tie goes to 8 lanes)
-    assert years(43).ring2_in_use() == 21                     # 41..48 tracks (OISST 1982-2024): 4 x 11
+    assert years(43, ring2=21).ring2_in_use() == 21           # 41..48 tracks (OISST 1982-2024): 4 x 11
     assert years(49).ring2_in_use() == 20 and years(88).ring2_in_use() == 20   # 49..88 tracks: ring3 on 8 lanes per cell
     assert years(89).ring2_in_use() == 12 and years(96).ring2_in_use() == 12   # 89..96 tracks: 16 lanes per cell (ring2)
     assert years(97).ring2_in_use() == -1                     # beyond: round-1 kernel (32 lanes per cell)

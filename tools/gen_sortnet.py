@@ -23,7 +23,8 @@ NMAX = 24
 MERGES = [(4, 4, 8), (8, 8, 12), (12, 8, 12), (8, 8, 16), (16, 8, 24), (10, 10, 20), (5, 5, 10), (6, 6, 12), (12, 12, 24),
           (8, 8, 8), (8, 4, 12), (4, 4, 4), (8, 4, 8), (11, 11, 22), (12, 12, 12), (10, 10, 16), (10, 10, 14), (10, 10, 18),
           (8, 8, 14), (5, 5, 8), (5, 5, 6), (6, 6, 8), (6, 6, 10), (7, 7, 14), (7, 7, 12), (9, 9, 16), (9, 9, 18), (11, 11, 16),
-          (12, 12, 16), (12, 12, 18), (12, 12, 20), (16, 8, 16), (16, 8, 20), (8, 8, 10), (10, 8, 10), (16, 16, 16)]
+          (12, 12, 16), (12, 12, 18), (12, 12, 20), (16, 8, 16), (16, 8, 20), (8, 8, 10), (10, 8, 10), (16, 16, 16),
+          (3, 3, 6), (6, 6, 10), (9, 9, 14), (11, 11, 18), (12, 12, 18)]
 BITONIC = [3, 4, 5, 6, 7, 8, 9, 10, 11, 12]
 
 
@@ -297,7 +298,7 @@ def main():
         out.append("};")
     out.append("// v[0..A) and v[A..A+B) sorted descending -> v[0..K) = the K largest, descending")
     out.append("template <int A, int B, int K> struct MergeTop;")
-    for (a, b, keep) in MERGES:
+    for (a, b, keep) in sorted(set(MERGES)):
         net, perm = merge_top(a, b, keep)
         assert verify_merge(a, b, keep, net, perm), (a, b, keep)
         report.append(f"MergeTop<{a},{b},{keep}>: {len(net)} comparators, depth {depth(net)}")

@@ -50,8 +50,9 @@ namespace {
     } while (0)
 
 constexpr int kSubs = 8;
-// the sorted-list kernel keeps the K largest keys of a row-list: quantiles from here up
-constexpr double kSortedMinQ = 0.75;
+// the sorted-list kernel keeps the K largest keys of a row-list, K sized for the top tenth of the pool (four times a list's
+// average share): quantiles from here up.  Below, a list's share outgrows K and too many cell-rows would be recomputed.
+constexpr double kSortedMinQ = 0.85;
 
 }  // namespace
 

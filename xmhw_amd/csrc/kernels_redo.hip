@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void redo_run(const T* __restrict__ ts, int64_
                                                 const unsigned long long* __restrict__ list,
                                                 const uint32_t* __restrict__ count, uint32_t cap) {
     using K = typename KeyOf<T>::type;
-    constexpr int KPL = 8;                      // keys per lane: pools of up to 512 samples
+    constexpr int KPL = 9;                      // keys per lane: pools of up to 576 samples (48 tracks x 11 = 528)
     const int lane = threadIdx.x & 63;
     const uint32_t nent = min(*count, cap);
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);

@@ -586,8 +586,13 @@ struct SortedEntry { int yps, k; SortedKernel fn, fn_stats; };
 #define XMHW_SS(Y, K) nullptr
 #endif
 #define XMHW_S(Y, K) {Y, K, clim_sorted_f32<Y, K, false>, XMHW_SS(Y, K)}
+// tracks per lane -> keys stored per list: about 0.4 x the tracks of the record (a list's share of the pool's top tenth
+// is a tenth of the tracks on average and reaches three to four times that on a steep seasonal slope), even, at most
+// what a lane holds.  9..48 tracks.
 const SortedEntry kSorted[] = {
-    XMHW_S(20, 16),
+    XMHW_S(5, 6),   XMHW_S(6, 6),   XMHW_S(7, 8),   XMHW_S(8, 8),   XMHW_S(9, 10),  XMHW_S(10, 10), XMHW_S(11, 10),
+    XMHW_S(12, 10), XMHW_S(13, 12), XMHW_S(14, 12), XMHW_S(15, 12), XMHW_S(16, 12), XMHW_S(17, 14), XMHW_S(18, 14),
+    XMHW_S(19, 16), XMHW_S(20, 16), XMHW_S(21, 18), XMHW_S(22, 18), XMHW_S(23, 18), XMHW_S(24, 18),
 };
 #undef XMHW_S
 #undef XMHW_SS
