@@ -179,7 +179,7 @@ def live_counters(argv, rows_per_wave):
                 return None, f"rocprofv3 --pmc {tag} failed (rc {r.returncode})", None
             tot, n, name = {}, 0, None
             for row in csv.DictReader(open(files[0])):
-                if "clim_ring" in row["Kernel_Name"] and row["Counter_Name"] in counters:
+                if ("clim_ring" in row["Kernel_Name"] or "clim_sorted" in row["Kernel_Name"]) and row["Counter_Name"] in counters:
                     tot[row["Counter_Name"]] = tot.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
                     n += row["Counter_Name"] == counters[0]
                     name = row["Kernel_Name"]
@@ -210,6 +210,8 @@ def live_counters(argv, rows_per_wave):
 
 def _ring_name(variant):
     """the kernel a float32 plan runs on, by its layout number (include/xmhw_amd.h: XMHW_LAYOUT_*)"""
+    if variant == 40:
+        return "clim_sorted_f32 (sorted row-lists in LDS, 2 lanes per cell, layout 40)"
     if variant >= 20:
         return f"clim_ring3_f32 ({ {20: 8, 21: 4, 22: 2}.get(variant, 8) } lanes per cell, layout {variant})"
     return f"clim_ring2_f32 (layout {variant})"
@@ -255,6 +257,9 @@ def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, c
         fin = h.stream_create() if nslab > 1 else 0
         evs = [(h.event_create(), h.event_create()) for _ in range(nslab)]
         ring_ms = []
+        main_timed = isz == 4 and plan.kernel == "ring"
+        if main_timed:
+            h.plan_set_timing(plan.handle, 1)
 
         def step():
             for i in range(nslab):
@@ -269,6 +274,8 @@ def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, c
             h.stream_sync(0)
             if nslab > 1:
                 h.stream_sync(fin)
+            if main_timed:
+                return sum(h.plan_kernel_ms(plan.handle, i) for i in range(nslab))
             return sum(h.event_elapsed_ms(e0_, e1_) for e0_, e1_ in evs)
         step()
         t0 = time.perf_counter()
@@ -352,8 +359,15 @@ def run(args):
         from xmhw_amd.device import Plan as _Plan
         _p = _Plan(doy, w, kernel=args.kernel, nchunks=args.chunks, ring2=args.ring2)      # (host side only: no GPU touched)
         _nch = _p.chunks_in_use(int(args.cells) or ps["cells"])
+        _rows_per_wave = float(len(np.unique(doy))) / max(_nch, 1) + 2 * w
+        if args.dtype == "f32" and _p.layout_in_use() == 40:
+            # the sorted-list kernel: a wave runs ONE of the plan's chunks (warm-up rows + rows with output)
+            from xmhw_amd._lib import hip as _hip
+            _k, _lds, _pieces = _hip().plan_sorted_info(_p.handle, int(args.cells) or ps["cells"])
+            _chunks = np.asarray(_hip().plan_sorted_table(_p.handle, int(_pieces))[0])
+            _rows_per_wave = float(np.mean(_chunks[:, 2] - _chunks[:, 0]))
         _p.destroy()
-        traffic, traffic_src, sq = live_counters(child_argv, float(len(np.unique(doy))) / max(_nch, 1) + 2 * w)
+        traffic, traffic_src, sq = live_counters(child_argv, _rows_per_wave)
 
     from xmhw_amd._lib import hip
     from xmhw_amd.device import DeviceBuffer, Plan, clim_finish, clim_raw, release_device_cache
@@ -377,6 +391,11 @@ def run(args):
     C = hi - lo
     plan = Plan(doy, w, kernel=args.kernel, nchunks=args.chunks, ring2=args.ring2)
     D = plan.D
+    # float32: the library records HIP events on the kernels' stream right around the MAIN kernel of every call (the
+    # sorted-list kernel; the recomputation of the cell-rows it flags is counted in the step, not in that launch)
+    main_timed = args.dtype == "f32" and plan.kernel == "ring"
+    if main_timed:
+        h.plan_set_timing(plan.handle, 1)
     nslab = args.slabs or (4 if use_dist else 1)
     edges = [C * i // nslab for i in range(nslab + 1)]
     slabs = [(edges[i], edges[i + 1]) for i in range(nslab) if edges[i + 1] > edges[i]]
@@ -400,7 +419,7 @@ def run(args):
             recv.append(DeviceBuffer(8 * 2 * D * int(counts.sum())) if rank == 0 else None)
     h.stream_sync(0)
     ev = [(h.event_create(), h.event_create(), h.event_create()) for _ in slabs]
-    ring_ms, finish_ms = [], []
+    ring_ms, finish_ms, raw_ms = [], [], []
 
     def step(timed):
         for i, (a, b) in enumerate(slabs):
@@ -426,7 +445,8 @@ def run(args):
             h.stream_sync(comm_stream)
         if timed:
             for i in range(len(slabs)):
-                ring_ms.append(h.event_elapsed_ms(ev[i][0], ev[i][1]))
+                raw_ms.append(h.event_elapsed_ms(ev[i][0], ev[i][1]))
+                ring_ms.append(h.plan_kernel_ms(plan.handle, len(slabs) - 1 - i) if main_timed else raw_ms[-1])
                 finish_ms.append(h.event_elapsed_ms(ev[i][1], ev[i][2]))
 
     for _ in range(args.warmup):
@@ -454,6 +474,9 @@ def run(args):
              _ring_name_f64(x64) if x64 >= 0 else
              "clim_generic" if isz == 8 else
              ("clim_ring_" + args.dtype if plan.kernel == "ring" else "clim_generic"))
+    waves_cu = 8
+    if v2 == 40:
+        waves_cu = min(32, (160 * 1024) // int(h.plan_sorted_info(plan.handle, C)[1]))
 
     result = {
         "metric": "grid-cells/sec for threshold() on 40yr daily SST",
@@ -484,17 +507,20 @@ def run(args):
             "algorithmic_bytes_per_launch": cells_per_launch * bytes_per_cell,
             "algorithmic_bytes_per_cell": bytes_per_cell, "cells_per_launch": cells_per_launch,
             "avg_launch_ms": ring_avg_ms,
-            # what actually binds this kernel: vector-instruction issue.  Two waves per SIMD (228 VGPRs) share one
-            # issue port; the share of the SIMD's cycles its vector ALU is busy is 2 x the per-wave share measured by
+            # the whole raw-climatology call: that kernel + the recomputation of the cell-rows it flagged (kernels_redo.hip)
+            "raw_call_avg_ms": float(np.mean(raw_ms)),
+            # what actually binds this kernel: vector-instruction issue.  The waves of a SIMD share one issue port; the
+            # share of the SIMD's cycles its vector ALU is busy is (waves per SIMD) x the per-wave share measured by
             # SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES -- 1.0 would be the kernel's ceiling at this instruction count
             "binding": None if sq is None else {
-                "resource": "vector-instruction issue (VALU), 2 waves per SIMD",
+                "resource": ("vector-instruction issue (VALU); LDS holds %d waves per CU (%.2f per SIMD)" % (waves_cu, waves_cu / 4.0)) if v2 == 40
+                            else "vector-instruction issue (VALU), 2 waves per SIMD",
                 "insts_per_wave_row": {"valu": sq["valu_per_wave_row"], "salu": sq["salu_per_wave_row"],
                                        "lds": sq["lds_per_wave_row"]},
-                "cells_per_wave": 16 if v2 in (21, 31) else 32 if v2 in (22, 32) else 8,
+                "cells_per_wave": 16 if v2 in (21, 31) else 32 if v2 in (22, 32, 40) else 8,
                 "valu_busy_of_wave_cycles": sq["valu_busy_of_wave_cycles"],
                 "wait_any_of_wave_cycles": sq["wait_any_of_wave_cycles"],
-                "frac_of_issue_peak": min(2.0 * sq["valu_busy_of_wave_cycles"], 1.0),
+                "frac_of_issue_peak": min((waves_cu / 4.0 if v2 == 40 else 2.0) * sq["valu_busy_of_wave_cycles"], 1.0),
                 "kernel": sq["kernel"], "source": "rocprofv3 --pmc SQ_* on one step of this run's box and workload "
                                                    "(the product kernel, no counter twin)"},
         },

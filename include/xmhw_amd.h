@@ -131,6 +131,12 @@ int xmhw_plan_set_kernel(xmhw_plan *plan, int32_t kernel);  /* tests / fallback 
  * default; xmhw_plan_narrowed() reports (synchronously) whether the last float64 call of this
  * plan stayed on the float32 kernel.                                                         */
 int xmhw_plan_set_narrowing(xmhw_plan *plan, int32_t enable);
+/* measurement (bench.py): with timing on, every float32 xmhw_clim_raw_f32 call records a HIP event on its stream right
+ * before and right after its MAIN kernel (the sorted-list kernel or the ring kernel; not the recomputation of flagged
+ * cell-rows behind it); xmhw_plan_kernel_ms returns the elapsed time of the call `calls_back` calls ago (0 = the last
+ * one, up to 15), waiting for it to finish.                                                                       */
+int xmhw_plan_set_timing(xmhw_plan *plan, int32_t enable);
+int xmhw_plan_kernel_ms(xmhw_plan *plan, int32_t calls_back, float *ms);
 int xmhw_plan_narrowed(xmhw_plan *plan, int32_t *narrowed_out);
 int xmhw_plan_set_chunks(xmhw_plan *plan, int32_t nchunks); /* 0 = auto         */
 /* how many chunks of the doy axis a launch over C cells is cut into (the automatic choice or the forced one):
@@ -147,6 +153,10 @@ int xmhw_plan_table(const xmhw_plan *plan, int32_t years_per_lane, uint32_t *tab
  * for).  Call with NULL outputs for the sizes: nchunks, nrows (table / flag rows), ntp (entries per row, track k at
  * index k); then chunks_out[nchunks][4] = {warm_start, begin, end, trow0}, table_out[nrows][ntp], flags_out[nrows].
  * XMHW_ERR_UNSUPPORTED if the kernel is not instantiated for this plan.                                          */
+/* the sorted-list kernel on this plan: keys stored per row-list, LDS bytes of a wave (32 cells), and the `pieces` a
+ * launch over C cells asks xmhw_plan_sorted_table for (the automatic choice or xmhw_plan_set_chunks)             */
+int xmhw_plan_sorted_info(const xmhw_plan *plan, int64_t C, int32_t *keys_per_list, int32_t *lds_bytes_per_wave,
+                          int32_t *pieces);
 int xmhw_plan_sorted_table(const xmhw_plan *plan, int32_t pieces, int32_t *nchunks, int32_t *nrows, int32_t *ntp,
                            int32_t *chunks_out, uint32_t *table_out, uint32_t *flags_out);
 

@@ -91,12 +91,17 @@ struct xmhw_plan {
     int64_t sorted_waves = -1;              // the grid width the sorted chunks were cut for
     uint32_t* d_redo = nullptr;
     size_t redo_words = 0;
+    // optional timing of the main kernel of every raw-climatology call (xmhw_plan_set_timing): a ring of event pairs
+    bool timing = false;
+    hipEvent_t tev[32] = {};
+    uint64_t tcalls = 0;
     unsigned long long* d_redo_list = nullptr;   // (row, cell) entries of the flagged cell-rows + their counter
     uint32_t* d_redo_count = nullptr;
     uint32_t redo_cap = 0;
 
     ~xmhw_plan() {
         if (d_stats) (void)hipFree(d_stats);
+        for (hipEvent_t e : tev) if (e) (void)hipEventDestroy(e);
         if (d_table_s) (void)hipFree(d_table_s);
         if (d_chunks_s) (void)hipFree(d_chunks_s);
         if (d_sflags_s) (void)hipFree(d_sflags_s);
@@ -457,13 +462,26 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
             unsigned long long* rstats = sorted ? nullptr : plan->d_stats;
             e = hipSuccess;
             const int64_t redo_ld = (C + 31) / 32;
+            hipEvent_t t0 = nullptr, t1 = nullptr;
+            if (plan->timing) {
+                const int slot = static_cast<int>(plan->tcalls % 16);
+                for (int i = 0; i < 2; ++i)
+                    if (!plan->tev[2 * slot + i]) HIP_TRY(hipEventCreate(&plan->tev[2 * slot + i]));
+                t0 = plan->tev[2 * slot];
+                t1 = plan->tev[2 * slot + 1];
+                plan->tcalls++;
+            }
             if (sorted) {
                 e = hipMemsetAsync(plan->d_redo, 0, sizeof(uint32_t) * static_cast<size_t>(h.D) * static_cast<size_t>(redo_ld), st);
+                if (e == hipSuccess && t0) e = hipEventRecord(t0, st);
                 if (e == hipSuccess)
                     e = xmhw::launch_sorted_f32(reinterpret_cast<const float*>(ts), C, ld, h.T, plan->d_table_s,
                                                 plan->d_sflags_s, plan->d_chunks_s, plan->nchunks_s, h.w,
                                                 plan->yps_s, h.ntracks, q, negate, thresh, seas, ldo, plan->d_redo, redo_ld,
                                                 st, plan->d_stats);
+                if (e == hipSuccess && t1) e = hipEventRecord(t1, st);
+            } else if (t0) {
+                e = hipEventRecord(t0, st);
             }
             if (e != hipSuccess) {
             } else if (rn == 0) {
@@ -476,6 +494,7 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
             e = xmhw::launch_ring_f32(reinterpret_cast<const float*>(ts), C, ld, plan->d_table,
                                       h.step_min, rchunks, rn, h.w, plan->yps, plan->subs, q,
                                       negate, thresh, seas, ldo, st, rstats);
+            if (e == hipSuccess && !sorted && t1) e = hipEventRecord(t1, st);
             // (XMHW_SORTED_NOREDO=1: timing experiments only -- flagged cell-rows keep the sorted kernel's own answer)
             static const bool noredo = [] { const char* v = std::getenv("XMHW_SORTED_NOREDO"); return v && v[0] == '1'; }();
             if (e == hipSuccess && sorted && !noredo)
@@ -1204,6 +1223,21 @@ int xmhw_plan_set_kernel(xmhw_plan* plan, int32_t kernel) {
     plan->host.kernel_choice = kernel;
     return XMHW_OK;
 }
+int xmhw_plan_set_timing(xmhw_plan* plan, int32_t enable) {
+    if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
+    plan->timing = enable != 0;
+    return XMHW_OK;
+}
+int xmhw_plan_kernel_ms(xmhw_plan* plan, int32_t calls_back, float* ms) {
+    if (!plan || !ms) return fail(XMHW_ERR_INVALID, "NULL argument");
+    if (calls_back < 0 || calls_back >= 16 || static_cast<uint64_t>(calls_back) >= plan->tcalls)
+        return fail(XMHW_ERR_INVALID, "no such timed call");
+    const int slot = static_cast<int>((plan->tcalls - 1 - static_cast<uint64_t>(calls_back)) % 16);
+    if (!plan->tev[2 * slot] || !plan->tev[2 * slot + 1]) return fail(XMHW_ERR_INVALID, "no such timed call");
+    HIP_TRY(hipEventSynchronize(plan->tev[2 * slot + 1]));
+    HIP_TRY(hipEventElapsedTime(ms, plan->tev[2 * slot], plan->tev[2 * slot + 1]));
+    return XMHW_OK;
+}
 int xmhw_plan_set_narrowing(xmhw_plan* plan, int32_t enable) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
     plan->narrowing = enable != 0;
@@ -1262,6 +1296,20 @@ int xmhw_plan_table(const xmhw_plan* plan, int32_t years_per_lane, uint32_t* tab
     if (table_out) {
         std::vector<uint32_t> tab = plan->host.ring_table(kSubs, years_per_lane);
         std::memcpy(table_out, tab.data(), sizeof(uint32_t) * tab.size());
+    }
+    return XMHW_OK;
+}
+
+int xmhw_plan_sorted_info(const xmhw_plan* plan, int64_t C, int32_t* keys_per_list, int32_t* lds_bytes_per_wave,
+                          int32_t* pieces) {
+    if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
+    const int32_t k = xmhw::sorted_pick_k(plan->host.w, plan->host.ntracks);
+    if (k == 0) return fail(XMHW_ERR_UNSUPPORTED, "the sorted-list kernel is not instantiated for this window / record length");
+    if (keys_per_list) *keys_per_list = k;
+    if (lds_bytes_per_wave) *lds_bytes_per_wave = (plan->host.R * (k + 2) * 32 + 64) * 4;
+    if (pieces) {
+        const int64_t waves = (std::max<int64_t>(C, 1) + 31) / 32;
+        *pieces = static_cast<int32_t>(plan->host.nchunks_req > 0 ? plan->host.nchunks_req : (1536 + waves - 1) / waves);
     }
     return XMHW_OK;
 }

@@ -65,6 +65,7 @@ hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
 // on its own chunks and table rows (plan.h: sorted_plan); cell-rows it cannot settle are flagged in redo_bits
 // [row * redo_ld + (cell >> 5)] for launch_generic_flagged
 int32_t sorted_pick_yps(int32_t w, int32_t ntracks);     // tracks per lane, 0 if not instantiated
+int32_t sorted_pick_k(int32_t w, int32_t ntracks);       // keys stored per row-list, 0 if not instantiated
 hipError_t launch_sorted_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
                              const uint32_t* sflags, const DevSortedChunk* chunks, int32_t nchunks,
                              int32_t w, int32_t yps, int32_t ntracks, double q, int negate, double* thresh, double* seas,

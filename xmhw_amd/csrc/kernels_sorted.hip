@@ -609,6 +609,12 @@ int32_t sorted_pick_yps(int32_t w, int32_t ntracks) {
     return find_sorted(yps) ? yps : 0;
 }
 
+int32_t sorted_pick_k(int32_t w, int32_t ntracks) {
+    if (w != 5) return 0;
+    const SortedEntry* e = find_sorted((ntracks + 1) / 2);
+    return e ? e->k : 0;
+}
+
 hipError_t launch_sorted_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
                              const uint32_t* sflags, const DevSortedChunk* chunks, int32_t nchunks,
                              int32_t w, int32_t yps, int32_t ntracks, double q, int negate, double* thresh, double* seas,

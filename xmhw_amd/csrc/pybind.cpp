@@ -135,6 +135,13 @@ PYBIND11_MODULE(_xmhw_hip, m) {
         return out;
     });
 
+    m.def("plan_set_timing", [](uintptr_t p, int on) { check(xmhw_plan_set_timing(pp(p), on)); });
+    m.def("plan_kernel_ms", [](uintptr_t p, int back) { float ms = 0; check(xmhw_plan_kernel_ms(pp(p), back, &ms)); return ms; });
+    m.def("plan_sorted_info", [](uintptr_t p, int64_t C) {
+        int32_t k = 0, lds = 0, pieces = 0;
+        check(xmhw_plan_sorted_info(pp(p), C, &k, &lds, &pieces));
+        return py::make_tuple(k, lds, pieces);
+    });
     m.def("plan_sorted_table", [](uintptr_t p, int pieces) {
         int32_t nc = 0, nr = 0, ntp = 0;
         check(xmhw_plan_sorted_table(pp(p), pieces, &nc, &nr, &ntp, nullptr, nullptr, nullptr));
