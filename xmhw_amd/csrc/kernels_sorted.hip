@@ -370,16 +370,32 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
             //    list's sentinels: +inf above, 0 below -- both the LOWEST key in the cell's own order)
             uint32_t a[NL][4];
             uint32_t F = 0;            // the largest FIFTH key: whatever the lists hold beyond the windows is not above it
+            {
+                // (addresses first, then the 30 reads back to back, then ONE wait: left to itself the compiler
+                // interleaves them and waits for the LDS five times per list)
+                uint32_t ad[NL][5];
 #pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                const int32_t topj = static_cast<int32_t>(ltop[j]);
-                const int32_t botj = j == NL - 1 ? static_cast<int32_t>(lbot_last) : topj + static_cast<int32_t>((K + 1) * LSTRIDE);
-                const int32_t A0 = static_cast<int32_t>(P[j]) - (grow ? 0 : static_cast<int32_t>(LSTRIDE));
-                a[j][0] = lds_ld(static_cast<uint32_t>(A0)) ^ cm;
+                for (int j = 0; j < NL; ++j) {
+                    const int32_t topj = static_cast<int32_t>(ltop[j]);
+                    const int32_t botj = j == NL - 1 ? static_cast<int32_t>(lbot_last) : topj + static_cast<int32_t>((K + 1) * LSTRIDE);
+                    const int32_t A0 = static_cast<int32_t>(P[j]) - (grow ? 0 : static_cast<int32_t>(LSTRIDE));
+                    ad[j][0] = static_cast<uint32_t>(A0);
 #pragma unroll
-                for (int i = 1; i < 4; ++i)
-                    a[j][i] = lds_ld(static_cast<uint32_t>(med3i(A0 + i * dstep, topj, botj))) ^ cm;
-                F = umax(F, lds_ld(static_cast<uint32_t>(med3i(A0 + 4 * dstep, topj, botj))) ^ cm);
+                    for (int i = 1; i < 5; ++i) ad[j][i] = static_cast<uint32_t>(med3i(A0 + i * dstep, topj, botj));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                uint32_t raw[NL][5];
+#pragma unroll
+                for (int j = 0; j < NL; ++j)
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) raw[j][i] = lds_ld(ad[j][i]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[j][i] = raw[j][i] ^ cm;
+                    F = umax(F, raw[j][4] ^ cm);
+                }
             }
             // -- the lane's 16 largest of its 24, sorted: a tree of merges of sorted runs
             uint32_t s16[16];
@@ -450,6 +466,7 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
                 psum += c;
             }
             if (__any(tie)) {
+                asm volatile("" ::: "memory");          // (keep this a branch: plain rows never come here)
                 // the d-th and the (d+1)-th key are equal: of the keys equal to tl only d - #{keys above tl} move, lists in
                 // order (lane 0 first)
                 uint32_t gj[NL];
