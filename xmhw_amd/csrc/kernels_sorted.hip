@@ -45,8 +45,11 @@ __device__ __forceinline__ uint32_t lds_ld(uint32_t a) { return *reinterpret_cas
 __device__ __forceinline__ void lds_st(uint32_t a, uint32_t v) { *reinterpret_cast<lds_u32*>(static_cast<uintptr_t>(a)) = v; }
 
 constexpr int kSwap1 = 0xB1;      // quad_perm [1, 0, 3, 2]: the other lane of the cell
+// EVERY exchange must run with both lanes of the cell active (never under a condition that can differ between them).
 __device__ __forceinline__ uint32_t swp(uint32_t v) {
-    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), kSwap1, 0xF, 0xF, false));
+    // (bound_ctrl set: every lane of a quad has its partner, and the DPP-combine pass then folds the exchange into the
+    // instruction that uses it)
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), kSwap1, 0xF, 0xF, true));
 }
 __device__ __forceinline__ double swp(double v) {
     const uint64_t b = static_cast<uint64_t>(__double_as_longlong(v));
@@ -66,11 +69,18 @@ __device__ __forceinline__ int32_t med3i(int32_t a, int32_t b, int32_t c) {
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
-// key of a non-NaN float in two instructions (v_ashrrev, v_bitop3: (sign | 0x80000000) ^ bits)
+// key of a non-NaN float in two instructions (v_ashrrev, v_bitop3): (sign | 0x80000000) ^ bits; NEG: the key of the
+// NEGATED sample, (~sign & 0x7FFFFFFF) ^ bits (the sign mask s of the sample itself, C = 0x80000000: ~s & ~C ^ bits)
+template <bool NEG>
 __device__ __forceinline__ uint32_t key_fast(uint32_t b) {
     int32_t sg;
     asm("v_ashrrev_i32 %0, 31, %1" : "=v"(sg) : "v"(b));
-    return static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(sg, static_cast<int32_t>(b), static_cast<int32_t>(0x80000000u), 0x36));
+    // truth tables over (A = sign mask, B = bits, C = 0x80000000), bit index = A * 4 + B * 2 + C:
+    //   (A | C) ^ B = 0x36      (~A & ~C) ^ B = 0xC9
+    if constexpr (NEG)
+        return static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(sg, static_cast<int32_t>(b), static_cast<int32_t>(0x80000000u), 0xC9));
+    else
+        return static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(sg, static_cast<int32_t>(b), static_cast<int32_t>(0x80000000u), 0x36));
 }
 
 typedef uint32_t V8 __attribute__((ext_vector_type(8)));
@@ -126,18 +136,20 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
     // own list slots: global slot g = sub * NL + j; P[j] = byte address of the first key OUTSIDE the top set
     V8 P;
     uint32_t ltop[NL];                           // address of the list's upper sentinel (word 0)
-    double rsum[NL];
-    uint32_t nvl[NL];
+    // (per own list: its valid keys and the float64 sum of its samples as two words -- register tuples indexed by the
+    // wave-uniform slot number through the index register, like P)
+    V8 nvl, rs_lo, rs_hi;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
         const int g = sub * NL + j;
         ltop[j] = (g < R) ? lcell + static_cast<uint32_t>(g) * LBYTES : ldummy;
         P[j] = (g < R) ? ltop[j] + LSTRIDE : ldummy + LSTRIDE;
-        rsum[j] = 0.0;
-        nvl[j] = 0;
     }
     P[6] = 0;
     P[7] = 0;
+    nvl = 0;
+    rs_lo = 0;
+    rs_hi = 0;
     // (the lower sentinel of the last own list: lane 1's is the dummy's, right behind its upper one)
     const uint32_t lbot_last = (sub * NL + NL - 1 < R) ? ltop[NL - 1] + (K + 1) * LSTRIDE : ldummy + LSTRIDE;
     uint32_t truncmask = 0;
@@ -209,17 +221,34 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
         if (!slow) {
             // a plain row: every real track pushes a sample; NaN shows in the sum (so does +inf next to -inf: those
             // rows take the general path below, which gives the same keys)
+            // (cold spells: key(-x) and -sum(x), one instruction per sample less than negating the samples)
+            if (negate) {
 #pragma unroll
-            for (int y = 0; y < YPS; ++y) {
-                uint32_t xb = __float_as_uint(x_in[y]) ^ sgnflip;
-                uint32_t ky = key_fast(xb);
-                if (y == YPS - 1) {
-                    xb &= ~padmask;
-                    ky &= ~padmask;
+                for (int y = 0; y < YPS; ++y) {
+                    uint32_t xb = __float_as_uint(x_in[y]);
+                    uint32_t ky = key_fast<true>(xb);
+                    if (y == YPS - 1) {
+                        xb &= ~padmask;
+                        ky &= ~padmask;
+                    }
+                    k[y] = ky;
+                    const double dv = static_cast<double>(__uint_as_float(xb));
+                    din = y == 0 ? dv : din + dv;
                 }
-                k[y] = ky;
-                const double dv = static_cast<double>(__uint_as_float(xb));
-                din = y == 0 ? dv : din + dv;
+                din = -din;
+            } else {
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) {
+                    uint32_t xb = __float_as_uint(x_in[y]);
+                    uint32_t ky = key_fast<false>(xb);
+                    if (y == YPS - 1) {
+                        xb &= ~padmask;
+                        ky &= ~padmask;
+                    }
+                    k[y] = ky;
+                    const double dv = static_cast<double>(__uint_as_float(xb));
+                    din = y == 0 ? dv : din + dv;
+                }
             }
             nvin = padded_last ? YPS - 1 : YPS;
             slow = __any(din != din);
@@ -290,13 +319,8 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
         double rs_old = 0.0;
         {
             const uint32_t Pm = P[mj];
-            uint32_t nvm = 0;
-            double rsm = 0.0;
-#pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                nvm = (j == mj) ? nvl[j] : nvm;
-                rsm = (j == mj) ? rsum[j] : rsm;
-            }
+            const uint32_t nvm = nvl[mj];
+            const double rsm = __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(rs_hi[mj]) << 32) | rs_lo[mj]));
             if (own_m) {
                 c_old = ((Pm - base_m) >> 7) - 1u;
                 nv_old = nvm;
@@ -324,16 +348,18 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
         total += din - rs_old;
         P[mj] = own_m ? base_m + (1u + c_new) * LSTRIDE : P[mj];
         if (own_m) truncmask = (truncmask & ~(1u << mj)) | ((nvin > static_cast<uint32_t>(K) ? 1u : 0u) << mj);
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            nvl[j] = (own_m && j == mj) ? nvin : nvl[j];
-            rsum[j] = (own_m && j == mj) ? din : rsum[j];
+        {
+            const uint64_t db = static_cast<uint64_t>(__double_as_longlong(din));
+            nvl[mj] = own_m ? nvin : nvl[mj];
+            rs_lo[mj] = own_m ? static_cast<uint32_t>(db) : rs_lo[mj];
+            rs_hi[mj] = own_m ? static_cast<uint32_t>(db >> 32) : rs_hi[mj];
         }
         if (!(fabs(total) <= 1.7976931348623157e308)) {
             // an infinity in the pool, or one that has just left it: the total is taken from the list sums again
             double tsum = 0.0;
 #pragma unroll
-            for (int j = 0; j < NL; ++j) tsum += rsum[j];
+            for (int j = 0; j < NL; ++j)
+                tsum += __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(rs_hi[j]) << 32) | rs_lo[j]));
             total = tsum + swp(tsum);
         }
         m = (m + 1 == R) ? 0 : m + 1;
@@ -535,7 +561,12 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
                 // a list stored to its last key, all of it inside the top set, with keys that were not stored
                 flag = flag || (P[j] == ltop[j] + (K + 1) * LSTRIDE && ((truncmask >> j) & 1u));     // (never the dummy: no bit)
         }
-        flag = flag || swp(flag ? 1u : 0u) != 0u;
+        {
+            // (NOT `flag || swp(...)`: the short-circuit would run the exchange with the flagged lanes switched off, and
+            // a DPP read of a lane that is switched off returns 0 -- the partner lane would never see the flag)
+            const uint32_t fl_ = flag ? 1u : 0u;
+            flag = (fl_ | swp(fl_)) != 0u;
+        }
         tick(3);
 
         // ---- 5. output ---------------------------------------------------------------------------------------------
