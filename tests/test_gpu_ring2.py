@@ -11,7 +11,7 @@ import xmhw_oracle as ora
 import oracle_fast as fast
 
 pytestmark = pytest.mark.gpu
-VARIANTS = [0, 1, 2, 4, 5, 7, 8, 9, 10]
+VARIANTS = [8, 10, 12]        # (the layouts the library is built with; the others are refused since round 5)
 
 
 @pytest.fixture(scope="module")
@@ -158,7 +158,7 @@ def test_no_leap_year_in_period(dev):
     doy = _daily(2001, 2003)
     x = _series(doy.shape[0], 16, 19)
     t0, s0, st0 = _raw(dev, x, doy, ring2=-1)
-    t1, s1, st1 = _raw(dev, x, doy, ring2=4)
+    t1, s1, st1 = _raw(dev, x, doy, ring2=8)
     npt.assert_array_equal(t0, t1)
     npt.assert_array_equal(s0, s1)
 

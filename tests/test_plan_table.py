@@ -118,8 +118,9 @@ def test_ring2_layout_choice():
     assert years(40, ring2=8).ring2_in_use() == 8 and years(40, ring2=20).ring2_in_use() == 20      # forced
     assert years(20, ring2=22).ring2_in_use() == 22           # 2 x 10 = 20 tracks
     assert years(12, ring2=22).ring2_in_use() == 22 and years(9, ring2=22).ring2_in_use() == 22
-    assert years(20, ring2=0).ring2_in_use() == -1            # (0 / 7: the plain second-generation layouts left the default build in round 4)
-    assert years(40, ring2=7).ring2_in_use() == -1
+    for gone in (0, 7, 9, 11, 30):                            # (layouts this build does not have are refused, not silently
+        with pytest.raises(Exception):                        # served by a slow fallback: ADVICE r4)
+            years(40, ring2=gone)
     assert years(40, ring2=-1).ring2_in_use() == -1           # round-1 kernel
     assert years(10, ring2=22).ring2_in_use() == 22 and years(10, ring2=10).ring2_in_use() == 10
     assert years(16, ring2=22).ring2_in_use() == 22           # 16 tracks: 2 x 8

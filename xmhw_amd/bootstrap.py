@@ -30,31 +30,40 @@ def _recv_exact(conn, n):
     return buf
 
 
+def _is_local_v4(ip):
+    """can a server socket of this host bind that IPv4 address?"""
+    probe = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    try:
+        probe.bind((ip, 0))
+        return True
+    except OSError:
+        return False
+    finally:
+        probe.close()
+
+
 def _bind_address(addr):
-    """The interface rank 0 listens on.  The rendezvous address itself when it is a literal IP or plainly the
-    loopback (`localhost`, 127.x: a single-node job stays off the network); for a HOST NAME only if it resolves to
-    a non-loopback address -- Debian / Ubuntu map a machine's own name to 127.0.1.1 in /etc/hosts, and a server
-    bound there would refuse the ranks of the other nodes, which resolve the routable address -- otherwise every
-    interface."""
+    """The interface rank 0 listens on.  The rendezvous address itself when this host owns it -- a literal IPv4
+    address, or a HOST NAME that resolves to a non-loopback address of this host (Debian / Ubuntu map a machine's own
+    name to 127.0.1.1 in /etc/hosts, and a server bound there would refuse the ranks of the other nodes, which resolve
+    the routable address); the loopback for `localhost` / 127.x (a single-node job stays off the network); otherwise
+    every interface: a literal that is NOT an address of this host (a NAT or floating address, a service VIP, an
+    address seen through another network namespace), an IPv6 literal (the server socket is IPv4), a name that does
+    not resolve."""
     import ipaddress
     try:
-        ipaddress.ip_address(addr)
-        return addr                                      # a literal address: exactly that interface
+        ip = ipaddress.ip_address(addr)
+        if ip.version == 4 and _is_local_v4(addr):
+            return addr                                  # a literal address of this host: exactly that interface
+        return "0.0.0.0"
     except ValueError:
         pass
     if addr == "localhost":
         return "127.0.0.1"
     try:
         resolved = socket.gethostbyname(addr)
-        if not ipaddress.ip_address(resolved).is_loopback:
-            probe = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            try:
-                probe.bind((resolved, 0))                # an address of this host?
-                return resolved
-            except OSError:
-                pass
-            finally:
-                probe.close()
+        if not ipaddress.ip_address(resolved).is_loopback and _is_local_v4(resolved):
+            return resolved
     except OSError:
         pass
     return "0.0.0.0"
@@ -70,7 +79,10 @@ def share_bytes(rank, size, make_payload, addr=None, port=None, timeout=120.0):
         payload = make_payload()
         srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind((_bind_address(addr), port))
+        try:
+            srv.bind((_bind_address(addr), port))
+        except OSError:
+            srv.bind(("0.0.0.0", port))                  # (the probe and the bind raced, or the port is per-interface)
         srv.listen(size)
         srv.settimeout(timeout)
         served = 0

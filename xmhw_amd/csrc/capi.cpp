@@ -1155,6 +1155,19 @@ int xmhw_event_elapsed_ms(void* start, void* stop, float* ms) {
     return XMHW_OK;
 }
 
+namespace {
+// the layouts this build instantiates (include/xmhw_amd.h: XMHW_LAYOUT_*)
+bool layout_compiled(int32_t layout) {
+    switch (layout) {
+        case -2: case -1: case 8: case 10: case 12: case 20: case 21: case 22: case XMHW_LAYOUT_SORTED: return true;
+#ifdef XMHW_RING4
+        case 30: case 31: case 32: return true;
+#endif
+        default: return false;
+    }
+}
+}  // namespace
+
 int xmhw_plan_create(const int32_t* doy_host, int64_t T, int32_t window_half_width, xmhw_plan** plan) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
     *plan = nullptr;
@@ -1166,15 +1179,22 @@ int xmhw_plan_create(const int32_t* doy_host, int64_t T, int32_t window_half_wid
         delete p;
         return fail(XMHW_ERR_INVALID, msg);
     }
-    if (const char* v = std::getenv("XMHW_RING2")) p->ring2_variant = std::atoi(v);
+    // (the environment sets the default layout of new plans; a number this build does not have is ignored)
+    if (const char* v = std::getenv("XMHW_RING2")) {
+        const int32_t lay = std::atoi(v);
+        if (layout_compiled(lay) && (lay != XMHW_LAYOUT_SORTED || xmhw::sorted_pick_yps(p->host.w, p->host.ntracks) != 0))
+            p->ring2_variant = lay;
+    }
     *plan = p;
     return XMHW_OK;
 }
 int xmhw_plan_set_layout(xmhw_plan* plan, int32_t layout) {
     if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
-    if (layout < -2 || (layout > 12 && !(layout >= 20 && layout <= 22) && !(layout >= 30 && layout <= 32) &&
-                        layout != XMHW_LAYOUT_SORTED))
-        return fail(XMHW_ERR_INVALID, "layout must be one of the XMHW_LAYOUT_* constants (-2, -1, 8, 10, 12, 20..22, 40)");
+    if (!layout_compiled(layout))
+        return fail(XMHW_ERR_UNSUPPORTED,
+                    "layout must be one of the XMHW_LAYOUT_* constants this library was built with: -2 (auto), -1, 8, 10, 12, "
+                    "20, 21, 22, 40 (the plain second-generation layouts 0..7, 9, 11 left the build in round 4; 30..32 need "
+                    "make RING4=1)");
     if (layout == XMHW_LAYOUT_SORTED && xmhw::sorted_pick_yps(plan->host.w, plan->host.ntracks) == 0)
         return fail(XMHW_ERR_UNSUPPORTED, "the sorted-list kernel is not instantiated for this window / record length");
     plan->ring2_variant = layout;

@@ -549,17 +549,17 @@ class File:
         root, nroot = b.off(addr + 16), b.u(addr + 16 + b.osz, 2)
         if root == _UNDEF or nroot == 0:
             return rtype, []
-        # bytes of the per-child record counts, level by level (H5B2: node_info): a leaf holds max_leaf records, an
-        # internal node of depth d as many as fit beside its child pointers
+        # H5B2hdr.c: ONE size for the "records in child" field of every node pointer at every depth, that of the LEAF
+        # maximum (hdr->max_nrec_size); a pointer to a child of depth >= 1 carries the child's total as well, sized for
+        # the most records a subtree of that depth can hold (cum_max_nrec_size)
         def enc(n):
             return (max(n, 1).bit_length() - 1) // 8 + 1
         max_leaf = (node_size - 10) // rec_size
-        nrec_bytes = [enc(max_leaf)]            # [d]: bytes of "records in child" for children of depth d
+        nrec_sz = enc(max_leaf)
         cum = [max_leaf]                        # [d]: most records a subtree of depth d can hold
         for d in range(1, depth + 1):
-            ptr = b.osz + nrec_bytes[d - 1] + (enc(cum[d - 1]) if d > 1 else 0)
+            ptr = b.osz + nrec_sz + (enc(cum[d - 1]) if d > 1 else 0)
             max_int = (node_size - 10 - ptr) // (rec_size + ptr)
-            nrec_bytes.append(enc(max_int))
             cum.append(max_int + (max_int + 1) * cum[d - 1])
         out = []
 
@@ -575,8 +575,8 @@ class File:
                 return
             for i in range(n + 1):
                 child = b.off(q)
-                cn = b.u(q + b.osz, nrec_bytes[d - 1])
-                q += b.osz + nrec_bytes[d - 1] + (enc(cum[d - 1]) if d > 1 else 0)
+                cn = b.u(q + b.osz, nrec_sz)
+                q += b.osz + nrec_sz + (enc(cum[d - 1]) if d > 1 else 0)
                 node(child, cn, d - 1)
                 if i < n:
                     out.append(recs[i])
@@ -652,11 +652,20 @@ class File:
                 raise XmhwException(f"{self.path}: version-2 B-tree of type {rtype} is not a name index")
             # a managed heap ID: flags byte (version << 6 | type << 4), offset, length
             len_bytes = min((maxdirect.bit_length() - 1) // 8 + 1, (max(max_obj, 1).bit_length() - 1) // 8 + 1)
+            nskipped = 0
             for rec in recs:
                 hid = rec[:idlen] if rtype == 8 else rec[4:4 + idlen]
                 kind = (hid[0] >> 4) & 3
                 if kind != 0:
-                    raise XmhwException(f"{self.path}: {'huge' if kind == 1 else 'tiny'} fractal heap objects are not supported")
+                    # a "huge" object (> the heap's largest managed size, e.g. a 100 KB NCO history string) lives outside
+                    # the heap, a "tiny" one inside its ID: neither can be one of the small numeric attributes the decoding
+                    # needs (scale_factor, add_offset, _FillValue, units ...) -- skipped with a warning, the rest of the
+                    # object header stays readable
+                    import warnings
+                    warnings.warn(f"{self.path}: a {'huge' if kind == 1 else 'tiny'} fractal heap object (a very long or "
+                                  f"very short attribute / link) is skipped", stacklevel=2)
+                    nskipped += 1
+                    continue
                 off = int.from_bytes(hid[1:1 + boff], "little")
                 ln = int.from_bytes(hid[1 + boff:1 + boff + len_bytes], "little")
                 for blk_off, size, addr in blocks:
@@ -665,8 +674,8 @@ class File:
                         break
                 else:
                     raise XmhwException(f"{self.path}: fractal heap object at offset {off} is in no direct block")
-            if len(recs) != nmanaged:
-                raise XmhwException(f"{self.path}: the name index lists {len(recs)} objects, the fractal heap manages {nmanaged}")
+            if len(recs) - nskipped != nmanaged:
+                raise XmhwException(f"{self.path}: the name index lists {len(recs) - nskipped} managed objects, the fractal heap manages {nmanaged}")
             return
 
         found = 0
