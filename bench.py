@@ -60,6 +60,14 @@ PRESETS = {
                         name="0.25deg global, 5% NaN, skipna=True (configs[3])"),
     "0.05deg_tstep": dict(cells=810000, years=(2001, 2020), nan=0.0, tstep=True, skipna=False, index=4,
                           name="0.05deg tile share, 6-hourly no-leap tstep (configs[4], one GPU's share)"),
+    # configs[2]'s shape on data that looks like a real archive: values stored at 0.01 K with 10 % of the cells
+    # held at -1.8 for 120 days a year (sea ice); AR(1) anomalies (rho = 0.9) instead of white noise.  Never the headline.
+    "0.25deg_quant_ice": dict(cells=1440 * 720, years=(1982, 2021), nan=0.0, tstep=False, skipna=False, index=2,
+                              gen=dict(quant=0.01, ice_frac=0.10, rho=0.0),
+                              name="0.25deg global, values at 0.01 K, 10 % of cells at -1.8 for 120 days a year (configs[2] shape)"),
+    "0.25deg_ar1": dict(cells=1440 * 720, years=(1982, 2021), nan=0.0, tstep=False, skipna=False, index=2,
+                        gen=dict(quant=0.0, ice_frac=0.0, rho=0.9),
+                        name="0.25deg global, AR(1) anomalies rho = 0.9 (configs[2] shape)"),
 }
 
 
@@ -68,7 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default=None, choices=sorted(PRESETS),
+    ap.add_argument("--config", default=None, choices=sorted(k for k in PRESETS if not PRESETS[k].get("gen")),
                     help="default: 0.25deg (configs[2]) at N=1, 0.25deg_nan (configs[3]) at N>1")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N>1: strong = one grid split over the ranks (default); weak = a full grid per rank")
@@ -243,7 +251,11 @@ def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, c
     bufs = []
     try:
         ts = DeviceBuffer(isz * T * C); bufs.append(ts)
-        h.synth_sst(ts.ptr, isz, T, C, C, 0, 20260101 + ps["index"], ps["nan"], 0)
+        if ps.get("gen"):
+            h.synth_sst_ex(ts.ptr, T, C, C, 0, 20260101 + ps["index"], ps["nan"], ps["gen"]["quant"], ps["gen"]["ice_frac"],
+                           ps["gen"]["rho"], 0)
+        else:
+            h.synth_sst(ts.ptr, isz, T, C, C, 0, 20260101 + ps["index"], ps["nan"], 0)
         th, se = DeviceBuffer(8 * D * C), DeviceBuffer(8 * D * C)
         out = DeviceBuffer(8 * 2 * D * C)
         bufs += [th, se, out]
@@ -669,7 +681,8 @@ def run(args):
         import oracle_fast as fast
         others = []
         for ocfg, odt in (("0.25deg", "f64"), ("1deg", "f32"), ("1deg", "f64"), ("0.25deg_nan", "f32"),
-                          ("0.05deg_tstep", "f32"), ("0.05deg_tstep", "f64")):
+                          ("0.05deg_tstep", "f32"), ("0.05deg_tstep", "f64"), ("0.25deg_quant_ice", "f32"),
+                          ("0.25deg_ar1", "f32")):
             if ocfg == cfg and odt == args.dtype:
                 continue
             try:

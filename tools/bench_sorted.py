@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--q", type=float, default=0.9)
+    ap.add_argument("--gen", type=float, nargs=3, default=None, metavar=("QUANT", "ICE_FRAC", "RHO"),
+                    help="the extended generator (xmhw_synth_sst_ex_f32) instead of the SURVEY 8(d) one")
     args = ap.parse_args()
     import xmhw_amd.device as dev
     from xmhw_amd.calendar import add_doy
@@ -35,7 +37,10 @@ def main():
     doy = add_doy(np.arange(f"{years[0]}-01-01", f"{years[1] + 1}-01-01", dtype="datetime64[D]"))
     T = doy.shape[0]
     ts = dev.DeviceBuffer(4 * T * C)
-    h.synth_sst(ts.ptr, 4, T, C, C, 0, 20260103, nan, 0)
+    if args.gen:
+        h.synth_sst_ex(ts.ptr, T, C, C, 0, 20260103, nan, args.gen[0], args.gen[1], args.gen[2], 0)
+    else:
+        h.synth_sst(ts.ptr, 4, T, C, C, 0, 20260103, nan, 0)
     ref = None
     idx = np.unique(np.linspace(0, C - 1, 2048).astype(np.int64))
     d_idx = dev.DeviceBuffer.from_array(idx)

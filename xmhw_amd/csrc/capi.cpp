@@ -337,10 +337,10 @@ int upload_sorted(xmhw_plan* p, int64_t C) {
         p->redo_words = words;
     }
     if (p->nchunks_s > 0) {
-        // the work list of the flagged cell-rows: one entry per 64 cell-rows (the sorted kernel flags well under 0.1 %
+        // the work list of the flagged cell-rows: one entry per 16 cell-rows (the sorted kernel flags well under 0.1 %
         // of them on SST-like data; what does not fit goes the slow way, kernels_redo.hip)
         if (!p->d_redo_count) HIP_TRY(hipMalloc(&p->d_redo_count, sizeof(uint32_t)));
-        const size_t want = std::max<size_t>(4096, static_cast<size_t>(h.D) * static_cast<size_t>(C) / 64);
+        const size_t want = std::max<size_t>(4096, static_cast<size_t>(h.D) * static_cast<size_t>(C) / 16);
         const uint32_t cap = static_cast<uint32_t>(std::min<size_t>(want, size_t(1) << 28));
         if (cap > p->redo_cap) {
             if (p->d_redo_list) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p->d_redo_list)); p->d_redo_list = nullptr; p->redo_cap = 0; }
@@ -1580,6 +1580,16 @@ int xmhw_synth_sst_f32(float* ts, int64_t T, int64_t C, int64_t ld, int64_t cell
                        double nan_frac, void* stream) {
     if (C < 0 || ld < C || T <= 0) return fail(XMHW_ERR_INVALID, "bad T/C/ld");
     hipError_t e = xmhw::launch_synth<float>(ts, T, C, ld, cell0, seed, nan_frac, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "synth launch");
+    return XMHW_OK;
+}
+int xmhw_synth_sst_ex_f32(float* ts, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed, double nan_frac,
+                          double quant, double ice_frac, double rho, void* stream) {
+    if (!ts || T < 0 || C < 0 || ld < C) return fail(XMHW_ERR_INVALID, "bad argument");
+    if (!(rho >= 0.0 && rho < 1.0) || quant < 0.0 || ice_frac < 0.0 || ice_frac > 1.0)
+        return fail(XMHW_ERR_INVALID, "rho must be in [0, 1), quant >= 0, ice_frac in [0, 1]");
+    hipError_t e = xmhw::launch_synth_ex<float>(ts, T, C, ld, cell0, seed, nan_frac, quant, ice_frac, rho,
+                                                static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail(e, "synth launch");
     return XMHW_OK;
 }

@@ -715,6 +715,56 @@ __global__ __launch_bounds__(256) void synth_sst(T* __restrict__ ts, int64_t Tn,
     }
 }
 
+// The same series with what real archives add (bench legs): values QUANTISED to a step (OISST stores 0.01 K),
+// a share of the cells held at -1.8 for 120 days of every year (sea ice), AR(1) anomalies instead of white noise
+// (rho: the day-to-day correlation; the anomaly keeps unit variance).  Thread per cell, sequential in time (the AR(1)
+// recursion); bit-identical to synth_sst for quant = 0, ice_frac = 0, rho = 0.
+template <typename T>
+__global__ __launch_bounds__(256) void synth_sst_ex(T* __restrict__ ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0,
+                                                    uint64_t seed, double nan_frac, double quant, double ice_frac,
+                                                    double rho) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const uint64_t cell = static_cast<uint64_t>(cell0 + c);
+    const uint64_t hc = mix64(seed * 0x100000001B3ull + cell);
+    const double A = 2.0 + 8.0 * u01(mix64(hc ^ 0xA1));
+    const double phi = 365.0 * u01(mix64(hc ^ 0xB2));
+    const double beta = 2.0 * u01(mix64(hc ^ 0xC3)) - 1.0;
+    const bool ice = ice_frac > 0.0 && u01(mix64(hc ^ 0xF6)) < ice_frac;
+    const double ice0 = 365.25 * u01(mix64(hc ^ 0x17));            // start of the cell's ice season (day of the year)
+    const double srho = sqrt(1.0 - rho * rho);
+    double e = 0.0;
+    for (int64_t t = 0; t < Tn; ++t) {
+        const uint64_t h1 = mix64(hc + 0x9E3779B97F4A7C15ull * static_cast<uint64_t>(t + 1));
+        const uint64_t h2 = mix64(h1 ^ 0xD4);
+        const double u1 = u01(h1), u2 = u01(h2);
+        const double eps = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        e = rho != 0.0 ? (t == 0 ? eps : rho * e + srho * eps) : eps;
+        double v = 15.0 + A * sin(6.283185307179586 * (static_cast<double>(t) - phi) / 365.25) +
+                   0.0005 * static_cast<double>(t) * beta + e;
+        if (ice) {
+            const double day = fmod(static_cast<double>(t) - ice0 + 36525.0, 365.25);
+            if (day < 120.0) v = -1.8;
+        }
+        if (quant > 0.0) v = rint(v / quant) * quant;
+        if (nan_frac > 0.0 && u01(mix64(h2 ^ 0xE5)) < nan_frac) v = make_nan();
+        ts[t * ld + c] = static_cast<T>(v);
+    }
+}
+
+template <typename T>
+hipError_t launch_synth_ex(T* ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0, uint64_t seed, double nan_frac,
+                           double quant, double ice_frac, double rho, hipStream_t stream) {
+    if (C <= 0 || Tn <= 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_sst_ex<T>, dim3(static_cast<unsigned>((C + 255) / 256)), dim3(256), 0, stream, ts, Tn, C, ld,
+                       cell0, seed, nan_frac, quant, ice_frac, rho);
+    return hipGetLastError();
+}
+template hipError_t launch_synth_ex<float>(float*, int64_t, int64_t, int64_t, int64_t, uint64_t, double, double, double,
+                                           double, hipStream_t);
+template hipError_t launch_synth_ex<double>(double*, int64_t, int64_t, int64_t, int64_t, uint64_t, double, double, double,
+                                            double, hipStream_t);
+
 template <typename T>
 hipError_t launch_synth(T* ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
                         double nan_frac, hipStream_t stream) {

@@ -6,9 +6,10 @@
 //   redo_collect   thread per bitmap word: every set bit becomes an entry (row, cell) of a work list (an atomic counter
 //                  hands out the slots) and is cleared; bits that do not fit the list stay set;
 //   redo_run       ONE WAVE per entry, a fixed grid striding over the list: the wave loads the row's pool (the samples
-//                  at centre +- w of every centre of the row: window_roll(), identify.py:184-209) -- seven keys per
-//                  lane --, builds the key of order statistic lo bit by bit with wave-wide counts (ballot + popcount:
-//                  the counts and every decision are scalar) and finds its successor; numpy's linear interpolation
+//                  at centre +- w of every centre of the row: window_roll(), identify.py:184-209) -- nine keys per
+//                  lane --, starts from the sorted kernel's own (wrong, but close) answer, counts the keys below it and
+//                  steps from key to neighbouring key until order statistic lo is reached (wave-wide counts by ballot +
+//                  popcount: the counts and every decision are scalar); numpy's linear interpolation
 //                  (identify.py:233-235);
 //   clim_generic_flagged (kernels_generic.hip) on whatever is still set: only when the list overflowed.
 #include "device_common.h"
@@ -25,23 +26,50 @@ __global__ __launch_bounds__(256) void redo_collect(uint32_t* __restrict__ bits,
     if (word == 0u) return;
     const uint64_t row = static_cast<uint64_t>(w / ldb);
     const uint64_t cell0 = static_cast<uint64_t>(w % ldb) * 32u;
+    // (one atomic per word: the word's entries take consecutive slots)
+    const uint32_t nb = static_cast<uint32_t>(__builtin_popcount(word));
+    uint32_t idx = atomicAdd(count, nb);
     uint32_t left = word;
     while (word != 0u) {
         const uint32_t b = static_cast<uint32_t>(__builtin_ctz(word));
         word &= word - 1u;
-        const uint32_t idx = atomicAdd(count, 1u);
         if (idx < cap) {
             list[idx] = (row << 40) | (cell0 + b);
             left &= ~(1u << b);
         }
+        ++idx;
     }
     bits[w] = left;
 }
 
-template <typename T>
+// wave-wide helpers: every lane ends with the result
+template <typename K>
+__device__ __forceinline__ K wave_min(K v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const K o = static_cast<K>(__shfl_xor(static_cast<unsigned long long>(v), off, 64));
+        v = o < v ? o : v;
+    }
+    return v;
+}
+template <typename K>
+__device__ __forceinline__ K wave_max(K v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const K o = static_cast<K>(__shfl_xor(static_cast<unsigned long long>(v), off, 64));
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// W = the window half width as a compile-time constant (5: the default, every plan the sorted kernel serves) or 0 = taken
+// from the argument.  The selection starts from the answer the sorted kernel left in `thresh` (wrong, but a few ranks
+// away at most): count the keys below it, then step from key to neighbouring key until order statistic lo is reached;
+// the bit-by-bit descent over the whole key is kept for guesses that turn out to be far off.
+template <typename T, int W>
 __global__ __launch_bounds__(256) void redo_run(const T* __restrict__ ts, int64_t Tn, int64_t ld,
                                                 const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ centres,
-                                                int32_t w, double q, int negate, double* __restrict__ thresh, int64_t ldo,
+                                                int32_t w_arg, double q, int negate, double* __restrict__ thresh, int64_t ldo,
                                                 const unsigned long long* __restrict__ list,
                                                 const uint32_t* __restrict__ count, uint32_t cap) {
     using K = typename KeyOf<T>::type;
@@ -49,13 +77,16 @@ __global__ __launch_bounds__(256) void redo_run(const T* __restrict__ ts, int64_
     const int lane = threadIdx.x & 63;
     const uint32_t nent = min(*count, cap);
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-    const int R = 2 * w + 1;
+    const int32_t w = W > 0 ? W : w_arg;
+    const int32_t R = 2 * w + 1;
     for (uint32_t e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); e < nent; e += nwaves) {
         const unsigned long long ent = list[e];
         const int32_t row = static_cast<int32_t>(ent >> 40);
         const int64_t c = static_cast<int64_t>(ent & ((1ull << 40) - 1ull));
         const int32_t cb = row_ptr[row], ce = row_ptr[row + 1];
         const int32_t npool = (ce - cb) * R;
+        // (pools beyond KPL * 64 samples do not occur on plans the sorted kernel serves; such an entry is left alone)
+        if (npool > KPL * 64) continue;
         const T* col = ts + c;
         K key[KPL];
 #pragma unroll
@@ -63,7 +94,8 @@ __global__ __launch_bounds__(256) void redo_run(const T* __restrict__ ts, int64_
             const int32_t p = lane + 64 * i;
             K kk = 0;
             if (p < npool) {
-                const int64_t t = static_cast<int64_t>(centres[cb + p / R]) + (p % R - w);
+                const int32_t ci = p / R;
+                const int64_t t = static_cast<int64_t>(centres[cb + ci]) + (p - ci * R - w);
                 if (t >= 0 && t < Tn) {
                     T v = col[t * ld];
                     if (negate) v = -v;
@@ -72,8 +104,6 @@ __global__ __launch_bounds__(256) void redo_run(const T* __restrict__ ts, int64_
             }
             key[i] = kk;
         }
-        // (pools beyond KPL * 64 samples do not occur on plans the sorted kernel serves; such an entry is left alone)
-        if (npool > KPL * 64) continue;
         uint32_t n = 0;
 #pragma unroll
         for (int i = 0; i < KPL; ++i) n += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(key[i] != 0)));
@@ -83,31 +113,75 @@ __global__ __launch_bounds__(256) void redo_run(const T* __restrict__ ts, int64_
             const double fl = floor(vi);
             const uint32_t lo = static_cast<uint32_t>(fl);
             const double g = vi - fl;
-            K v = 0;
-            for (int bit = KeyOf<T>::bits - 1; bit >= 0; --bit) {
-                const K cand = v | (static_cast<K>(1) << bit);
-                uint32_t cnt = 0;       // valid keys < cand   (key 0 = invalid: (0 - 1) wraps high)
+            auto count_lt = [&](K v) -> uint32_t {       // valid keys below v
+                uint32_t cnt = 0;
 #pragma unroll
                 for (int i = 0; i < KPL; ++i)
-                    cnt += static_cast<uint32_t>(__builtin_popcountll(
-                        __builtin_amdgcn_ballot_w64(static_cast<K>(key[i] - 1) < static_cast<K>(cand - 1))));
-                if (cnt <= lo) v = cand;
+                    cnt += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(key[i] != 0 && key[i] < v)));
+                return cnt;
+            };
+            auto count_eq = [&](K v) -> uint32_t {
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int i = 0; i < KPL; ++i)
+                    cnt += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(key[i] == v)));
+                return cnt;
+            };
+            auto next_above = [&](K v) -> K {            // the smallest key above v (all ones if none)
+                K m = ~static_cast<K>(0);
+#pragma unroll
+                for (int i = 0; i < KPL; ++i) m = (key[i] > v && key[i] < m) ? key[i] : m;
+                return wave_min<K>(m);
+            };
+            auto next_below = [&](K v) -> K {            // the largest valid key below v (0 if none)
+                K m = 0;
+#pragma unroll
+                for (int i = 0; i < KPL; ++i) m = (key[i] < v && key[i] > m) ? key[i] : m;
+                return wave_max<K>(m);
+            };
+            // -- from the sorted kernel's answer: a key near order statistic lo
+            const double guess = thresh[static_cast<int64_t>(row) * ldo + c];
+            K v = guess == guess ? KeyOf<T>::key(static_cast<T>(guess)) : static_cast<K>(0);
+            bool found = false;
+            uint32_t cl = 0, ev = 0;                     // keys below v, keys equal to v
+            if (v != 0) {
+                cl = count_lt(v);
+                ev = count_eq(v);
+                for (int it = 0; it < 24 && !found; ++it) {
+                    if (cl <= lo && lo < cl + ev) {
+                        found = true;
+                    } else if (lo < cl) {
+                        v = next_below(v);
+                        if (v == 0) break;
+                        ev = count_eq(v);
+                        cl -= ev;
+                    } else {
+                        const K nv = next_above(v);
+                        if (nv == ~static_cast<K>(0)) break;
+                        cl += ev;
+                        v = nv;
+                        ev = count_eq(v);
+                    }
+                }
+            }
+            if (!found) {
+                // the whole key, bit by bit: largest v with #{valid keys < v} <= lo   (key 0 = invalid: (0 - 1) wraps high)
+                v = 0;
+                for (int bit = KeyOf<T>::bits - 1; bit >= 0; --bit) {
+                    const K cand = v | (static_cast<K>(1) << bit);
+                    uint32_t cnt = 0;
+#pragma unroll
+                    for (int i = 0; i < KPL; ++i)
+                        cnt += static_cast<uint32_t>(__builtin_popcountll(
+                            __builtin_amdgcn_ballot_w64(static_cast<K>(key[i] - 1) < static_cast<K>(cand - 1))));
+                    if (cnt <= lo) v = cand;
+                }
+                cl = count_lt(v);
+                ev = count_eq(v);
             }
             // v = key of a[lo]; a[lo + 1]: v again if it is duplicated past lo, else the smallest key above v
-            uint32_t cle = 0;
-            K mn = ~static_cast<K>(0);
-#pragma unroll
-            for (int i = 0; i < KPL; ++i) {
-                cle += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(key[i] != 0 && key[i] <= v)));
-                if (key[i] > v && key[i] < mn) mn = key[i];
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const K o = static_cast<K>(__shfl_xor(static_cast<unsigned long long>(mn), off, 64));
-                mn = o < mn ? o : mn;
-            }
             K vhi = v;
-            if (lo + 1 < n && cle < lo + 2) vhi = mn;
+            if (lo + 1 < n && lo + 1 >= cl + ev) vhi = next_above(v);
             th = numpy_lerp(KeyOf<T>::value(v), KeyOf<T>::value(vhi), g);
         }
         if (lane == 0) thresh[static_cast<int64_t>(row) * ldo + c] = th;
@@ -124,8 +198,12 @@ hipError_t launch_redo(const float* ts, int64_t Tn, int64_t C, int64_t ld, const
     const int64_t nwords = static_cast<int64_t>(D) * ldb;
     hipLaunchKernelGGL(redo_collect, dim3(static_cast<unsigned>((nwords + 255) / 256)), dim3(256), 0, stream, bits, nwords,
                        ldb, list, count, cap);
-    hipLaunchKernelGGL(redo_run<float>, dim3(2048), dim3(256), 0, stream, ts, Tn, ld, row_ptr, centres, w, q, negate,
-                       thresh, ldo, list, count, cap);
+    if (w == 5)
+        hipLaunchKernelGGL((redo_run<float, 5>), dim3(2048), dim3(256), 0, stream, ts, Tn, ld, row_ptr, centres, w, q, negate,
+                           thresh, ldo, list, count, cap);
+    else
+        hipLaunchKernelGGL((redo_run<float, 0>), dim3(2048), dim3(256), 0, stream, ts, Tn, ld, row_ptr, centres, w, q, negate,
+                           thresh, ldo, list, count, cap);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // whatever did not fit the list (bits still set): the thread-per-cell-row kernel

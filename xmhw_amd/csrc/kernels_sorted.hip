@@ -556,10 +556,20 @@ __global__ __launch_bounds__(64) void clim_sorted_f32(
         a_hi = need2 ? a_hi : a_lo;
         B = a_lo;
         {
+            // a list stored to its last key, all of it inside the top set, with keys that were not stored: what was not
+            // stored is not above the list's last stored key U -- the row is wrong only if U lies above the key outside
+            // the top set (a tie with it is harmless: sea-ice plateaus, quantised values)
+            uint32_t atb = 0;
 #pragma unroll
             for (int j = 0; j < NL; ++j)
-                // a list stored to its last key, all of it inside the top set, with keys that were not stored
-                flag = flag || (P[j] == ltop[j] + (K + 1) * LSTRIDE && ((truncmask >> j) & 1u));     // (never the dummy: no bit)
+                atb |= (P[j] == ltop[j] + (K + 1) * LSTRIDE && ((truncmask >> j) & 1u)) ? (1u << j) : 0u;     // (never the dummy: no bit)
+            if (__any(atb != 0u)) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+                    const uint32_t Uj = lds_ld(P[j] - LSTRIDE);
+                    flag = flag || (((atb >> j) & 1u) && Uj > a_lo);
+                }
+            }
         }
         {
             // (NOT `flag || swp(...)`: the short-circuit would run the exchange with the flagged lanes switched off, and
