@@ -3,8 +3,8 @@
 // The sorted kernel flags a cell-row in a bitmap (bits[row * ldb + (cell >> 5)], bit cell & 31) when a row-list was too
 // short for the row; its `seas` is right (sums do not depend on the lists), its `thresh` is not.  Three launches, no
 // host round trip:
-//   redo_collect   thread per bitmap word: every set bit becomes an entry (row, cell) of a work list (an atomic counter
-//                  hands out the slots) and is cleared; bits that do not fit the list stay set;
+//   redo_collect   thread per cell: the cell's set bits become consecutive entries (row, cell) of a work list (one atomic
+//                  per cell reserves them) and are cleared; bits that do not fit the list stay set;
 //   redo_run       ONE WAVE per entry, a fixed grid striding over the list: the wave loads the row's pool (the samples
 //                  at centre +- w of every centre of the row: window_roll(), identify.py:184-209) -- nine keys per
 //                  lane --, starts from the sorted kernel's own (wrong, but close) answer, counts the keys below it and
@@ -17,29 +17,28 @@
 
 namespace xmhw {
 
-__global__ __launch_bounds__(256) void redo_collect(uint32_t* __restrict__ bits, int64_t nwords, int64_t ldb,
+// thread per CELL: the cell's flagged rows become consecutive entries of the work list (one atomic per cell reserves
+// them), so that the wave that takes them in redo_run works through a cell's neighbouring rows back to back -- their pools
+// overlap by (R - 1) / R and the second row's samples come from the caches instead of HBM again.
+__global__ __launch_bounds__(256) void redo_collect(uint32_t* __restrict__ bits, int64_t C, int32_t D, int64_t ldb,
                                                     unsigned long long* __restrict__ list, uint32_t* __restrict__ count,
                                                     uint32_t cap) {
-    const int64_t w = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (w >= nwords) return;
-    uint32_t word = bits[w];
-    if (word == 0u) return;
-    const uint64_t row = static_cast<uint64_t>(w / ldb);
-    const uint64_t cell0 = static_cast<uint64_t>(w % ldb) * 32u;
-    // (one atomic per word: the word's entries take consecutive slots)
-    const uint32_t nb = static_cast<uint32_t>(__builtin_popcount(word));
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const uint32_t* col = bits + (c >> 5);
+    const uint32_t bit = 1u << (c & 31);
+    uint32_t nb = 0;
+    for (int32_t r = 0; r < D; ++r) nb += (col[static_cast<int64_t>(r) * ldb] & bit) ? 1u : 0u;
+    if (nb == 0u) return;
     uint32_t idx = atomicAdd(count, nb);
-    uint32_t left = word;
-    while (word != 0u) {
-        const uint32_t b = static_cast<uint32_t>(__builtin_ctz(word));
-        word &= word - 1u;
+    for (int32_t r = 0; r < D; ++r) {
+        if ((col[static_cast<int64_t>(r) * ldb] & bit) == 0u) continue;
         if (idx < cap) {
-            list[idx] = (row << 40) | (cell0 + b);
-            left &= ~(1u << b);
+            list[idx] = (static_cast<unsigned long long>(r) << 40) | static_cast<unsigned long long>(c);
+            atomicAnd(&bits[static_cast<int64_t>(r) * ldb + (c >> 5)], ~bit);
         }
         ++idx;
     }
-    bits[w] = left;
 }
 
 // wave-wide helpers: every lane ends with the result
@@ -79,7 +78,11 @@ __global__ __launch_bounds__(256) void redo_run(const T* __restrict__ ts, int64_
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
     const int32_t w = W > 0 ? W : w_arg;
     const int32_t R = 2 * w + 1;
-    for (uint32_t e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); e < nent; e += nwaves) {
+    // (a wave takes a contiguous piece of the list: the entries of a cell are neighbours in it)
+    const uint32_t per = (nent + nwaves - 1) / nwaves;
+    const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t e_end = min((wid + 1) * per, nent);
+    for (uint32_t e = wid * per; e < e_end; ++e) {
         const unsigned long long ent = list[e];
         const int32_t row = static_cast<int32_t>(ent >> 40);
         const int64_t c = static_cast<int64_t>(ent & ((1ull << 40) - 1ull));
@@ -89,20 +92,34 @@ __global__ __launch_bounds__(256) void redo_run(const T* __restrict__ ts, int64_
         if (npool > KPL * 64) continue;
         const T* col = ts + c;
         K key[KPL];
+        {
+            // (branch-free, in three sweeps -- centre indices, centres, samples -- so that the nine loads of a sweep are in
+            // flight together: a wave pays two memory latencies per entry instead of eighteen)
+            int32_t off[KPL], cen[KPL];
+            bool inb[KPL];
 #pragma unroll
-        for (int i = 0; i < KPL; ++i) {
-            const int32_t p = lane + 64 * i;
-            K kk = 0;
-            if (p < npool) {
-                const int32_t ci = p / R;
-                const int64_t t = static_cast<int64_t>(centres[cb + ci]) + (p - ci * R - w);
-                if (t >= 0 && t < Tn) {
-                    T v = col[t * ld];
-                    if (negate) v = -v;
-                    kk = KeyOf<T>::key(v);
-                }
+            for (int i = 0; i < KPL; ++i) {
+                const int32_t p = lane + 64 * i;
+                inb[i] = p < npool;
+                const int32_t ci = inb[i] ? p / R : 0;
+                off[i] = p - ci * R - w;
+                cen[i] = centres[cb + ci];
             }
-            key[i] = kk;
+            T val[KPL];
+            bool ok[KPL];
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) {
+                const int64_t t = static_cast<int64_t>(cen[i]) + off[i];
+                ok[i] = inb[i] && t >= 0 && t < Tn;
+                const int64_t tc = t < 0 ? 0 : (t >= Tn ? Tn - 1 : t);
+                val[i] = col[tc * ld];
+            }
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) {
+                T v = val[i];
+                if (negate) v = -v;
+                key[i] = ok[i] ? KeyOf<T>::key(v) : static_cast<K>(0);
+            }
         }
         uint32_t n = 0;
 #pragma unroll
@@ -195,9 +212,8 @@ hipError_t launch_redo(const float* ts, int64_t Tn, int64_t C, int64_t ld, const
     if (C <= 0 || D <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    const int64_t nwords = static_cast<int64_t>(D) * ldb;
-    hipLaunchKernelGGL(redo_collect, dim3(static_cast<unsigned>((nwords + 255) / 256)), dim3(256), 0, stream, bits, nwords,
-                       ldb, list, count, cap);
+    hipLaunchKernelGGL(redo_collect, dim3(static_cast<unsigned>((C + 255) / 256)), dim3(256), 0, stream, bits, C, D, ldb, list,
+                       count, cap);
     if (w == 5)
         hipLaunchKernelGGL((redo_run<float, 5>), dim3(2048), dim3(256), 0, stream, ts, Tn, ld, row_ptr, centres, w, q, negate,
                            thresh, ldo, list, count, cap);
