@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--q", type=float, default=0.9)
+    ap.add_argument("--years", type=int, nargs=2, default=None, help="first and last year instead of the preset's")
     ap.add_argument("--gen", type=float, nargs=3, default=None, metavar=("QUANT", "ICE_FRAC", "RHO"),
                     help="the extended generator (xmhw_synth_sst_ex_f32) instead of the SURVEY 8(d) one")
     args = ap.parse_args()
@@ -34,6 +35,8 @@ def main():
                "0.25deg_nan": (1440 * 720, (1982, 2021), 0.05)}
     C, years, nan = presets[args.config]
     C = args.cells or C
+    if args.years:
+        years = tuple(args.years)
     doy = add_doy(np.arange(f"{years[0]}-01-01", f"{years[1] + 1}-01-01", dtype="datetime64[D]"))
     T = doy.shape[0]
     ts = dev.DeviceBuffer(4 * T * C)

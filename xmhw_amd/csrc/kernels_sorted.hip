@@ -89,8 +89,10 @@ typedef uint32_t V8 __attribute__((ext_vector_type(8)));
 
 // stats (STATS builds): [0] wave-rows, [1] walk iterations (what the wave pays), [2] flagged cell-rows, [3] walk steps
 // summed over cells, [8..15] shader-clock ticks per section (push, sort, bookkeeping, walk, epilogue)
+// (registers: LDS holds 6 waves per CU at K = 16 and more for shorter lists -- 8 at K = 12, 11 at K = 8: the shorter
+// records are asked to fit three waves per SIMD)
 template <int YPS, int K, bool STATS>
-__global__ __launch_bounds__(64) void clim_sorted_f32(
+__global__ __launch_bounds__(64, 2) void clim_sorted_f32(
     const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, const DevSortedChunk* __restrict__ chunks, double q, int negate,
     int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
