@@ -208,6 +208,7 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
     double e_total = 0.0, e_g = 0.0;
     uint32_t e_flag = 0;
 
+    bool nan_mode = false;         // (wave-uniform) the last plain row had a NaN sample
     int m = (ch.warm_start - step_min) % R;
     uint32_t sf_cur = __builtin_amdgcn_readfirstlane(sflags[ch.warm_start - step_min]);
     uint32_t sf_nxt = ch.warm_start + 1 < ch.end ? __builtin_amdgcn_readfirstlane(sflags[ch.warm_start + 1 - step_min]) : 0u;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
         uint32_t k[HE];
         double din = 0.0;
         uint32_t nvin = 0;
-        bool slow = !(sf & 1u);
+        bool slow = !(sf & 1u) || nan_mode;
         if (!slow) {
             // a plain row: every real track pushes a sample; NaN shows in the sum (so does +inf next to -inf: those
             // rows take the general path below, which gives the same keys)
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
             }
             nvin = padded_last ? YPS - 1 : YPS;
             slow = __any(din != din);
+            nan_mode = slow;      // (rows with NaN come in runs -- masked data: the next row goes straight to the general path)
         }
         if (slow) {
             uint32_t e[YPS];
@@ -265,14 +267,29 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
             }
             din = 0.0;
             nvin = 0;
+            // (the key through the two-instruction conversion, zeroed for a NaN or absent sample; the sample itself zeroed
+            // before it is widened; cold spells: key(-x) and the sum negated once)
+            if (negate) {
 #pragma unroll
-            for (int y = 0; y < YPS; ++y) {
-                const float xv = __uint_as_float(__float_as_uint(x_in[y]) ^ sgnflip);
-                const bool ok = xv == xv && (e[y] >> 1) >= 2u;
-                k[y] = ok ? f32_key(xv) : 0u;
-                din += ok ? static_cast<double>(xv) : 0.0;
-                nvin += ok ? 1u : 0u;
+                for (int y = 0; y < YPS; ++y) {
+                    const float xv = x_in[y];
+                    const bool ok = xv == xv && (e[y] >> 1) >= 2u;
+                    k[y] = ok ? key_fast<true>(__float_as_uint(xv)) : 0u;
+                    din += static_cast<double>(ok ? xv : 0.0f);
+                    nvin += ok ? 1u : 0u;
+                }
+                din = -din;
+            } else {
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) {
+                    const float xv = x_in[y];
+                    const bool ok = xv == xv && (e[y] >> 1) >= 2u;
+                    k[y] = ok ? key_fast<false>(__float_as_uint(xv)) : 0u;
+                    din += static_cast<double>(ok ? xv : 0.0f);
+                    nvin += ok ? 1u : 0u;
+                }
             }
+            if (sf & 1u) nan_mode = __any(nvin != static_cast<uint32_t>(padded_last ? YPS - 1 : YPS));
         }
 #pragma unroll
         for (int y = YPS; y < HE; ++y) k[y] = 0u;
