@@ -83,6 +83,24 @@ __device__ __forceinline__ uint32_t key_fast(uint32_t b) {
         return static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(sg, static_cast<int32_t>(b), static_cast<int32_t>(0x80000000u), 0x36));
 }
 
+// #{a0..a3 >= th}: four compares into four SGPR pairs, then four add-with-carry -- no wait states between a compare and
+// the instruction that reads its mask (left to the compiler every compare goes through VCC with an s_nop behind it)
+__device__ __forceinline__ uint32_t count_ge4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t th) {
+    uint32_t c = 0;
+    unsigned long long s0, s1, s2, s3, sd;
+    asm("v_cmp_ge_u32_e64 %[s0], %[a0], %[t]\n\t"
+        "v_cmp_ge_u32_e64 %[s1], %[a1], %[t]\n\t"
+        "v_cmp_ge_u32_e64 %[s2], %[a2], %[t]\n\t"
+        "v_cmp_ge_u32_e64 %[s3], %[a3], %[t]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s0]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s1]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s2]\n\t"
+        "v_addc_co_u32_e64 %[c], %[sd], %[c], 0, %[s3]"
+        : [c] "+v"(c), [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [sd] "=&s"(sd)
+        : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [t] "v"(th));
+    return c;
+}
+
 typedef uint32_t V8 __attribute__((ext_vector_type(8)));
 
 }  // namespace
@@ -504,11 +522,8 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
             uint32_t psum = 0;
 #pragma unroll
             for (int j = 0; j < NL; ++j) {
-                uint32_t c = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) c += a[j][i] >= th ? 1u : 0u;
-                pj[j] = c;
-                psum += c;
+                pj[j] = count_ge4(a[j][0], a[j][1], a[j][2], a[j][3], th);
+                psum += pj[j];
             }
             if (__any(tie)) {
                 asm volatile("" ::: "memory");          // (keep this a branch: plain rows never come here)
