@@ -73,8 +73,7 @@ __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b 
 // NEGATED sample, (~sign & 0x7FFFFFFF) ^ bits (the sign mask s of the sample itself, C = 0x80000000: ~s & ~C ^ bits)
 template <bool NEG>
 __device__ __forceinline__ uint32_t key_fast(uint32_t b) {
-    int32_t sg;
-    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(sg) : "v"(b));
+    const int32_t sg = static_cast<int32_t>(b) >> 31;
     // truth tables over (A = sign mask, B = bits, C = 0x80000000), bit index = A * 4 + B * 2 + C:
     //   (A | C) ^ B = 0x36      (~A & ~C) ^ B = 0xC9
     if constexpr (NEG)
@@ -243,6 +242,7 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
             // a plain row: every real track pushes a sample; NaN shows in the sum (so does +inf next to -inf: those
             // rows take the general path below, which gives the same keys)
             // (cold spells: key(-x) and -sum(x), one instruction per sample less than negating the samples)
+            double din1 = 0.0;
             if (negate) {
 #pragma unroll
                 for (int y = 0; y < YPS; ++y) {
@@ -254,8 +254,10 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
                     }
                     k[y] = ky;
                     const double dv = static_cast<double>(__uint_as_float(xb));
-                    din = y == 0 ? dv : din + dv;
+                    if (y & 1) din1 = y == 1 ? dv : din1 + dv;      // (two chains: a float64 add waits for the one before it)
+                    else din = y == 0 ? dv : din + dv;
                 }
+                din += din1;
                 din = -din;
             } else {
 #pragma unroll
@@ -268,8 +270,10 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
                     }
                     k[y] = ky;
                     const double dv = static_cast<double>(__uint_as_float(xb));
-                    din = y == 0 ? dv : din + dv;
+                    if (y & 1) din1 = y == 1 ? dv : din1 + dv;      // (two chains: a float64 add waits for the one before it)
+                    else din = y == 0 ? dv : din + dv;
                 }
+                din += din1;
             }
             nvin = padded_last ? YPS - 1 : YPS;
             slow = __any(din != din);
