@@ -184,7 +184,20 @@ def test_chunked_equals_unchunked(dev):
     a = _raw(dev, x, doy, nchunks=1, layout="sorted")
     b = _raw(dev, x, doy, nchunks=5, layout="sorted")
     npt.assert_array_equal(a[0], b[0])
-    npt.assert_allclose(a[1], b[1], rtol=1e-12, equal_nan=True)
+    npt.assert_array_equal(a[1], b[1])      # (seas too: the pool's total is a fixed-order sum of the list sums, the slot of a
+    #                                          step does not depend on the chunk)
+
+
+def test_a_grid_split_by_cells_is_bit_identical_to_the_whole(dev):
+    """what the sharded path relies on: a block of columns computed on its own (another grid width, so another cut of
+    the row axis into pieces) gives the same bits as the same columns inside the whole grid"""
+    doy = _daily(1982, 2021)
+    x = _series(doy.shape[0], 200, 31, nanfrac=0.01)
+    whole = _raw(dev, x, doy, layout="sorted")
+    for a, b in ((0, 37), (37, 200)):
+        part = _raw(dev, np.ascontiguousarray(x[:, a:b]), doy, layout="sorted")
+        npt.assert_array_equal(part[0], whole[0][:, a:b])
+        npt.assert_array_equal(part[1], whole[1][:, a:b])
 
 
 def test_partial_first_and_last_year(dev):

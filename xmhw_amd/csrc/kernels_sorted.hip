@@ -226,7 +226,9 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
     uint32_t e_flag = 0;
 
     bool nan_mode = false;         // (wave-uniform) the last plain row had a NaN sample
-    int m = (ch.warm_start - step_min) % R;
+    // (the slot of a step is a function of the step itself, not of the chunk: with the fixed-order total below the
+    // outputs do not depend on how the row axis is cut -- a grid split over N ranks is bit-identical to the whole)
+    int m = ((ch.warm_start % R) + R) % R;
     uint32_t sf_cur = __builtin_amdgcn_readfirstlane(sflags[ch.warm_start - step_min]);
     uint32_t sf_nxt = ch.warm_start + 1 < ch.end ? __builtin_amdgcn_readfirstlane(sflags[ch.warm_start + 1 - step_min]) : 0u;
     for (int32_t s = ch.warm_start; s < ch.end; ++s) {
@@ -357,15 +359,12 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
         for (int i = 0; i < KH; ++i) lds_st(base_m + static_cast<uint32_t>(1 + sub * KH + i) * LSTRIDE, u[i]);
         // what leaves: the evicted list's share of the top set, its valid keys, its sum
         uint32_t c_old = 0, nv_old = 0;
-        double rs_old = 0.0;
         {
             const uint32_t Pm = P[mj];
             const uint32_t nvm = nvl[mj];
-            const double rsm = __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(rs_hi[mj]) << 32) | rs_lo[mj]));
             if (own_m) {
                 c_old = ((Pm - base_m) >> 7) - 1u;
                 nv_old = nvm;
-                rs_old = rsm;
             }
         }
         // what comes: keys above the carried boundary join the top set
@@ -383,10 +382,8 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
             nv_old = po & 0xFFFFu;
         }
         din += swp(din);
-        rs_old += swp(rs_old);
         Ctop += c_new - c_old;
         n += nvin - nv_old;
-        total += din - rs_old;
         P[mj] = own_m ? base_m + (1u + c_new) * LSTRIDE : P[mj];
         if (own_m) truncmask = (truncmask & ~(1u << mj)) | ((nvin > static_cast<uint32_t>(K) ? 1u : 0u) << mj);
         {
@@ -395,8 +392,9 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
             rs_lo[mj] = own_m ? static_cast<uint32_t>(db) : rs_lo[mj];
             rs_hi[mj] = own_m ? static_cast<uint32_t>(db >> 32) : rs_hi[mj];
         }
-        if (!(fabs(total) <= 1.7976931348623157e308)) {
-            // an infinity in the pool, or one that has just left it: the total is taken from the list sums again
+        {
+            // the pool's total: the 11 list sums added in slot order, every row (a running total would round differently
+            // for every cut of the row axis, and an infinity that has left the pool would stay in it)
             double tsum = 0.0;
 #pragma unroll
             for (int j = 0; j < NL; ++j)
