@@ -380,6 +380,23 @@ def run(args):
             _rows_per_wave = float(np.mean(_chunks[:, 2] - _chunks[:, 0]))
         _p.destroy()
         traffic, traffic_src, sq = live_counters(child_argv, _rows_per_wave)
+        # the issue floor of the sorted-list kernel: its vector instructions by issue class (from the ISA, hipcc
+        # -S on this box: no GPU) priced with the measured per-class costs, against the live counters -- tools/issue_mix.py
+        if sq is not None and "clim_sorted" in str(sq.get("kernel", "")):
+            try:
+                rounds = 1.26
+                tk = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r5_ticks.jsonl")
+                if os.path.exists(tk):
+                    first = json.loads(open(tk).readline())
+                    rounds = float(first["sorted"]["walk_iterations_per_wave_row"])
+                r_ = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "issue_mix.py"),
+                                     "--rounds", str(rounds), "--measured-valu", str(sq["valu_per_wave_row"]),
+                                     "--measured-quad-cycles", str(sq["wave_quad_cycles_per_wave_row"])],
+                                    stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+                if r_.returncode == 0:
+                    sq["issue_mix"] = json.loads(r_.stdout.decode())
+            except Exception:      # noqa: BLE001 -- the floor is a report, not the benchmark
+                pass
 
     from xmhw_amd._lib import hip
     from xmhw_amd.device import DeviceBuffer, Plan, clim_finish, clim_raw, release_device_cache
@@ -533,6 +550,11 @@ def run(args):
                 "valu_busy_of_wave_cycles": sq["valu_busy_of_wave_cycles"],
                 "wait_any_of_wave_cycles": sq["wait_any_of_wave_cycles"],
                 "frac_of_issue_peak": min((waves_cu / 4.0 if v2 == 40 else 2.0) * sq["valu_busy_of_wave_cycles"], 1.0),
+                # priced per issue class (tools/issue_mix.py): SIMD cycles a wave-row needs at least, and how close the kernel is
+                "issue_floor_cycles_per_wave_row": None if "issue_mix" not in sq else sq["issue_mix"]["issue_floor_cycles_per_wave_row"],
+                "class_B_share_of_valu": None if "issue_mix" not in sq else sq["issue_mix"]["class_B_share"],
+                "frac_of_issue_floor": None if "issue_mix" not in sq else sq["issue_mix"].get("frac_of_issue_floor_at_this_occupancy"),
+                "frac_of_issue_floor_at_two_waves_per_simd": None if "issue_mix" not in sq else sq["issue_mix"].get("frac_of_issue_floor_at_two_waves_per_simd"),
                 "kernel": sq["kernel"], "source": "rocprofv3 --pmc SQ_* on one step of this run's box and workload "
                                                    "(the product kernel, no counter twin)"},
         },

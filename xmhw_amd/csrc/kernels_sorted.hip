@@ -535,11 +535,9 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
                 uint32_t gsum = 0;
 #pragma unroll
                 for (int j = 0; j < NL; ++j) {
-                    uint32_t c = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) c += a[j][i] > tl ? 1u : 0u;
-                    gj[j] = c;
-                    gsum += c;
+                    // (keys above tl = keys at or above tl + 1; tl is a real key here, never all ones)
+                    gj[j] = count_ge4(a[j][0], a[j][1], a[j][2], a[j][3], tl + 1u);
+                    gsum += gj[j];
                 }
                 const uint32_t G = gsum + swp(gsum);
                 const uint32_t e_mine = psum - gsum;
