@@ -61,10 +61,15 @@ PRESETS = {
     "0.05deg_tstep": dict(cells=810000, years=(2001, 2020), nan=0.0, tstep=True, skipna=False, index=4,
                           name="0.05deg tile share, 6-hourly no-leap tstep (configs[4], one GPU's share)"),
     # configs[2]'s shape on data that looks like a real archive: values stored at 0.01 K with 10 % of the cells
-    # held at -1.8 for 120 days a year (sea ice); AR(1) anomalies (rho = 0.9) instead of white noise.  Never the headline.
+    # held at -1.8 for 120 days a year (sea ice: scattered cells, each with its own season -- the worst case for 32 cells in
+    # lockstep -- and packs of neighbouring cells that freeze together); AR(1) anomalies (rho = 0.9) instead of white noise.  Never the headline.
     "0.25deg_quant_ice": dict(cells=1440 * 720, years=(1982, 2021), nan=0.0, tstep=False, skipna=False, index=2,
                               gen=dict(quant=0.01, ice_frac=0.10, rho=0.0),
                               name="0.25deg global, values at 0.01 K, 10 % of cells at -1.8 for 120 days a year (configs[2] shape)"),
+    "0.25deg_quant_icepack": dict(cells=1440 * 720, years=(1982, 2021), nan=0.0, tstep=False, skipna=False, index=2,
+                                  gen=dict(quant=0.01, ice_frac=0.10, rho=0.0, ice_patch=4320),
+                                  name="0.25deg global, values at 0.01 K, 10 % of cells under ice 120 days a year in packs of 4,320 "
+                                       "neighbouring cells that freeze within 15 days of each other (configs[2] shape)"),
     "0.25deg_ar1": dict(cells=1440 * 720, years=(1982, 2021), nan=0.0, tstep=False, skipna=False, index=2,
                         gen=dict(quant=0.0, ice_frac=0.0, rho=0.9),
                         name="0.25deg global, AR(1) anomalies rho = 0.9 (configs[2] shape)"),
@@ -253,7 +258,7 @@ def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, c
         ts = DeviceBuffer(isz * T * C); bufs.append(ts)
         if ps.get("gen"):
             h.synth_sst_ex(ts.ptr, T, C, C, 0, 20260101 + ps["index"], ps["nan"], ps["gen"]["quant"], ps["gen"]["ice_frac"],
-                           ps["gen"]["rho"], 0)
+                           ps["gen"]["rho"], ps["gen"].get("ice_patch", 0), 0)
         else:
             h.synth_sst(ts.ptr, isz, T, C, C, 0, 20260101 + ps["index"], ps["nan"], 0)
         th, se = DeviceBuffer(8 * D * C), DeviceBuffer(8 * D * C)
@@ -704,7 +709,7 @@ def run(args):
         others = []
         for ocfg, odt in (("0.25deg", "f64"), ("1deg", "f32"), ("1deg", "f64"), ("0.25deg_nan", "f32"),
                           ("0.05deg_tstep", "f32"), ("0.05deg_tstep", "f64"), ("0.25deg_quant_ice", "f32"),
-                          ("0.25deg_ar1", "f32")):
+                          ("0.25deg_quant_icepack", "f32"), ("0.25deg_ar1", "f32")):
             if ocfg == cfg and odt == args.dtype:
                 continue
             try:

@@ -404,9 +404,13 @@ int xmhw_synth_sst_f64(double *ts_dev, int64_t T, int64_t C, int64_t ld, int64_t
                        uint64_t seed, double nan_frac, void *stream);
 /* the same with what real archives add (bench legs): values rounded to multiples of `quant` (OISST: 0.01; 0 = off), a
  * share `ice_frac` of the cells held at -1.8 for 120 days of every year, AR(1) anomalies with day-to-day correlation
- * `rho` (unit variance; 0 = the white noise of xmhw_synth_sst_f32, to which this is then bit-identical)           */
+ * `rho` (unit variance; 0 = the white noise of xmhw_synth_sst_f32, to which this is then bit-identical).  ice_patch:
+ * the ice cells come in patches of that many consecutive cells with one season start per patch and +-15 days per cell
+ * (an ice pack: neighbours freeze together); <= 1 = every cell decides and freezes on its own (scattered: the worst
+ * case for a kernel that runs 32 neighbouring cells in lockstep)                                                     */
 int xmhw_synth_sst_ex_f32(float *ts_dev, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
-                          double nan_frac, double quant, double ice_frac, double rho, void *stream);
+                          double nan_frac, double quant, double ice_frac, double rho, int64_t ice_patch,
+                          void *stream);
 
 /* The detect-side entries above take host row tables (row_of_t).  Their device copies (and the tiled
  * exceedance kernel's chunk tables, and per-stream scratch such as the float32 threshold copy) are

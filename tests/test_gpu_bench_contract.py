@@ -26,7 +26,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     oc = d["other_configs"]
     # (round 4: six of them -- float64 legs of configs[1] and of the configs[4] share too -- each with its own parity sample;
     # round 5: two more on configs[2]'s shape -- values at 0.01 K with sea-ice plateaus, AR(1) anomalies)
-    assert len(oc) == 8 and all("error" not in o for o in oc), oc
+    assert len(oc) == 9 and all("error" not in o for o in oc), oc
     assert sum(o["dtype"].startswith("f64") for o in oc) == 3
     assert sum("0.01 K" in o["workload"] or "AR(1)" in o["workload"] for o in oc) == 2
     assert all(o["parity_cells"] >= 16 for o in oc)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--q", type=float, default=0.9)
     ap.add_argument("--years", type=int, nargs=2, default=None, help="first and last year instead of the preset's")
+    ap.add_argument("--ice-patch", type=int, default=0, help="ice cells in patches of that many cells (0: scattered)")
     ap.add_argument("--gen", type=float, nargs=3, default=None, metavar=("QUANT", "ICE_FRAC", "RHO"),
                     help="the extended generator (xmhw_synth_sst_ex_f32) instead of the SURVEY 8(d) one")
     args = ap.parse_args()
@@ -41,7 +42,7 @@ def main():
     T = doy.shape[0]
     ts = dev.DeviceBuffer(4 * T * C)
     if args.gen:
-        h.synth_sst_ex(ts.ptr, T, C, C, 0, 20260103, nan, args.gen[0], args.gen[1], args.gen[2], 0)
+        h.synth_sst_ex(ts.ptr, T, C, C, 0, 20260103, nan, args.gen[0], args.gen[1], args.gen[2], args.ice_patch, 0)
     else:
         h.synth_sst(ts.ptr, 4, T, C, C, 0, 20260103, nan, 0)
     ref = None

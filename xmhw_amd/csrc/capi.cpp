@@ -1584,11 +1584,11 @@ int xmhw_synth_sst_f32(float* ts, int64_t T, int64_t C, int64_t ld, int64_t cell
     return XMHW_OK;
 }
 int xmhw_synth_sst_ex_f32(float* ts, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed, double nan_frac,
-                          double quant, double ice_frac, double rho, void* stream) {
+                          double quant, double ice_frac, double rho, int64_t ice_patch, void* stream) {
     if (!ts || T < 0 || C < 0 || ld < C) return fail(XMHW_ERR_INVALID, "bad argument");
     if (!(rho >= 0.0 && rho < 1.0) || quant < 0.0 || ice_frac < 0.0 || ice_frac > 1.0)
         return fail(XMHW_ERR_INVALID, "rho must be in [0, 1), quant >= 0, ice_frac in [0, 1]");
-    hipError_t e = xmhw::launch_synth_ex<float>(ts, T, C, ld, cell0, seed, nan_frac, quant, ice_frac, rho,
+    hipError_t e = xmhw::launch_synth_ex<float>(ts, T, C, ld, cell0, seed, nan_frac, quant, ice_frac, rho, ice_patch,
                                                 static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail(e, "synth launch");
     return XMHW_OK;

@@ -208,6 +208,6 @@ hipError_t launch_synth(T* ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0,
 
 template <typename T>
 hipError_t launch_synth_ex(T* ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0, uint64_t seed, double nan_frac,
-                           double quant, double ice_frac, double rho, hipStream_t stream);
+                           double quant, double ice_frac, double rho, int64_t ice_patch, hipStream_t stream);
 
 }  // namespace xmhw

@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256) void synth_sst(T* __restrict__ ts, int64_t Tn,
 template <typename T>
 __global__ __launch_bounds__(256) void synth_sst_ex(T* __restrict__ ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0,
                                                     uint64_t seed, double nan_frac, double quant, double ice_frac,
-                                                    double rho) {
+                                                    double rho, int64_t ice_patch) {
     const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const uint64_t cell = static_cast<uint64_t>(cell0 + c);
@@ -730,8 +730,11 @@ __global__ __launch_bounds__(256) void synth_sst_ex(T* __restrict__ ts, int64_t 
     const double A = 2.0 + 8.0 * u01(mix64(hc ^ 0xA1));
     const double phi = 365.0 * u01(mix64(hc ^ 0xB2));
     const double beta = 2.0 * u01(mix64(hc ^ 0xC3)) - 1.0;
-    const bool ice = ice_frac > 0.0 && u01(mix64(hc ^ 0xF6)) < ice_frac;
-    const double ice0 = 365.25 * u01(mix64(hc ^ 0x17));            // start of the cell's ice season (day of the year)
+    // (ice_patch > 1: the patch decides whether it freezes and when, a cell starts within 15 days of its patch)
+    const uint64_t hp = ice_patch > 1 ? mix64(seed * 0x100000001B3ull + 0x5851F42D4C957F2Dull * (cell / static_cast<uint64_t>(ice_patch) + 1ull)) : hc;
+    const bool ice = ice_frac > 0.0 && u01(mix64(hp ^ 0xF6)) < ice_frac;
+    const double ice0 = 365.25 * u01(mix64(hp ^ 0x17)) +           // start of the cell's ice season (day of the year)
+                        (ice_patch > 1 ? 30.0 * u01(mix64(hc ^ 0x28)) - 15.0 : 0.0);
     const double srho = sqrt(1.0 - rho * rho);
     double e = 0.0;
     for (int64_t t = 0; t < Tn; ++t) {
@@ -754,16 +757,16 @@ __global__ __launch_bounds__(256) void synth_sst_ex(T* __restrict__ ts, int64_t 
 
 template <typename T>
 hipError_t launch_synth_ex(T* ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0, uint64_t seed, double nan_frac,
-                           double quant, double ice_frac, double rho, hipStream_t stream) {
+                           double quant, double ice_frac, double rho, int64_t ice_patch, hipStream_t stream) {
     if (C <= 0 || Tn <= 0) return hipSuccess;
     hipLaunchKernelGGL(synth_sst_ex<T>, dim3(static_cast<unsigned>((C + 255) / 256)), dim3(256), 0, stream, ts, Tn, C, ld,
-                       cell0, seed, nan_frac, quant, ice_frac, rho);
+                       cell0, seed, nan_frac, quant, ice_frac, rho, ice_patch);
     return hipGetLastError();
 }
 template hipError_t launch_synth_ex<float>(float*, int64_t, int64_t, int64_t, int64_t, uint64_t, double, double, double,
-                                           double, hipStream_t);
+                                           double, int64_t, hipStream_t);
 template hipError_t launch_synth_ex<double>(double*, int64_t, int64_t, int64_t, int64_t, uint64_t, double, double, double,
-                                            double, hipStream_t);
+                                            double, int64_t, hipStream_t);
 
 template <typename T>
 hipError_t launch_synth(T* ts, int64_t Tn, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,

@@ -509,10 +509,10 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     }, py::arg("counts"), py::arg("n"), py::arg("offsets"), py::arg("stream") = 0);
 
     m.def("synth_sst_ex", [](uintptr_t ts, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed, double nan_frac,
-                             double quant, double ice_frac, double rho, uintptr_t stream) {
-        check(xmhw_synth_sst_ex_f32(static_cast<float*>(vp(ts)), T, C, ld, cell0, seed, nan_frac, quant, ice_frac, rho, vp(stream)));
+                             double quant, double ice_frac, double rho, int64_t ice_patch, uintptr_t stream) {
+        check(xmhw_synth_sst_ex_f32(static_cast<float*>(vp(ts)), T, C, ld, cell0, seed, nan_frac, quant, ice_frac, rho, ice_patch, vp(stream)));
     }, py::arg("ts"), py::arg("T"), py::arg("C"), py::arg("ld"), py::arg("cell0"), py::arg("seed"), py::arg("nan_frac") = 0.0,
-       py::arg("quant") = 0.0, py::arg("ice_frac") = 0.0, py::arg("rho") = 0.0, py::arg("stream") = 0);
+       py::arg("quant") = 0.0, py::arg("ice_frac") = 0.0, py::arg("rho") = 0.0, py::arg("ice_patch") = 0, py::arg("stream") = 0);
     m.def("synth_sst", [](uintptr_t ts, int itemsize, int64_t T, int64_t C, int64_t ld, int64_t cell0, uint64_t seed,
                           double nan_frac, uintptr_t stream) {
         if (itemsize == 4)
