@@ -552,6 +552,7 @@ def run(args):
                 "insts_per_wave_row": {"valu": sq["valu_per_wave_row"], "salu": sq["salu_per_wave_row"],
                                        "lds": sq["lds_per_wave_row"]},
                 "cells_per_wave": 16 if v2 in (21, 31) else 32 if v2 in (22, 32, 40) else 8,
+                "wave_quad_cycles_per_wave_row": sq["wave_quad_cycles_per_wave_row"],
                 "valu_busy_of_wave_cycles": sq["valu_busy_of_wave_cycles"],
                 "wait_any_of_wave_cycles": sq["wait_any_of_wave_cycles"],
                 "frac_of_issue_peak": min((waves_cu / 4.0 if v2 == 40 else 2.0) * sq["valu_busy_of_wave_cycles"], 1.0),

@@ -6,6 +6,9 @@
 #   r5_pmc_sq_prod.txt     SQ counters of the PRODUCT kernel clim_sorted_f32<20, 16, false> (own --pmc pass)
 #   r5_pmc_lds_prod.txt    its LDS counters (own --pmc pass)
 #   r5_ticks.jsonl         section ticks + counters of the STATS twin (ab/stats.so, if present): white noise, quantised + ice
+#                          (scattered cells, ice packs), 5 % NaN
+#   r5_issue_mix.json      the vector instructions of the product kernel by issue class and its issue floor (tools/issue_mix.py
+#                          with this run's SQ counters)
 # Every step runs under its own timeout; the program sits directly after `--`.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r5; mkdir -p $O
@@ -39,7 +42,7 @@ PY
 head -6 $O/r5_kernel_stats.csv | cut -c1-160
 if [ -f $R/ab/stats.so ]; then
   cp $R/xmhw_amd/libxmhw_amd.so /tmp/lib_keep.so; cp $R/ab/stats.so $R/xmhw_amd/libxmhw_amd.so
-  (timeout 120 python3 $R/tools/bench_sorted.py --layouts 40 --reps 3; timeout 120 python3 $R/tools/bench_sorted.py --layouts 40 --reps 3 --gen 0.01 0.1 0; timeout 120 python3 $R/tools/bench_sorted.py --layouts 40 --reps 3 --config 0.25deg_nan) > $O/r5_ticks.jsonl 2> $O/ticks.err
+  (timeout 120 python3 $R/tools/bench_sorted.py --layouts 40 --reps 3; timeout 120 python3 $R/tools/bench_sorted.py --layouts 40 --reps 3 --gen 0.01 0.1 0; timeout 120 python3 $R/tools/bench_sorted.py --layouts 40 --reps 3 --gen 0.01 0.1 0 --ice-patch 4320; timeout 120 python3 $R/tools/bench_sorted.py --layouts 40 --reps 3 --config 0.25deg_nan) > $O/r5_ticks.jsonl 2> $O/ticks.err
   cp /tmp/lib_keep.so $R/xmhw_amd/libxmhw_amd.so; cat $O/r5_ticks.jsonl
 fi
 python3 -c "
@@ -49,4 +52,13 @@ print('binding', d['roofline']['binding'])
 print('parity', d['parity']); print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
 for o in d['other_configs']: print(o.get('workload','')[:50], o.get('dtype'), o.get('ms_per_step'), o.get('kernel_avg_launch_ms'), o.get('roofline_frac'), o.get('parity_cells'), o.get('parity_ok'), o.get('error'), o.get('note'))
 "
+python3 - <<PY
+import json, subprocess, sys
+d = json.load(open('$O/r5_bench.json')); b = d['roofline']['binding']
+tk = json.loads(open('$O/r5_ticks.jsonl').readline())['sorted']['walk_iterations_per_wave_row'] if __import__('os').path.exists('$O/r5_ticks.jsonl') else 1.26
+out = subprocess.run([sys.executable, '$R/tools/issue_mix.py', '--rounds', str(tk), '--measured-valu', str(b['insts_per_wave_row']['valu']),
+                      '--measured-quad-cycles', str(b['wave_quad_cycles_per_wave_row'])], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+open('$O/r5_issue_mix.json', 'wb').write(out.stdout); open('$O/r5_issue_mix.txt', 'wb').write(out.stderr)
+print(out.stderr.decode()[-900:])
+PY
 tail -3 $O/bench.err
