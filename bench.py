@@ -70,6 +70,12 @@ PRESETS = {
                                   gen=dict(quant=0.01, ice_frac=0.10, rho=0.0, ice_patch=4320),
                                   name="0.25deg global, values at 0.01 K, 10 % of cells under ice 120 days a year in packs of 4,320 "
                                        "neighbouring cells that freeze within 15 days of each other (configs[2] shape)"),
+    # configs[2]'s shape stored as int16 codes (OISST: scale_factor 0.01, add_offset 0, _FillValue -999) and read IN PLACE by
+    # the sorted-list kernel (xmhw_clim_raw_i16): no decoded copy of the series, T * 2 bytes per cell instead of T * 4 / T * 8.
+    # dtype "i16>f32" = the float32 decode xarray applies for float32 attributes, "i16>f64" = float64 attributes.
+    "0.25deg_packed": dict(cells=1440 * 720, years=(1982, 2021), nan=0.0, tstep=False, skipna=False, index=2,
+                           gen=dict(quant=0.01, ice_frac=0.0, rho=0.0), packed=dict(scale=0.01, offset=0.0, fill=-999),
+                           name="0.25deg global stored as int16 codes (scale_factor 0.01), read in place (configs[2] shape)"),
     "0.25deg_ar1": dict(cells=1440 * 720, years=(1982, 2021), nan=0.0, tstep=False, skipna=False, index=2,
                         gen=dict(quant=0.0, ice_frac=0.0, rho=0.9),
                         name="0.25deg global, AR(1) anomalies rho = 0.9 (configs[2] shape)"),
@@ -249,14 +255,27 @@ def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, c
     else:
         doy = add_doy(np.arange(f"{ps['years'][0]}-01-01", f"{ps['years'][1] + 1}-01-01", dtype="datetime64[D]"))
     T, C = int(doy.shape[0]), int(cells) or int(args.other_cells) or ps["cells"]
-    isz = 4 if dtype == "f32" else 8
+    packed = ps.get("packed") if dtype.startswith("i16") else None
+    isz = 2 if packed else 4 if dtype == "f32" else 8
     w, pctile, width = 5, 90, 31
     plan = Plan(doy, w, kernel=args.kernel, nchunks=args.chunks, ring2=args.ring2 if isz == 4 else None)
     D = plan.D
     bufs = []
     try:
         ts = DeviceBuffer(isz * T * C); bufs.append(ts)
-        if ps.get("gen"):
+        if packed:
+            # the synthetic series, then its codes (the float32 copy is released before anything is timed)
+            from xmhw_amd.device import clim_raw_packed
+            f32 = DeviceBuffer(4 * T * C)
+            h.synth_sst_ex(f32.ptr, T, C, C, 0, 20260101 + ps["index"], ps["nan"], ps["gen"]["quant"], ps["gen"]["ice_frac"],
+                           ps["gen"]["rho"], ps["gen"].get("ice_patch", 0), 0)
+            h.encode_i16(f32.ptr, T, C, C, ts.ptr, C, packed["scale"], packed["offset"], packed["fill"], 0)
+            h.stream_sync(0)
+            f32.free()
+            dec = "float64" if dtype.endswith("f64") else "float32"
+            # (float32 attributes are float32 numbers: the recipe xarray would apply)
+            sc, of = (packed["scale"], packed["offset"]) if dec == "float64" else (float(np.float32(packed["scale"])), float(np.float32(packed["offset"])))
+        elif ps.get("gen"):
             h.synth_sst_ex(ts.ptr, T, C, C, 0, 20260101 + ps["index"], ps["nan"], ps["gen"]["quant"], ps["gen"]["ice_frac"],
                            ps["gen"]["rho"], ps["gen"].get("ice_patch", 0), 0)
         else:
@@ -274,7 +293,7 @@ def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, c
         fin = h.stream_create() if nslab > 1 else 0
         evs = [(h.event_create(), h.event_create()) for _ in range(nslab)]
         ring_ms = []
-        main_timed = isz == 4 and plan.kernel == "ring"
+        main_timed = isz in (2, 4) and plan.kernel == "ring"
         if main_timed:
             h.plan_set_timing(plan.handle, 1)
 
@@ -282,7 +301,11 @@ def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, c
             for i in range(nslab):
                 a, n = edges[i], edges[i + 1] - edges[i]
                 h.event_record(evs[i][0], 0)
-                clim_raw(plan, ts.ptr + isz * a, isz, n, pctile / 100.0, False, th.ptr + 8 * a, se.ptr + 8 * a, ld=C, ldo=C)
+                if packed:
+                    clim_raw_packed(plan, ts.ptr + isz * a, n, pctile / 100.0, False, th.ptr + 8 * a, se.ptr + 8 * a, scale_factor=sc,
+                                    add_offset=of, fill=packed["fill"], decoded=dec, ld=C, ldo=C)
+                else:
+                    clim_raw(plan, ts.ptr + isz * a, isz, n, pctile / 100.0, False, th.ptr + 8 * a, se.ptr + 8 * a, ld=C, ldo=C)
                 h.event_record(evs[i][1], 0)
                 if nslab > 1:
                     h.stream_wait_event(fin, evs[i][1])
@@ -301,21 +324,29 @@ def _other_config(h, np, fast, cfg, dtype, args, DeviceBuffer, Plan, clim_raw, c
         ms = 1e3 * (time.perf_counter() - t0) / steps
         idx = np.unique(np.linspace(0, C - 1, parity_cells).astype(np.int64))
         d_idx = DeviceBuffer.from_array(idx); bufs.append(d_idx)
-        d_s = DeviceBuffer(isz * T * idx.size); bufs.append(d_s)
-        h.gather_cells(ts.ptr, isz, T, C, d_idx.ptr, idx.size, d_s.ptr, idx.size)
+        src, sisz = ts, isz
+        if packed:
+            # parity against the oracle on the DECODED series (xmhw_decode: what the float paths would have been handed)
+            sisz = 8 if dec == "float64" else 4
+            src = DeviceBuffer(sisz * T * C); bufs.append(src)
+            h.decode(ts.ptr, 2, 0, T, C, C, src.ptr, sisz, C, True, sc, of, True, float(packed["fill"]), 0)
+        d_s = DeviceBuffer(sisz * T * idx.size); bufs.append(d_s)
+        h.gather_cells(src.ptr, sisz, T, C, d_idx.ptr, idx.size, d_s.ptr, idx.size)
         d_o = DeviceBuffer(8 * 2 * D * idx.size); bufs.append(d_o)
         h.gather_cells(out.ptr, 8, 2 * D, C, d_idx.ptr, idx.size, d_o.ptr, idx.size)
         h.stream_sync(0)
-        sample = d_s.to_array((T, idx.size), np.float32 if isz == 4 else np.float64)
+        sample = d_s.to_array((T, idx.size), np.float32 if (sisz if packed else isz) == 4 else np.float64)
         got = d_o.to_array((2 * D, idx.size), np.float64)
         _, th0, se0 = fast.threshold_cells_fast(sample, doy, pctile=pctile, windowHalfWidth=w, smoothPercentileWidth=width,
                                                 tstep=tstep)
         with np.errstate(invalid="ignore", divide="ignore"):
             err = max(float(np.nanmax(np.abs(got[:D] - th0) / np.abs(th0))), float(np.nanmax(np.abs(got[D:] - se0) / np.abs(se0))))
-        v2 = plan.ring2_in_use() if isz == 4 and plan.kernel == "ring" else -1
+        v2 = plan.ring2_in_use() if isz in (2, 4) and plan.kernel == "ring" else -1
         x64 = plan.f64_mode() if isz == 8 and plan.kernel == "ring" else -1
         kname = (_ring_name(v2) if v2 >= 0 else
                  _ring_name_f64(x64) if x64 >= 0 else "clim_generic")
+        if packed:
+            kname = kname.replace("clim_sorted_f32", "clim_sorted_i16 (int16 codes read in place)")
         bpc = T * isz + 2 * D * 8
         ring_avg = float(np.mean(ring_ms))
         return {"workload": f"{ps['name']}: {C} cells, T={T}, D={D}, nan_frac={ps['nan']}", "dtype": f"{dtype} in / f64 out",
@@ -710,7 +741,8 @@ def run(args):
         others = []
         for ocfg, odt in (("0.25deg", "f64"), ("1deg", "f32"), ("1deg", "f64"), ("0.25deg_nan", "f32"),
                           ("0.05deg_tstep", "f32"), ("0.05deg_tstep", "f64"), ("0.25deg_quant_ice", "f32"),
-                          ("0.25deg_quant_icepack", "f32"), ("0.25deg_ar1", "f32")):
+                          ("0.25deg_quant_icepack", "f32"), ("0.25deg_ar1", "f32"),
+                          ("0.25deg_packed", "i16>f32"), ("0.25deg_packed", "i16>f64")):
             if ocfg == cfg and odt == args.dtype:
                 continue
             try:

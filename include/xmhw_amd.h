@@ -84,6 +84,11 @@ int xmhw_event_sync(void *event);                           /* block the host un
 int xmhw_decode(const void *raw_dev, int raw_itemsize, int big_endian, int64_t rows, int64_t cols,
                 int64_t ld_raw, void *out_dev, int out_itemsize, int64_t ld_out, int has_scale,
                 double scale_factor, double add_offset, int has_fill, double fill_value, void *stream);
+/* the inverse for float32 -> int16 codes (what writing a packed archive does: xarray's CF encoding): code =
+ * rint((x - add_offset) / scale_factor) computed in float64 and clamped to [-32767, 32767]; NaN -> fill_code.  bench.py
+ * and the tests make packed input for xmhw_clim_raw_i16 with it.                                              */
+int xmhw_encode_i16(const float *in_dev, int64_t rows, int64_t cols, int64_t ld_in, int16_t *out_dev, int64_t ld_out,
+                    double scale_factor, double add_offset, int32_t fill_code, void *stream);
 /* File bytes -> a (page-locked) host buffer without mapping the file: `rows` strips of row_bytes bytes,
  * row_pitch apart in the file starting at file_offset, are read with pread() into a dense buffer.
  * Thread-safe; the ingest path calls it from many threads at once (copies out of an mmap() of the same
@@ -230,6 +235,22 @@ int xmhw_clim_raw_f32(xmhw_plan *plan, const float *ts_dev, int64_t C, int64_t l
                       int64_t ldo, void *stream);
 int xmhw_clim_raw_f64(xmhw_plan *plan, const double *ts_dev, int64_t C, int64_t ld,
                       double q, int negate, double *thresh_dev, double *seas_dev,
+                      int64_t ldo, void *stream);
+/* The same on an int16-PACKED series read in place (CF packing: value = code * scale_factor + add_offset, `_FillValue`
+ * -> NaN; what xr.open_dataset() decodes before threshold() sees it, docs/gettingstarted.rst:30-33): no decoded copy of
+ * the series in HBM (2 bytes per sample instead of 4 or 8) and no decode pass.  codes_dev[T][ld] int16 (big_endian != 0:
+ * byte-swapped, netCDF classic); decoded_itemsize = the dtype xarray (and xmhw_decode) would decode to:
+ *   4  float32 (float32 packing attributes): the result is bit-identical to xmhw_decode(..., float32) +
+ *      xmhw_clim_raw_f32 -- the kernel keys and sums float(code) * sf + of, two float32 roundings;
+ *   8  float64 (float64 attributes): code -> value is monotone, so the kernel selects on the codes and decodes the
+ *      two selected codes and the mean of the codes in float64: thresh bit-identical to xmhw_decode(..., float64) +
+ *      xmhw_clim_raw_f64, seas within rounding (<= 1e-12: an exact integer sum instead of 440 rounded additions) --
+ *      at the float32 kernel's speed instead of the 64-bit-key kernel's.
+ * has_scale == 0: the samples are the codes themselves.  Served by the sorted-list kernel only: w = 5, records of 9..48
+ * tracks, q >= 0.85; otherwise XMHW_ERR_UNSUPPORTED (decode, then xmhw_clim_raw_f32 / _f64).                        */
+int xmhw_clim_raw_i16(xmhw_plan *plan, const int16_t *codes_dev, int64_t C, int64_t ld, int big_endian,
+                      int has_scale, double scale_factor, double add_offset, int has_fill, int32_t fill_code,
+                      int decoded_itemsize, double q, int negate, double *thresh_dev, double *seas_dev,
                       int64_t ldo, void *stream);
 
 /* xmhw_clim_finish: the Feb-29 substitution (feb29(), identify.py:137-151,

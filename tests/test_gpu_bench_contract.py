@@ -25,10 +25,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     # SURVEY 8(d) "report both f32 and f64" + the other BASELINE configs ride the same line
     oc = d["other_configs"]
     # (round 4: six of them -- float64 legs of configs[1] and of the configs[4] share too -- each with its own parity sample;
-    # round 5: two more on configs[2]'s shape -- values at 0.01 K with sea-ice plateaus, AR(1) anomalies)
-    assert len(oc) == 9 and all("error" not in o for o in oc), oc
+    # round 5: five more on configs[2]'s shape -- values at 0.01 K with sea-ice plateaus (scattered, packs), AR(1)
+    # anomalies, int16 codes read in place)
+    assert len(oc) == 11 and all("error" not in o for o in oc), oc
     assert sum(o["dtype"].startswith("f64") for o in oc) == 3
-    assert sum("0.01 K" in o["workload"] or "AR(1)" in o["workload"] for o in oc) == 2
+    assert sum("0.01 K" in o["workload"] or "AR(1)" in o["workload"] for o in oc) == 3
+    # ... and the int16-packed legs (codes read in place, float32 and float64 decode)
+    assert sum(o["dtype"].startswith("i16") for o in oc) == 2
     assert all(o["parity_cells"] >= 16 for o in oc)
     assert all(o["parity_ok"] and o["roofline_frac"] > 0 and o["ms_per_step"] > 0 for o in oc), oc
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1

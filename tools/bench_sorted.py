@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--q", type=float, default=0.9)
     ap.add_argument("--years", type=int, nargs=2, default=None, help="first and last year instead of the preset's")
+    ap.add_argument("--packed", default=None, choices=["float32", "float64"],
+                    help="store the series as int16 codes (scale 0.01) and read them in place (xmhw_clim_raw_i16), decoded as ...")
     ap.add_argument("--ice-patch", type=int, default=0, help="ice cells in patches of that many cells (0: scattered)")
     ap.add_argument("--gen", type=float, nargs=3, default=None, metavar=("QUANT", "ICE_FRAC", "RHO"),
                     help="the extended generator (xmhw_synth_sst_ex_f32) instead of the SURVEY 8(d) one")
@@ -45,6 +47,18 @@ def main():
         h.synth_sst_ex(ts.ptr, T, C, C, 0, 20260103, nan, args.gen[0], args.gen[1], args.gen[2], args.ice_patch, 0)
     else:
         h.synth_sst(ts.ptr, 4, T, C, C, 0, 20260103, nan, 0)
+    codes = None
+    if args.packed:
+        codes = dev.DeviceBuffer(2 * T * C)
+        h.encode_i16(ts.ptr, T, C, C, codes.ptr, C, 0.01, 0.0, -999, 0)
+        h.stream_sync(0)
+    sc = 0.01 if args.packed == "float64" else float(np.float32(0.01))
+
+    def call(plan, th, se):
+        if codes is not None:
+            dev.clim_raw_packed(plan, codes, C, args.q, False, th, se, scale_factor=sc, add_offset=0.0, fill=-999, decoded=args.packed)
+        else:
+            dev.clim_raw(plan, ts, 4, C, args.q, False, th, se)
     ref = None
     idx = np.unique(np.linspace(0, C - 1, 2048).astype(np.int64))
     d_idx = dev.DeviceBuffer.from_array(idx)
@@ -57,13 +71,13 @@ def main():
         D = plan.D
         th, se = dev.DeviceBuffer(8 * D * C), dev.DeviceBuffer(8 * D * C)
         e0, e1 = h.event_create(), h.event_create()
-        dev.clim_raw(plan, ts, 4, C, args.q, False, th, se)      # warm-up (plan upload)
+        call(plan, th, se)      # warm-up (plan upload)
         h.stream_sync(0)
         h.plan_debug_stats(plan.handle, 1, False)
         ms = []
         for _ in range(args.reps):
             h.event_record(e0, 0)
-            dev.clim_raw(plan, ts, 4, C, args.q, False, th, se)
+            call(plan, th, se)
             h.event_record(e1, 0)
             ms.append(h.event_elapsed_ms(e0, e1))
         st = h.plan_debug_stats(plan.handle, 1, True)

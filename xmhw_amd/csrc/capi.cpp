@@ -1073,6 +1073,19 @@ int xmhw_decode(const void* raw_dev, int raw_itemsize, int big_endian, int64_t r
     if (e != hipSuccess) return hip_fail(e, "decode launch");
     return XMHW_OK;
 }
+int xmhw_encode_i16(const float* in_dev, int64_t rows, int64_t cols, int64_t ld_in, int16_t* out_dev, int64_t ld_out,
+                    double scale_factor, double add_offset, int32_t fill_code, void* stream) {
+    if (rows < 0 || cols < 0 || ld_in < cols || ld_out < cols) return fail(XMHW_ERR_INVALID, "bad rows/cols/ld");
+    if (!(scale_factor == scale_factor) || scale_factor == 0.0 || !(add_offset == add_offset))
+        return fail(XMHW_ERR_INVALID, "scale_factor must be a non-zero number, add_offset a number");
+    if (fill_code < -32768 || fill_code > 32767) return fail(XMHW_ERR_INVALID, "fill_code is not an int16");
+    if (rows == 0 || cols == 0) return XMHW_OK;
+    if (!in_dev || !out_dev) return fail(XMHW_ERR_INVALID, "NULL device buffer");
+    hipError_t e = xmhw::launch_encode_i16(in_dev, rows, cols, ld_in, out_dev, ld_out, scale_factor, add_offset, fill_code,
+                                           static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "encode launch");
+    return XMHW_OK;
+}
 int xmhw_read_rows(int fd, int64_t file_offset, int64_t row_pitch, int64_t row_bytes, int64_t rows, void* dst_host) {
     // pread() copies from the page cache (or the disk) straight into the caller's buffer -- for the ingest
     // path a page-locked staging buffer: no page of the file is ever mapped into this process, so many
@@ -1362,6 +1375,70 @@ int xmhw_clim_raw_f32(xmhw_plan* plan, const float* ts, int64_t C, int64_t ld, d
 int xmhw_clim_raw_f64(xmhw_plan* plan, const double* ts, int64_t C, int64_t ld, double q, int negate,
                       double* thresh, double* seas, int64_t ldo, void* stream) {
     return clim_raw<double>(plan, ts, C, ld, q, negate, thresh, seas, ldo, stream);
+}
+
+int xmhw_clim_raw_i16(xmhw_plan* plan, const int16_t* codes, int64_t C, int64_t ld, int big_endian, int has_scale,
+                      double scale_factor, double add_offset, int has_fill, int32_t fill_code, int decoded_itemsize, double q,
+                      int negate, double* thresh, double* seas, int64_t ldo, void* stream) {
+    if (!plan) return fail(XMHW_ERR_INVALID, "plan is NULL");
+    if (C < 0 || ld < C || ldo < C) return fail(XMHW_ERR_INVALID, "bad C/ld/ldo");
+    if (!(q >= 0.0 && q <= 1.0)) return fail(XMHW_ERR_INVALID, "quantile must be in [0, 1]");
+    if (decoded_itemsize != 4 && decoded_itemsize != 8) return fail(XMHW_ERR_INVALID, "decoded_itemsize must be 4 or 8");
+    if (has_scale && !(scale_factor == scale_factor && add_offset == add_offset && scale_factor != 0.0))
+        return fail(XMHW_ERR_INVALID, "scale_factor must be a non-zero number, add_offset a number");
+    if (C == 0) return XMHW_OK;
+    if (!codes || !thresh || !seas) return fail(XMHW_ERR_INVALID, "NULL device buffer");
+    // the codes are read in place by the sorted-list kernel and its recomputation only: the plans and quantiles those
+    // serve (w = 5, 9..48 tracks, quantile >= 0.85).  Anything else: xmhw_decode() + xmhw_clim_raw_f32 / _f64.
+    int rc = upload(plan, C);
+    if (rc != XMHW_OK) return rc;
+    if (!(plan->nchunks_s > 0 && q >= kSortedMinQ))
+        return fail(XMHW_ERR_UNSUPPORTED, "packed input runs on the sorted-list kernel only (w = 5, 9..48 tracks, quantile >= 0.85): "
+                                         "decode the series (xmhw_decode) and call xmhw_clim_raw_f32 / _f64");
+    xmhw::PackedI16 pk;
+    pk.swap = big_endian ? 1 : 0;
+    pk.fill = has_fill ? fill_code : 0x7FFFFFFF;
+    int kneg = negate ? 1 : 0;
+    if (!has_scale) {
+        pk.mode = 3;
+    } else if (decoded_itemsize == 4) {
+        // float32 decode: the kernels key and sum float(code) * sf + of, exactly the series xmhw_decode() would write
+        pk.mode = 1;
+        pk.sf = static_cast<float>(scale_factor);
+        pk.of = static_cast<float>(add_offset);
+    } else {
+        // float64 decode: code -> value is monotone (decreasing for a negative scale_factor: the kernels then key the
+        // negated codes); the two selected codes and the mean of the codes are decoded in float64
+        pk.mode = 2;
+        pk.s = scale_factor;
+        pk.o = add_offset;
+        pk.val_neg = negate ? 1 : 0;
+        kneg = (negate ? 1 : 0) ^ (scale_factor < 0.0 ? 1 : 0);
+    }
+    pk.key_neg = kneg;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const xmhw::Plan& h = plan->host;
+    const int64_t redo_ld = (C + 31) / 32;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (plan->timing) {
+        const int slot = static_cast<int>(plan->tcalls % 16);
+        for (int i = 0; i < 2; ++i)
+            if (!plan->tev[2 * slot + i]) HIP_TRY(hipEventCreate(&plan->tev[2 * slot + i]));
+        t0 = plan->tev[2 * slot];
+        t1 = plan->tev[2 * slot + 1];
+        plan->tcalls++;
+    }
+    hipError_t e = hipMemsetAsync(plan->d_redo, 0, sizeof(uint32_t) * static_cast<size_t>(h.D) * static_cast<size_t>(redo_ld), st);
+    if (e == hipSuccess && t0) e = hipEventRecord(t0, st);
+    if (e == hipSuccess)
+        e = xmhw::launch_sorted_i16(codes, pk, C, ld, h.T, plan->d_table_s, plan->d_sflags_s, plan->d_chunks_s, plan->nchunks_s,
+                                    h.w, plan->yps_s, h.ntracks, q, kneg, thresh, seas, ldo, plan->d_redo, redo_ld, st);
+    if (e == hipSuccess && t1) e = hipEventRecord(t1, st);
+    if (e == hipSuccess)
+        e = xmhw::launch_redo_packed(codes, pk, h.T, C, ld, plan->d_row_ptr, plan->d_centres, h.D, h.w, q, kneg, thresh, seas,
+                                     ldo, plan->d_redo, redo_ld, plan->d_redo_list, plan->d_redo_count, plan->redo_cap, st);
+    if (e != hipSuccess) return hip_fail(e, "packed climatology launch");
+    return XMHW_OK;
 }
 
 int xmhw_clim_finish(const xmhw_plan* plan, const double* thresh_in, const double* seas_in, int64_t C,

@@ -54,6 +54,21 @@ __device__ __forceinline__ double numpy_lerp(double a, double b, double g) {
 
 __device__ __forceinline__ double make_nan() { return __longlong_as_double(0x7FF8000000000000ll); }
 
+// ---- where a kernel's samples come from ---------------------------------------------------------------------------
+// PlainSrc<T>: a float32 / float64 series.  PackedSrc: int16 codes + the CF recipe (kernels.h: PackedI16).  at(i) = the
+// sample a kernel keys and sums (before the kernel's own negation for cold spells), value(v) = the output value of a
+// keyed sample, mean(m) = the output value of the mean of the keyed samples, guess(y) = a sample near output value y.
+template <typename T>
+struct PlainSrc {
+    using sample = T;
+    const T* p;
+    __device__ __forceinline__ T at(int64_t i) const { return p[i]; }
+    __device__ __forceinline__ double value(T v) const { return static_cast<double>(v); }
+    __device__ __forceinline__ double mean(double m) const { return m; }
+    __device__ __forceinline__ T guess(double y) const { return static_cast<T>(y); }
+};
+
+
 // splitmix64 finaliser: counter-based generator for the synthetic SST
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;

@@ -6,6 +6,23 @@
 namespace xmhw {
 
 struct DevChunk { int32_t warm_start, begin, end; };
+// int16-packed input (CF packing: value = code * scale_factor + add_offset, _FillValue -> NaN; what xmhw_decode() would
+// write out, see kernels_ingest.hip) read by the kernels directly: the sorted-list kernel, its recomputation and the
+// leftover kernel take the codes and this recipe instead of a decoded copy of the series (capi.cpp: xmhw_clim_raw_i16).
+//   mode 1  float32 decode: a sample is float(code) * sf + of, two float32 roundings -- the float32 series xarray (and
+//           xmhw_decode) would hand over; the kernels key and sum exactly those values;
+//   mode 2  float64 decode (float64 packing attributes): code -> value is monotone, so the kernels key float(code)
+//           (exact) and decode only the two selected codes and the mean of the codes: double(code) * s + o;
+//   mode 3  no packing attributes: a sample is float(code).
+struct PackedI16 {
+    int32_t mode = 0;
+    int32_t fill = 0x7FFFFFFF;   // the code that means "missing" (0x7FFFFFFF: none)
+    int32_t swap = 0;            // the codes are big-endian
+    int32_t key_neg = 0;         // the kernel keys the NEGATED sample (cold spells; mode 2: XOR a negative scale_factor)
+    int32_t val_neg = 0;         // mode 2: the outputs are those of the negated series (cold spells)
+    float sf = 1.0f, of = 0.0f;
+    double s = 1.0, o = 0.0;
+};
 // a chunk of the sorted-list kernel: its table / flag rows start at trow0 (row of step warm_start)
 struct DevSortedChunk { int32_t warm_start, begin, end, trow0; };
 
@@ -82,6 +99,20 @@ hipError_t launch_redo(const float* ts, int64_t Tn, int64_t C, int64_t ld, const
                        int32_t D, int32_t w, double q, int negate, double* thresh, double* seas, int64_t ldo,
                        uint32_t* bits, int64_t ldb, unsigned long long* list, uint32_t* count, uint32_t cap,
                        hipStream_t stream);
+
+hipError_t launch_redo_packed(const int16_t* codes, const PackedI16& pk, int64_t Tn, int64_t C, int64_t ld,
+                              const int32_t* row_ptr, const int32_t* centres, int32_t D, int32_t w, double q, int negate,
+                              double* thresh, double* seas, int64_t ldo, uint32_t* bits, int64_t ldb,
+                              unsigned long long* list, uint32_t* count, uint32_t cap, hipStream_t stream);
+hipError_t launch_generic_flagged_packed(const int16_t* codes, const PackedI16& pk, int64_t Tn, int64_t C, int64_t ld,
+                                         const int32_t* row_ptr, const int32_t* centres, int32_t nrows, int32_t w, double q,
+                                         int negate, double* thresh, double* seas, int64_t ldo, const uint32_t* bits,
+                                         int64_t ldb, hipStream_t stream);
+// the sorted-list kernel on int16 codes (instantiated for the same records as launch_sorted_f32)
+hipError_t launch_sorted_i16(const int16_t* codes, const PackedI16& pk, int64_t C, int64_t ld, int64_t Tn,
+                             const uint32_t* table, const uint32_t* sflags, const DevSortedChunk* chunks, int32_t nchunks,
+                             int32_t w, int32_t yps, int32_t ntracks, double q, int negate, double* thresh, double* seas,
+                             int64_t ldo, uint32_t* redo_bits, int64_t redo_ld, hipStream_t stream);
 
 // fourth-generation float32 ring kernel (kernels_ring4.hip): a windowed key store in LDS instead of histogram + band
 // compaction; same lane layouts and step tables as the third generation (ring2 variants 30 / 31 / 32 = 8 / 4 / 2 lanes)
@@ -194,6 +225,8 @@ hipError_t launch_block_time(const T* ts, int64_t Tn, int64_t C, int64_t ld, con
 
 // file bytes -> samples (kernels_ingest.hip): raw_type = item size of the stored type (2 int16, 4 float32,
 // 8 float64), swap = the file is big-endian, optional scale/offset (CF packing) and fill value -> NaN
+hipError_t launch_encode_i16(const float* in, int64_t rows, int64_t cols, int64_t ld_in, int16_t* out, int64_t ld_out,
+                             double scale, double offset, int32_t fill, hipStream_t stream);
 hipError_t launch_decode(const void* in, int raw_type, int swap, int64_t rows, int64_t cols, int64_t ld_in, void* out,
                          int out_itemsize, int64_t ld_out, double scale, double offset, int has_scale, int has_fill,
                          double fill, hipStream_t stream);

@@ -7,6 +7,7 @@
 // All global accesses are coalesced along the stacked cell axis (lane = cell).
 #include "device_common.h"
 #include "kernels.h"
+#include "packed_src.h"
 
 namespace xmhw {
 
@@ -20,11 +21,14 @@ namespace xmhw {
 // The pool is re-read from L2 for every pass (lanes of a block share rows).
 // ---------------------------------------------------------------------------
 // one (cell, row): col = the cell's column of the series
-template <typename T>
-__device__ __forceinline__ void generic_cell_row(const T* __restrict__ col, int64_t Tn, int64_t ld,
+// (Src: where the samples come from -- a float32 / float64 series or int16 codes with their CF recipe, device_common.h /
+// packed_src.h; c = the cell's column)
+template <typename Src>
+__device__ __forceinline__ void generic_cell_row(const Src& src, int64_t c, int64_t Tn, int64_t ld,
                                                  const int32_t* __restrict__ row_ptr,
                                                  const int32_t* __restrict__ centres, int32_t row, int32_t w, double q,
                                                  int negate, double& th_out, double& se_out) {
+    using T = typename Src::sample;
     using K = typename KeyOf<T>::type;
     const int32_t cb = row_ptr[row], ce = row_ptr[row + 1];
 
@@ -35,7 +39,7 @@ __device__ __forceinline__ void generic_cell_row(const T* __restrict__ col, int6
         for (int32_t k = -w; k <= w; ++k) {
             const int64_t t = t0 + k;
             if (t < 0 || t >= Tn) continue;
-            T v = col[t * ld];
+            T v = src.at(c + t * ld);
             if (negate) v = -v;
             if (v == v) { ++n; sum += static_cast<double>(v); }
         }
@@ -55,7 +59,7 @@ __device__ __forceinline__ void generic_cell_row(const T* __restrict__ col, int6
                 for (int32_t k = -w; k <= w; ++k) {
                     const int64_t t = t0 + k;
                     if (t < 0 || t >= Tn) continue;
-                    T x = col[t * ld];
+                    T x = src.at(c + t * ld);
                     if (negate) x = -x;
                     const K key = KeyOf<T>::key(x);
                     cnt += (static_cast<K>(key - 1) < static_cast<K>(cand - 1)) ? 1u : 0u;
@@ -71,7 +75,7 @@ __device__ __forceinline__ void generic_cell_row(const T* __restrict__ col, int6
             for (int32_t k = -w; k <= w; ++k) {
                 const int64_t t = t0 + k;
                 if (t < 0 || t >= Tn) continue;
-                T x = col[t * ld];
+                T x = src.at(c + t * ld);
                 if (negate) x = -x;
                 const K key = KeyOf<T>::key(x);
                 if (key != 0 && key <= v) ++cle;
@@ -80,8 +84,8 @@ __device__ __forceinline__ void generic_cell_row(const T* __restrict__ col, int6
         }
         K vhi = v;
         if (lo + 1 < n && cle < lo + 2) vhi = mn;
-        th = numpy_lerp(KeyOf<T>::value(v), KeyOf<T>::value(vhi), g);
-        se = sum / static_cast<double>(n);
+        th = numpy_lerp(src.value(static_cast<T>(KeyOf<T>::value(v))), src.value(static_cast<T>(KeyOf<T>::value(vhi))), g);
+        se = src.mean(sum / static_cast<double>(n));
     }
     th_out = th;
     se_out = se;
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void clim_generic(const T* __restrict__ ts, in
     const int32_t row = blockIdx.y;
     if (c >= C) return;
     double th, se;
-    generic_cell_row<T>(ts + c, Tn, ld, row_ptr, centres, row, w, q, negate, th, se);
+    generic_cell_row(PlainSrc<T>{ts}, c, Tn, ld, row_ptr, centres, row, w, q, negate, th, se);
     thresh[static_cast<int64_t>(row) * ldo + c] = th;
     seas[static_cast<int64_t>(row) * ldo + c] = se;
 }
@@ -108,8 +112,8 @@ __global__ __launch_bounds__(256) void clim_generic(const T* __restrict__ ts, in
 // The same for the cell-rows still FLAGGED in the sorted-list kernel's bitmap after kernels_redo.hip has taken what
 // fits its work list: bits[row * ldb + (c >> 5)] bit (c & 31).  Thread per bitmap WORD (the bitmap is nearly always
 // empty by now: the launch costs one read of it); a thread walks the set bits of its word one cell-row after the other.
-template <typename T>
-__global__ __launch_bounds__(256) void clim_generic_flagged(const T* __restrict__ ts, int64_t Tn, int64_t C,
+template <typename Src>
+__global__ __launch_bounds__(256) void clim_generic_flagged(Src src, int64_t Tn, int64_t C,
                                                             int64_t ld, const int32_t* __restrict__ row_ptr,
                                                             const int32_t* __restrict__ centres, int32_t w,
                                                             double q, int negate, double* __restrict__ thresh,
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void clim_generic_flagged(const T* __restrict_
         word &= word - 1u;
         if (c >= C) break;
         double th, se;
-        generic_cell_row<T>(ts + c, Tn, ld, row_ptr, centres, row, w, q, negate, th, se);
+        generic_cell_row(src, c, Tn, ld, row_ptr, centres, row, w, q, negate, th, se);
         thresh[static_cast<int64_t>(row) * ldo + c] = th;
         seas[static_cast<int64_t>(row) * ldo + c] = se;
     }
@@ -151,8 +155,18 @@ hipError_t launch_generic_flagged(const T* ts, int64_t Tn, int64_t C, int64_t ld
     if (C <= 0 || nrows <= 0) return hipSuccess;
     (void)row0;      // (the bitmap covers rows [0, nrows))
     const int64_t nwords = static_cast<int64_t>(nrows) * ldb;
-    hipLaunchKernelGGL(clim_generic_flagged<T>, dim3(static_cast<unsigned>((nwords + 255) / 256)), dim3(256), 0, stream, ts,
-                       Tn, C, ld, row_ptr, centres, w, q, negate, thresh, seas, ldo, bits, ldb, nwords);
+    hipLaunchKernelGGL(clim_generic_flagged<PlainSrc<T>>, dim3(static_cast<unsigned>((nwords + 255) / 256)), dim3(256), 0, stream,
+                       PlainSrc<T>{ts}, Tn, C, ld, row_ptr, centres, w, q, negate, thresh, seas, ldo, bits, ldb, nwords);
+    return hipGetLastError();
+}
+hipError_t launch_generic_flagged_packed(const int16_t* codes, const PackedI16& pk, int64_t Tn, int64_t C, int64_t ld,
+                                         const int32_t* row_ptr, const int32_t* centres, int32_t nrows, int32_t w, double q,
+                                         int negate, double* thresh, double* seas, int64_t ldo, const uint32_t* bits,
+                                         int64_t ldb, hipStream_t stream) {
+    if (C <= 0 || nrows <= 0) return hipSuccess;
+    const int64_t nwords = static_cast<int64_t>(nrows) * ldb;
+    hipLaunchKernelGGL(clim_generic_flagged<PackedSrc>, dim3(static_cast<unsigned>((nwords + 255) / 256)), dim3(256), 0, stream,
+                       PackedSrc{codes, pk}, Tn, C, ld, row_ptr, centres, w, q, negate, thresh, seas, ldo, bits, ldb, nwords);
     return hipGetLastError();
 }
 template hipError_t launch_generic_flagged<float>(const float*, int64_t, int64_t, int64_t, const int32_t*,

@@ -67,6 +67,21 @@ hipError_t launch(const void* in, int swap, int64_t rows, int64_t cols, int64_t 
 }
 
 
+// The inverse for float32 -> int16: code = rint((x - add_offset) / scale_factor) in float64, clamped to the int16 range
+// without its lowest code; NaN -> fill_code.  What writing a packed archive does (xarray's CF encoding); bench.py and
+// the tests make packed input with it.
+__global__ __launch_bounds__(256) void encode_i16(const float* __restrict__ in, int64_t rows, int64_t cols, int64_t ld_in,
+                                                  int16_t* __restrict__ out, int64_t ld_out, double scale, double offset,
+                                                  int32_t fill) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+        const float x = in[r * ld_in + c];
+        double k = rint((static_cast<double>(x) - offset) / scale);
+        k = k < -32767.0 ? -32767.0 : (k > 32767.0 ? 32767.0 : k);
+        out[r * ld_out + c] = static_cast<int16_t>(x == x ? static_cast<int32_t>(k) : fill);
+    }
+}
 // ---------------------------------------------------------------------------
 // pad_gaps: ts.interpolate_na(dim=tdim, max_gap=maxPadLength) of the reference (xmhw/xmhw.py:159-160,
 // :409-410), i.e. xarray's linear interpolate_na with use_coordinate=True on the device copy of the
@@ -119,6 +134,14 @@ __global__ __launch_bounds__(256) void pad_gaps(T* __restrict__ ts, int64_t Tn, 
 }
 
 }  // namespace
+
+hipError_t launch_encode_i16(const float* in, int64_t rows, int64_t cols, int64_t ld_in, int16_t* out, int64_t ld_out,
+                             double scale, double offset, int32_t fill, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    dim3 grid(static_cast<unsigned>((cols + 255) / 256), static_cast<unsigned>(rows < 2048 ? rows : 2048));
+    hipLaunchKernelGGL(encode_i16, grid, dim3(256), 0, stream, in, rows, cols, ld_in, out, ld_out, scale, offset, fill);
+    return hipGetLastError();
+}
 
 hipError_t launch_decode(const void* in, int raw_type, int swap, int64_t rows, int64_t cols, int64_t ld_in, void* out,
                          int out_itemsize, int64_t ld_out, double scale, double offset, int has_scale, int has_fill,

@@ -14,6 +14,7 @@
 //   clim_generic_flagged (kernels_generic.hip) on whatever is still set: only when the list overflowed.
 #include "device_common.h"
 #include "kernels.h"
+#include "packed_src.h"
 
 namespace xmhw {
 
@@ -86,10 +87,11 @@ __device__ __forceinline__ K wave_max(K v) {
 }
 
 // one row of a run: order statistic lo of the keys whose place in the stretch is k .. k + R - 1
-template <typename T, int KPL>
-__device__ __forceinline__ void redo_one(const typename KeyOf<T>::type (&all)[KPL], const int32_t (&joff)[KPL], int32_t k,
-                                         int32_t R, int32_t row, int64_t c, double q, double* __restrict__ thresh, int64_t ldo,
-                                         int lane) {
+template <typename Src, int KPL>
+__device__ __forceinline__ void redo_one(const Src& src, const typename KeyOf<typename Src::sample>::type (&all)[KPL],
+                                         const int32_t (&joff)[KPL], int32_t k, int32_t R, int32_t row, int64_t c, double q,
+                                         int negate, double* __restrict__ thresh, int64_t ldo, int lane) {
+    using T = typename Src::sample;
     using K = typename KeyOf<T>::type;
     K key[KPL];
 #pragma unroll
@@ -131,7 +133,7 @@ __device__ __forceinline__ void redo_one(const typename KeyOf<T>::type (&all)[KP
         };
         // -- from the sorted kernel's answer: a key near order statistic lo
         const double guess = thresh[static_cast<int64_t>(row) * ldo + c];
-        K v = guess == guess ? KeyOf<T>::key(static_cast<T>(guess)) : static_cast<K>(0);
+        K v = guess == guess ? KeyOf<T>::key(src.guess(guess)) : static_cast<K>(0);
         bool found = false;
         uint32_t cl = 0, ev = 0;                     // keys below v, keys equal to v
         if (v != 0) {
@@ -172,8 +174,9 @@ __device__ __forceinline__ void redo_one(const typename KeyOf<T>::type (&all)[KP
         // v = key of a[lo]; a[lo + 1]: v again if it is duplicated past lo, else the smallest key above v
         K vhi = v;
         if (lo + 1 < n && lo + 1 >= cl + ev) vhi = next_above(v);
-        th = numpy_lerp(KeyOf<T>::value(v), KeyOf<T>::value(vhi), g);
+        th = numpy_lerp(src.value(static_cast<T>(KeyOf<T>::value(v))), src.value(static_cast<T>(KeyOf<T>::value(vhi))), g);
     }
+    (void)negate;
     if (lane == 0) thresh[static_cast<int64_t>(row) * ldo + c] = th;
 }
 
@@ -181,12 +184,13 @@ __device__ __forceinline__ void redo_one(const typename KeyOf<T>::type (&all)[KP
 // from the argument.  The selection starts from the answer the sorted kernel left in `thresh` (wrong, but a few ranks
 // away at most): count the keys below it, then step from key to neighbouring key until order statistic lo is reached;
 // the bit-by-bit descent over the whole key is kept for guesses that turn out to be far off.
-template <typename T, int W>
-__global__ __launch_bounds__(256) void redo_run(const T* __restrict__ ts, int64_t Tn, int64_t ld,
+template <typename Src, int W>
+__global__ __launch_bounds__(256) void redo_run(Src src, int64_t Tn, int64_t ld,
                                                 const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ centres,
                                                 int32_t w_arg, double q, int negate, double* __restrict__ thresh, int64_t ldo,
                                                 const unsigned long long* __restrict__ list,
                                                 const uint32_t* __restrict__ count, uint32_t cap) {
+    using T = typename Src::sample;
     using K = typename KeyOf<T>::type;
     constexpr int KPL = 10;                     // keys per lane: up to 640 samples (48 tracks x 11 = 528; 40 tracks x 16)
     const int lane = threadIdx.x & 63;
@@ -224,7 +228,6 @@ __global__ __launch_bounds__(256) void redo_run(const T* __restrict__ ts, int64_
         }
         const int32_t RL = R + L - 1;
         const int32_t nload = ntr * RL;
-        const T* col = ts + c;
         K key[KPL];
         int32_t joff[KPL];                      // the sample's place in its track's stretch: row k of the run owns k .. k + R - 1
         {
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(256) void redo_run(const T* __restrict__ ts, int64_
                 const int64_t t = static_cast<int64_t>(cen[i]) + joff[i] - w;
                 ok[i] = inb[i] && t >= 0 && t < Tn;
                 const int64_t tc = t < 0 ? 0 : (t >= Tn ? Tn - 1 : t);
-                val[i] = col[tc * ld];
+                val[i] = src.at(c + tc * ld);
             }
 #pragma unroll
             for (int i = 0; i < KPL; ++i) {
@@ -256,30 +259,53 @@ __global__ __launch_bounds__(256) void redo_run(const T* __restrict__ ts, int64_
                 key[i] = ok[i] ? KeyOf<T>::key(v) : static_cast<K>(0);
             }
         }
-        for (int32_t k = 0; k < L; ++k) redo_one<T, KPL>(key, joff, k, R, row0 + k, c, q, thresh, ldo, lane);
+        for (int32_t k = 0; k < L; ++k) redo_one<Src, KPL>(src, key, joff, k, R, row0 + k, c, q, negate, thresh, ldo, lane);
         e += static_cast<uint32_t>(L);
     }
 }
+
+namespace {
+template <typename Src>
+hipError_t launch_redo_src(Src src, int64_t Tn, int64_t C, int64_t ld, const int32_t* row_ptr, const int32_t* centres, int32_t D,
+                           int32_t w, double q, int negate, double* thresh, int64_t ldo, uint32_t* bits, int64_t ldb,
+                           unsigned long long* list, uint32_t* count, uint32_t cap, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(redo_collect, dim3(static_cast<unsigned>((ldb + 3) / 4)), dim3(256), 0, stream, bits, C, D, ldb, list,
+                       count, cap);
+    if (w == 5)
+        hipLaunchKernelGGL((redo_run<Src, 5>), dim3(2048), dim3(256), 0, stream, src, Tn, ld, row_ptr, centres, w, q, negate,
+                           thresh, ldo, list, count, cap);
+    else
+        hipLaunchKernelGGL((redo_run<Src, 0>), dim3(2048), dim3(256), 0, stream, src, Tn, ld, row_ptr, centres, w, q, negate,
+                           thresh, ldo, list, count, cap);
+    return hipGetLastError();
+}
+}  // namespace
 
 hipError_t launch_redo(const float* ts, int64_t Tn, int64_t C, int64_t ld, const int32_t* row_ptr, const int32_t* centres,
                        int32_t D, int32_t w, double q, int negate, double* thresh, double* seas, int64_t ldo,
                        uint32_t* bits, int64_t ldb, unsigned long long* list, uint32_t* count, uint32_t cap,
                        hipStream_t stream) {
     if (C <= 0 || D <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(redo_collect, dim3(static_cast<unsigned>((ldb + 3) / 4)), dim3(256), 0, stream, bits, C, D, ldb, list,
-                       count, cap);
-    if (w == 5)
-        hipLaunchKernelGGL((redo_run<float, 5>), dim3(2048), dim3(256), 0, stream, ts, Tn, ld, row_ptr, centres, w, q, negate,
-                           thresh, ldo, list, count, cap);
-    else
-        hipLaunchKernelGGL((redo_run<float, 0>), dim3(2048), dim3(256), 0, stream, ts, Tn, ld, row_ptr, centres, w, q, negate,
-                           thresh, ldo, list, count, cap);
-    e = hipGetLastError();
+    hipError_t e = launch_redo_src(PlainSrc<float>{ts}, Tn, C, ld, row_ptr, centres, D, w, q, negate, thresh, ldo, bits, ldb,
+                                   list, count, cap, stream);
     if (e != hipSuccess) return e;
     // whatever did not fit the list (bits still set): the thread-per-cell-row kernel
     return launch_generic_flagged<float>(ts, Tn, C, ld, row_ptr, centres, 0, D, w, q, negate, thresh, seas, ldo, bits, ldb,
+                                         stream);
+}
+
+// the same on int16 codes read in place (negate: what the kernels negate -- pk.key_neg in mode 2)
+hipError_t launch_redo_packed(const int16_t* codes, const PackedI16& pk, int64_t Tn, int64_t C, int64_t ld,
+                              const int32_t* row_ptr, const int32_t* centres, int32_t D, int32_t w, double q, int negate,
+                              double* thresh, double* seas, int64_t ldo, uint32_t* bits, int64_t ldb,
+                              unsigned long long* list, uint32_t* count, uint32_t cap, hipStream_t stream) {
+    if (C <= 0 || D <= 0) return hipSuccess;
+    hipError_t e = launch_redo_src(PackedSrc{codes, pk}, Tn, C, ld, row_ptr, centres, D, w, q, negate, thresh, ldo, bits, ldb,
+                                   list, count, cap, stream);
+    if (e != hipSuccess) return e;
+    return launch_generic_flagged_packed(codes, pk, Tn, C, ld, row_ptr, centres, D, w, q, negate, thresh, seas, ldo, bits, ldb,
                                          stream);
 }
 

@@ -32,8 +32,11 @@
 //
 // Reference semantics restated: window_roll() (identify.py:184-209), calculate_thresh() / calculate_seas() without
 // the Feb-29 step (identify.py:233-235, :263), coldSpells negation (xmhw.py:153-154).
+#include <type_traits>
+
 #include "device_common.h"
 #include "kernels.h"
+#include "packed_src.h"
 #include "plan.h"
 #include "sortnet_gen.h"
 
@@ -108,13 +111,17 @@ typedef uint32_t V8 __attribute__((ext_vector_type(8)));
 // summed over cells, [8..15] shader-clock ticks per section (push, sort, bookkeeping, walk, epilogue)
 // (registers: LDS holds 6 waves per CU at K = 16 and more for shorter lists -- 8 at K = 12, 11 at K = 8: the shorter
 // records are asked to fit three waves per SIMD)
-template <int YPS, int K, bool STATS>
-__global__ __launch_bounds__(64, 2) void clim_sorted_f32(
-    const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
+// PACKED: the samples are int16 codes read in place (kernels.h: PackedI16, packed_src.h): a row's codes become the float32
+// samples the rest of the row works on -- float(code) * sf + of in mode 1, float(code) in modes 2 and 3 -- and in mode 2 the
+// epilogue decodes the two selected codes and the mean of the codes in float64.
+template <int YPS, int K, bool STATS, bool PACKED>
+__device__ __forceinline__ void sorted_body(
+    const void* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, const DevSortedChunk* __restrict__ chunks, double q, int negate,
     int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
-    uint32_t* __restrict__ redo_bits, int64_t redo_ld, unsigned long long* __restrict__ stats) {
-    constexpr int R = 11;                        // w = 5
+    uint32_t* __restrict__ redo_bits, int64_t redo_ld, unsigned long long* __restrict__ stats, const PackedI16& pk) {
+    constexpr int R = 11;
+    constexpr uint32_t ES = PACKED ? 2u : 4u;    // bytes per stored sample                        // w = 5
     constexpr int NL = 6;                        // list slots per lane (lane 1 owns 5 and a dummy)
     constexpr int HE = (YPS + 1) / 2 * 2;        // keys per lane, padded to an even count
     constexpr int HH = HE / 2;                   // sorted keys per lane after the exchange
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
     const DevSortedChunk ch = chunks[blockIdx.y];
     // (the chunk's own table and flag rows: row of step s = trow0 + s - warm_start)
     const int32_t step_min = ch.warm_start - ch.trow0;
-    const float* col = ts + (cell_ok ? cell : C - 1);
+    const char* col = static_cast<const char*>(ts) + (cell_ok ? cell : C - 1) * static_cast<int64_t>(ES);
     const uint32_t sgnflip = negate ? 0x80000000u : 0u;
     const uint32_t tmax = static_cast<uint32_t>(Tn - 1);
     const bool padded_last = (YPS - 1) * 2 + sub >= ntracks;
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
     double total = 0.0;
 
     // ---- sample addresses: a 64-bit pointer per track ------------------------------------------------------
-    const uint32_t ld4 = static_cast<uint32_t>(ld) * 4u;
+    const uint32_t ld4 = static_cast<uint32_t>(ld) * ES;    // bytes between the steps of a cell
     const char* ap[YPS];
     auto entries_of = [&](int32_t step, uint32_t (&e)[YPS]) {
         const uint32_t* p = tab + static_cast<int64_t>(step - step_min) * NTP;
@@ -190,17 +197,21 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
 #pragma unroll
         for (int y = 0; y < YPS; ++y) {
             const uint32_t t = umin((e[y] >> 1) - 2u, tmax);
-            ap[y] = reinterpret_cast<const char*>(col) + static_cast<uint64_t>(t) * ld4;
+            ap[y] = col + static_cast<uint64_t>(t) * ld4;
         }
     };
     auto advance = [&]() {
 #pragma unroll
         for (int y = 0; y < YPS; ++y) ap[y] += (y == YPS - 1 && padded_last) ? 0u : ld4;
     };
-    float x_in[YPS];
+    // (PACKED: the raw codes, sign-extended by the load; converted when their row starts)
+    typename std::conditional<PACKED, int32_t, float>::type x_in[YPS];
     auto request = [&]() {
 #pragma unroll
-        for (int y = 0; y < YPS; ++y) x_in[y] = *reinterpret_cast<const float*>(ap[y]);
+        for (int y = 0; y < YPS; ++y) {
+            if constexpr (PACKED) x_in[y] = static_cast<int32_t>(*reinterpret_cast<const int16_t*>(ap[y]));
+            else x_in[y] = *reinterpret_cast<const float*>(ap[y]);
+        }
     };
     point_at(ch.warm_start);
     request();
@@ -239,6 +250,37 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
         uint32_t k[HE];
         double din = 0.0;
         uint32_t nvin = 0;
+        float xv[YPS];
+        if constexpr (PACKED) {
+            // (codes -> samples: xmhw_decode()'s arithmetic, the fill code -> NaN; big-endian codes swapped first.  Every
+            // wave-uniform choice -- byte order, float32 recipe, "a lane holds a fill code" -- is ONE branch around a block
+            // of YPS instructions, not a select per sample)
+            if (pk.swap) {
+#pragma unroll
+                for (int y = 0; y < YPS; ++y)
+                    x_in[y] = static_cast<int32_t>(static_cast<int16_t>(__builtin_bswap16(static_cast<uint16_t>(x_in[y]))));
+            }
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) xv[y] = static_cast<float>(x_in[y]);
+            if (pk.mode == 1) {
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) {
+                    float f = xv[y] * pk.sf;
+                    f = f + pk.of;
+                    xv[y] = f;
+                }
+            }
+            bool anyfill = false;
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) anyfill = anyfill || x_in[y] == pk.fill;
+            if (__any(anyfill)) {
+#pragma unroll
+                for (int y = 0; y < YPS; ++y) xv[y] = x_in[y] == pk.fill ? __uint_as_float(0x7FC00000u) : xv[y];
+            }
+        } else {
+#pragma unroll
+            for (int y = 0; y < YPS; ++y) xv[y] = x_in[y];
+        }
         bool slow = !(sf & 1u) || nan_mode;
         if (!slow) {
             // a plain row: every real track pushes a sample; NaN shows in the sum (so does +inf next to -inf: those
@@ -248,7 +290,7 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
             if (negate) {
 #pragma unroll
                 for (int y = 0; y < YPS; ++y) {
-                    uint32_t xb = __float_as_uint(x_in[y]);
+                    uint32_t xb = __float_as_uint(xv[y]);
                     uint32_t ky = key_fast<true>(xb);
                     if (y == YPS - 1) {
                         xb &= ~padmask;
@@ -264,7 +306,7 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
             } else {
 #pragma unroll
                 for (int y = 0; y < YPS; ++y) {
-                    uint32_t xb = __float_as_uint(x_in[y]);
+                    uint32_t xb = __float_as_uint(xv[y]);
                     uint32_t ky = key_fast<false>(xb);
                     if (y == YPS - 1) {
                         xb &= ~padmask;
@@ -296,20 +338,20 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
             if (negate) {
 #pragma unroll
                 for (int y = 0; y < YPS; ++y) {
-                    const float xv = x_in[y];
-                    const bool ok = xv == xv && (e[y] >> 1) >= 2u;
-                    k[y] = ok ? key_fast<true>(__float_as_uint(xv)) : 0u;
-                    din += static_cast<double>(ok ? xv : 0.0f);
+                    const float xs = xv[y];
+                    const bool ok = xs == xs && (e[y] >> 1) >= 2u;
+                    k[y] = ok ? key_fast<true>(__float_as_uint(xs)) : 0u;
+                    din += static_cast<double>(ok ? xs : 0.0f);
                     nvin += ok ? 1u : 0u;
                 }
                 din = -din;
             } else {
 #pragma unroll
                 for (int y = 0; y < YPS; ++y) {
-                    const float xv = x_in[y];
-                    const bool ok = xv == xv && (e[y] >> 1) >= 2u;
-                    k[y] = ok ? key_fast<false>(__float_as_uint(xv)) : 0u;
-                    din += static_cast<double>(ok ? xv : 0.0f);
+                    const float xs = xv[y];
+                    const bool ok = xs == xs && (e[y] >> 1) >= 2u;
+                    k[y] = ok ? key_fast<false>(__float_as_uint(xs)) : 0u;
+                    din += static_cast<double>(ok ? xs : 0.0f);
                     nvin += ok ? 1u : 0u;
                 }
             }
@@ -635,10 +677,15 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
             if (eph == 1u || s + 1 == ch.end) {
                 double th = make_nan(), se = make_nan();
                 if (e_n > 0) {
-                    const double v_lo = static_cast<double>(key_f32(e_alo));
-                    const double v_hi = static_cast<double>(key_f32(e_ahi));
-                    th = numpy_lerp(v_lo, v_hi, e_g);
+                    double v_lo = static_cast<double>(key_f32(e_alo));
+                    double v_hi = static_cast<double>(key_f32(e_ahi));
                     se = e_total / static_cast<double>(e_n);
+                    if constexpr (PACKED) {
+                        v_lo = packed_value(pk, v_lo);
+                        v_hi = packed_value(pk, v_hi);
+                        se = packed_value(pk, se);
+                    }
+                    th = numpy_lerp(v_lo, v_hi, e_g);
                 }
                 if (static_cast<uint32_t>(sub) <= eph && cell_ok) {
                     const int64_t row = static_cast<int64_t>(s) - static_cast<int64_t>(eph) + sub;
@@ -666,18 +713,41 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
     }
 }
 
+// (registers: LDS holds 6 waves per CU at K = 16 and more for shorter lists: two waves per SIMD is what the body is asked to fit)
+template <int YPS, int K, bool STATS>
+__global__ __launch_bounds__(64, 2) void clim_sorted_f32(
+    const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
+    const uint32_t* __restrict__ sflags, const DevSortedChunk* __restrict__ chunks, double q, int negate,
+    int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
+    uint32_t* __restrict__ redo_bits, int64_t redo_ld, unsigned long long* __restrict__ stats) {
+    sorted_body<YPS, K, STATS, false>(ts, C, ld, Tn, table, sflags, chunks, q, negate, ntracks, thresh, seas, ldo, redo_bits,
+                                      redo_ld, stats, PackedI16{});
+}
+// the same on int16 codes (no counter twin)
+template <int YPS, int K>
+__global__ __launch_bounds__(64, 2) void clim_sorted_i16(
+    const int16_t* __restrict__ codes, PackedI16 pk, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
+    const uint32_t* __restrict__ sflags, const DevSortedChunk* __restrict__ chunks, double q, int negate,
+    int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
+    uint32_t* __restrict__ redo_bits, int64_t redo_ld) {
+    sorted_body<YPS, K, false, true>(codes, C, ld, Tn, table, sflags, chunks, q, negate, ntracks, thresh, seas, ldo, redo_bits,
+                                     redo_ld, nullptr, pk);
+}
+
 // ---------------------------------------------------------------------------
 namespace {
 typedef void (*SortedKernel)(const float*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*,
                              const DevSortedChunk*, double, int, int32_t, double*, double*, int64_t, uint32_t*, int64_t,
                              unsigned long long*);
-struct SortedEntry { int yps, k; SortedKernel fn, fn_stats; };
+typedef void (*SortedKernelI16)(const int16_t*, PackedI16, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*,
+                                const DevSortedChunk*, double, int, int32_t, double*, double*, int64_t, uint32_t*, int64_t);
+struct SortedEntry { int yps, k; SortedKernel fn, fn_stats; SortedKernelI16 fn_i16; };
 #ifdef XMHW_RING_STATS
 #define XMHW_SS(Y, K) clim_sorted_f32<Y, K, true>
 #else
 #define XMHW_SS(Y, K) nullptr
 #endif
-#define XMHW_S(Y, K) {Y, K, clim_sorted_f32<Y, K, false>, XMHW_SS(Y, K)}
+#define XMHW_S(Y, K) {Y, K, clim_sorted_f32<Y, K, false>, XMHW_SS(Y, K), clim_sorted_i16<Y, K>}
 // tracks per lane -> keys stored per list: about 0.4 x the tracks of the record (a list's share of the pool's top tenth
 // is a tenth of the tracks on average and reaches three to four times that on a steep seasonal slope), even, at most
 // what a lane holds.  9..48 tracks.
@@ -719,6 +789,19 @@ hipError_t launch_sorted_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn,
     const bool twin = stats != nullptr && e->fn_stats != nullptr;
     hipLaunchKernelGGL(twin ? e->fn_stats : e->fn, grid, dim3(64), 0, stream, ts, C, ld, Tn, table, sflags, chunks, q,
                        negate, ntracks, thresh, seas, ldo, redo_bits, redo_ld, twin ? stats : nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_sorted_i16(const int16_t* codes, const PackedI16& pk, int64_t C, int64_t ld, int64_t Tn,
+                             const uint32_t* table, const uint32_t* sflags, const DevSortedChunk* chunks, int32_t nchunks,
+                             int32_t w, int32_t yps, int32_t ntracks, double q, int negate, double* thresh, double* seas,
+                             int64_t ldo, uint32_t* redo_bits, int64_t redo_ld, hipStream_t stream) {
+    const SortedEntry* e = w == 5 ? find_sorted(yps) : nullptr;
+    if (!e || !e->fn_i16 || ld >= (int64_t(1) << 30) || !redo_bits || pk.mode < 1 || pk.mode > 3) return hipErrorInvalidValue;
+    if (C <= 0 || nchunks <= 0) return hipSuccess;
+    dim3 grid(static_cast<unsigned>((C + 31) / 32), static_cast<unsigned>(nchunks));
+    hipLaunchKernelGGL(e->fn_i16, grid, dim3(64), 0, stream, codes, pk, C, ld, Tn, table, sflags, chunks, q, negate, ntracks,
+                       thresh, seas, ldo, redo_bits, redo_ld);
     return hipGetLastError();
 }
 

@@ -179,6 +179,16 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     }, py::arg("plan"), py::arg("ts"), py::arg("itemsize"), py::arg("C"), py::arg("ld"), py::arg("q"),
        py::arg("negate"), py::arg("thresh"), py::arg("seas"), py::arg("ldo"), py::arg("stream") = 0);
 
+    m.def("clim_raw_i16", [](uintptr_t plan, uintptr_t codes, int64_t C, int64_t ld, int big_endian, int has_scale,
+                             double scale_factor, double add_offset, int has_fill, int32_t fill_code, int decoded_itemsize,
+                             double q, int negate, uintptr_t th, uintptr_t se, int64_t ldo, uintptr_t stream) {
+        check(xmhw_clim_raw_i16(pp(plan), static_cast<const int16_t*>(vp(codes)), C, ld, big_endian, has_scale, scale_factor,
+                                add_offset, has_fill, fill_code, decoded_itemsize, q, negate, static_cast<double*>(vp(th)),
+                                static_cast<double*>(vp(se)), ldo, vp(stream)));
+    }, py::arg("plan"), py::arg("codes"), py::arg("C"), py::arg("ld"), py::arg("big_endian"), py::arg("has_scale"),
+       py::arg("scale_factor"), py::arg("add_offset"), py::arg("has_fill"), py::arg("fill_code"), py::arg("decoded_itemsize"),
+       py::arg("q"), py::arg("negate"), py::arg("thresh"), py::arg("seas"), py::arg("ldo"), py::arg("stream") = 0);
+
     m.def("clim_finish", [](uintptr_t plan, uintptr_t th_in, uintptr_t se_in, int64_t C, int64_t ldo, int feb29_fix,
                             int smooth, int width, uintptr_t th_out, uintptr_t se_out, uintptr_t stream) {
         check(xmhw_clim_finish(pp(plan), static_cast<const double*>(vp(th_in)), static_cast<const double*>(vp(se_in)),
@@ -455,6 +465,12 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     }, py::arg("raw"), py::arg("raw_itemsize"), py::arg("big_endian"), py::arg("rows"), py::arg("cols"), py::arg("ld_raw"),
        py::arg("out"), py::arg("out_itemsize"), py::arg("ld_out"), py::arg("has_scale"), py::arg("scale"),
        py::arg("offset"), py::arg("has_fill"), py::arg("fill"), py::arg("stream") = 0);
+    m.def("encode_i16", [](uintptr_t in, int64_t rows, int64_t cols, int64_t ld_in, uintptr_t out, int64_t ld_out, double scale,
+                           double offset, int32_t fill, uintptr_t stream) {
+        check(xmhw_encode_i16(static_cast<const float*>(vp(in)), rows, cols, ld_in, static_cast<int16_t*>(vp(out)), ld_out, scale,
+                              offset, fill, vp(stream)));
+    }, py::arg("in"), py::arg("rows"), py::arg("cols"), py::arg("ld_in"), py::arg("out"), py::arg("ld_out"), py::arg("scale"),
+       py::arg("offset"), py::arg("fill"), py::arg("stream") = 0);
     m.def("read_rows", [](int fd, int64_t off, int64_t pitch, int64_t row_bytes, int64_t rows, uintptr_t dst) {
         py::gil_scoped_release r;
         int rc = xmhw_read_rows(fd, off, pitch, row_bytes, rows, vp(dst));

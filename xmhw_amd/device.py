@@ -250,6 +250,23 @@ def clim_raw(plan, ts_dev, itemsize, C, q, negate, thresh_dev, seas_dev, ld=None
         raise XmhwException(str(e)) from e
 
 
+def clim_raw_packed(plan, codes_dev, C, q, negate, thresh_dev, seas_dev, scale_factor=None, add_offset=None, fill=None,
+                    decoded="float32", big_endian=False, ld=None, ldo=None, stream=0):
+    """xmhw_clim_raw_i16: the raw climatology of an int16-packed series read in place (CF packing attributes as xarray
+    would apply them before threshold() sees the data; `decoded` = the dtype it would decode to).  Raises XmhwException
+    where the sorted-list kernel does not serve the plan or the quantile: decode first (hip().decode) and use clim_raw."""
+    h = hip()
+    p = lambda b: b.ptr if hasattr(b, "ptr") else int(b)
+    has_scale = scale_factor is not None or add_offset is not None
+    try:
+        h.clim_raw_i16(plan.handle, p(codes_dev), C, C if ld is None else ld, int(bool(big_endian)), int(has_scale),
+                       1.0 if scale_factor is None else float(scale_factor), 0.0 if add_offset is None else float(add_offset),
+                       int(fill is not None), 0 if fill is None else int(fill), 8 if str(decoded) in ("float64", "f64", "8") else 4,
+                       float(q), int(bool(negate)), p(thresh_dev), p(seas_dev), C if ldo is None else ldo, stream)
+    except (h.InvalidArgument, h.HipError) as e:       # (HipError: XMHW_ERR_UNSUPPORTED -- the plan is not the sorted kernel's)
+        raise XmhwException(str(e)) from e
+
+
 def clim_finish(plan, th_in, se_in, C, feb29_fix, smooth, width, th_out, se_out, ldo=None, stream=0):
     h = hip()
     p = lambda b: b.ptr if hasattr(b, "ptr") else int(b)
