@@ -292,6 +292,11 @@ int xmhw_land_mask_f32(const float *ts_dev, int64_t T, int64_t C, int64_t ld, in
 int xmhw_land_mask_f64(const double *ts_dev, int64_t T, int64_t C, int64_t ld, int anynans,
                        uint8_t *keep_dev, void *stream);
 
+/* the same on int16 codes (packed input read in place, xmhw_clim_raw_i16): a sample is missing when its code is
+ * fill_code (has_fill == 0: no cell is dropped); big_endian: the codes are byte-swapped                         */
+int xmhw_land_mask_i16(const int16_t *codes_dev, int64_t T, int64_t C, int64_t ld, int big_endian, int has_fill,
+                       int32_t fill_code, int anynans, uint8_t *keep_dev, void *stream);
+
 /* land_check()'s compaction on resident data: out[r][c] = in[r][index[c]] for the
  * n ocean cells listed in index_dev (ascending stacked-cell numbers, int64), and
  * the inverse for the results (what unstack('cell') does, xmhw.py:210-214):
@@ -301,6 +306,9 @@ int xmhw_gather_cells_f32(const float *in_dev, int64_t rows, int64_t ld_in,
                           void *stream);
 int xmhw_gather_cells_f64(const double *in_dev, int64_t rows, int64_t ld_in,
                           const int64_t *index_dev, int64_t n, double *out_dev, int64_t ld_out,
+                          void *stream);
+int xmhw_gather_cells_i16(const int16_t *in_dev, int64_t rows, int64_t ld_in,
+                          const int64_t *index_dev, int64_t n, int16_t *out_dev, int64_t ld_out,
                           void *stream);
 int xmhw_scatter_cells_f64(const double *in_dev, int64_t rows, int64_t ld_in,
                            const int64_t *index_dev, int64_t n, double *out_dev, int64_t ld_out,

@@ -179,3 +179,56 @@ def test_plans_the_sorted_kernel_does_not_serve_are_refused(dev):
         _packed(dev, _codes(long.shape[0], 8, 2), long, 0.9, False, 0.01, 10.0, FILL, "float32")     # 70 tracks
     with pytest.raises(XmhwException):
         _packed(dev, codes, doy, 0.9, False, 0.0, 10.0, FILL, "float64")             # scale_factor 0
+
+
+@pytest.mark.parametrize("kind", ["i16_f32attrs", "i16_f64attrs"])
+@pytest.mark.parametrize("cold", [False, True])
+def test_threshold_from_a_packed_file_reads_the_codes_in_place(tmp_path, dev, monkeypatch, kind, cold):
+    """threshold() on the mapped netCDF file of a 12-year packed archive: the codes are what is uploaded, masked (land =
+    every code the fill code), compacted and read by the kernels; the result equals threshold() on the host-decoded
+    array (float32 attributes: bit for bit; float64 attributes: thresh bit for bit, seas within rounding)"""
+    import xmhw_amd
+    import xmhw_amd.device as device
+    from xmhw_amd import GridSeries, ingest, netcdf3
+    from ingest_oracle import decode_packed          # numpy restatement (oracle/), not product code
+    time = np.arange("2001-01-01", "2013-01-01", dtype="datetime64[D]")
+    T, ny, nx = time.shape[0], 6, 8
+    rng = np.random.default_rng(5)
+    t = np.arange(T)[:, None, None]
+    sst = 15.0 + rng.uniform(2, 8, (ny, nx)) * np.sin(2 * np.pi * (t - rng.uniform(0, 365, (ny, nx))) / 365.25) + rng.normal(size=(T, ny, nx))
+    sst[:, 2, 3] = np.nan                                # land
+    sst[:, 5, :2] = np.nan
+    sst[rng.random(sst.shape) < 0.002] = np.nan          # holes (the default anynans=False keeps those cells)
+    if kind == "i16_f32attrs":
+        at = {"scale_factor": np.float32(0.01), "add_offset": np.float32(10.0), "_FillValue": np.int16(-32768)}
+        packed = np.where(np.isnan(sst), -32768, np.round((sst - 10.0) / 0.01)).astype(np.int16)
+    else:
+        at = {"scale_factor": 0.005, "add_offset": 10.0, "_FillValue": np.int16(-32768)}
+        packed = np.where(np.isnan(sst), -32768, np.round((sst - 10.0) / 0.005)).astype(np.int16)
+    p = tmp_path / "packed.nc"
+    days = (time - np.datetime64("2001-01-01")).astype(np.float64)
+    netcdf3.write_classic(str(p), {"time": T, "lat": ny, "lon": nx},
+                          {"time": (("time",), days, {"units": "days since 2001-01-01 00:00:00", "calendar": "proleptic_gregorian"}),
+                           "lat": (("lat",), np.arange(ny, dtype=np.float32), {}), "lon": (("lon",), np.arange(nx, dtype=np.float32), {}),
+                           "sst": (("time", "lat", "lon"), packed, at)}, record_dim="time")
+    temp = ingest.open_series(str(p), "sst")
+    host = decode_packed(temp.values)
+    ref = xmhw_amd.threshold(GridSeries(host, temp.dims, temp.coords, time_encoding=temp.time_encoding), coldSpells=cold)
+    calls = []
+    real = device.clim_raw_packed
+    monkeypatch.setattr(device, "clim_raw_packed", lambda *a, **k: (calls.append(k.get("decoded")), real(*a, **k))[1])
+    got = xmhw_amd.threshold(temp, coldSpells=cold)
+    assert calls == ["float32" if kind == "i16_f32attrs" else "float64"], "the packed file did not take the in-place path"
+    npt.assert_array_equal(got["thresh"], ref["thresh"])
+    if kind == "i16_f32attrs":
+        npt.assert_array_equal(got["seas"], ref["seas"])
+    else:
+        npt.assert_allclose(got["seas"], ref["seas"], rtol=1e-12, atol=1e-12)
+    assert np.isnan(got["thresh"][:, 2, 3]).all() and np.isfinite(got["thresh"][:, 0, 0]).all()
+    # ... and with the in-place path switched off the decoded path gives the same
+    monkeypatch.setenv("XMHW_PACKED_DIRECT", "0")
+    calls.clear()
+    off = xmhw_amd.threshold(temp, coldSpells=cold)
+    assert calls == []
+    npt.assert_array_equal(off["thresh"], ref["thresh"])
+    npt.assert_array_equal(off["seas"], ref["seas"])

@@ -1506,6 +1506,32 @@ int xmhw_land_mask_f64(const double* ts, int64_t T, int64_t C, int64_t ld, int a
     return XMHW_OK;
 }
 
+int xmhw_land_mask_i16(const int16_t* codes, int64_t T, int64_t C, int64_t ld, int big_endian, int has_fill,
+                       int32_t fill_code, int anynans, uint8_t* keep, void* stream) {
+    if (C < 0 || ld < C || T <= 0) return fail(XMHW_ERR_INVALID, "bad T/C/ld");
+    if (has_fill && (fill_code < -32768 || fill_code > 32767)) return fail(XMHW_ERR_INVALID, "fill_code is not an int16");
+    if (C == 0) return XMHW_OK;
+    if (!codes || !keep) return fail(XMHW_ERR_INVALID, "NULL device buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!has_fill) {           // no code means "missing": every cell stays
+        hipError_t e = hipMemsetAsync(keep, 1, static_cast<size_t>(C), st);
+        if (e != hipSuccess) return hip_fail(e, "land_mask memset");
+        return XMHW_OK;
+    }
+    uint16_t raw = static_cast<uint16_t>(static_cast<int16_t>(fill_code));
+    if (big_endian) raw = static_cast<uint16_t>((raw >> 8) | (raw << 8));
+    hipError_t e = xmhw::launch_land_mask_i16(codes, T, C, ld, static_cast<int16_t>(raw), anynans, keep, st);
+    if (e != hipSuccess) return hip_fail(e, "land_mask launch");
+    return XMHW_OK;
+}
+int xmhw_gather_cells_i16(const int16_t* in, int64_t rows, int64_t ld_in, const int64_t* index, int64_t n,
+                          int16_t* out, int64_t ld_out, void* stream) {
+    if (rows < 0 || n < 0 || ld_out < n) return fail(XMHW_ERR_INVALID, "bad rows/n/ld_out");
+    hipError_t e = xmhw::launch_gather_cells<int16_t>(in, rows, ld_in, index, n, out, ld_out,
+                                                      static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "gather_cells launch");
+    return XMHW_OK;
+}
 int xmhw_gather_cells_f32(const float* in, int64_t rows, int64_t ld_in, const int64_t* index, int64_t n,
                           float* out, int64_t ld_out, void* stream) {
     if (rows < 0 || n < 0 || ld_out < n) return fail(XMHW_ERR_INVALID, "bad rows/n/ld_out");

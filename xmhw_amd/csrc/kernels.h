@@ -158,6 +158,9 @@ template <typename T>
 hipError_t launch_land_mask(const T* ts, int64_t Tn, int64_t C, int64_t ld, int anynans,
                             uint8_t* keep, hipStream_t stream);
 
+hipError_t launch_land_mask_i16(const int16_t* codes, int64_t Tn, int64_t C, int64_t ld, int16_t fill_raw, int anynans,
+                                uint8_t* keep, hipStream_t stream);
+
 template <typename T>
 hipError_t launch_gather_cells(const T* in, int64_t rows, int64_t ld_in, const int64_t* index, int64_t n,
                                T* out, int64_t ld_out, hipStream_t stream);

@@ -594,9 +594,10 @@ hipError_t launch_finish(const double* th_in, const double* se_in, int64_t C, in
 // A workgroup owns 64 cells; its four waves each scan a quarter of the time axis (rows loaded kAhead at
 // a time, lanes along the cell axis) and the NaN counts meet in LDS: four times the loads in flight
 // per cell of the one-thread-per-cell loop (2.25 TB/s on 259,200 cells x 14,610 steps).
-template <typename T>
+// (MISSING: a sample is missing when it is NaN -- float32 / float64 -- or when it equals `fillv` as stored: int16 codes)
+template <typename T, bool FILL>
 __global__ __launch_bounds__(256) void land_mask(const T* __restrict__ ts, int64_t Tn, int64_t C,
-                                                 int64_t ld, int anynans, uint8_t* __restrict__ keep) {
+                                                 int64_t ld, int anynans, uint8_t* __restrict__ keep, T fillv) {
     constexpr int kAhead = 8;
     __shared__ unsigned int part_nan[4][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -611,11 +612,11 @@ __global__ __launch_bounds__(256) void land_mask(const T* __restrict__ ts, int64
 #pragma unroll
         for (int u = 0; u < kAhead; ++u) v[u] = col[(t + u) * ld];
 #pragma unroll
-        for (int u = 0; u < kAhead; ++u) nnan += (v[u] != v[u]) ? 1u : 0u;
+        for (int u = 0; u < kAhead; ++u) nnan += (FILL ? v[u] == fillv : v[u] != v[u]) ? 1u : 0u;
     }
     for (; t < t1; ++t) {
         const T v = col[t * ld];
-        nnan += (v != v) ? 1u : 0u;
+        nnan += (FILL ? v == fillv : v != v) ? 1u : 0u;
     }
     part_nan[part][lane] = nnan;
     __syncthreads();
@@ -629,8 +630,16 @@ template <typename T>
 hipError_t launch_land_mask(const T* ts, int64_t Tn, int64_t C, int64_t ld, int anynans,
                             uint8_t* keep, hipStream_t stream) {
     if (C <= 0) return hipSuccess;
-    hipLaunchKernelGGL(land_mask<T>, dim3(static_cast<unsigned>((C + 63) / 64)), dim3(256), 0, stream,
-                       ts, Tn, C, ld, anynans, keep);
+    hipLaunchKernelGGL((land_mask<T, false>), dim3(static_cast<unsigned>((C + 63) / 64)), dim3(256), 0, stream,
+                       ts, Tn, C, ld, anynans, keep, static_cast<T>(0));
+    return hipGetLastError();
+}
+// int16 codes: a sample is missing when it equals fill_raw (the fill code AS STORED: byte-swapped for big-endian codes)
+hipError_t launch_land_mask_i16(const int16_t* codes, int64_t Tn, int64_t C, int64_t ld, int16_t fill_raw, int anynans,
+                                uint8_t* keep, hipStream_t stream) {
+    if (C <= 0) return hipSuccess;
+    hipLaunchKernelGGL((land_mask<int16_t, true>), dim3(static_cast<unsigned>((C + 63) / 64)), dim3(256), 0, stream,
+                       codes, Tn, C, ld, anynans, keep, fill_raw);
     return hipGetLastError();
 }
 template hipError_t launch_land_mask<float>(const float*, int64_t, int64_t, int64_t, int, uint8_t*,
@@ -681,6 +690,8 @@ template hipError_t launch_gather_cells<float>(const float*, int64_t, int64_t, c
                                                float*, int64_t, hipStream_t);
 template hipError_t launch_gather_cells<double>(const double*, int64_t, int64_t, const int64_t*, int64_t,
                                                 double*, int64_t, hipStream_t);
+template hipError_t launch_gather_cells<int16_t>(const int16_t*, int64_t, int64_t, const int64_t*, int64_t,
+                                                 int16_t*, int64_t, hipStream_t);
 
 hipError_t launch_scatter_cells(const double* in, int64_t rows, int64_t ld_in, const int64_t* index,
                                 int64_t n, double* out, int64_t ld_out, int64_t ncols_out,

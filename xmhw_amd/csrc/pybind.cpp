@@ -243,6 +243,12 @@ PYBIND11_MODULE(_xmhw_hip, m) {
         else throw InvalidError("itemsize must be 4 or 8");
     }, py::arg("ts"), py::arg("itemsize"), py::arg("T"), py::arg("C"), py::arg("ld"), py::arg("anynans"),
        py::arg("keep"), py::arg("stream") = 0);
+    m.def("land_mask_i16", [](uintptr_t codes, int64_t T, int64_t C, int64_t ld, int big_endian, int has_fill, int32_t fill_code,
+                              int anynans, uintptr_t keep, uintptr_t stream) {
+        check(xmhw_land_mask_i16(static_cast<const int16_t*>(vp(codes)), T, C, ld, big_endian, has_fill, fill_code, anynans,
+                                 static_cast<uint8_t*>(vp(keep)), vp(stream)));
+    }, py::arg("codes"), py::arg("T"), py::arg("C"), py::arg("ld"), py::arg("big_endian"), py::arg("has_fill"),
+       py::arg("fill_code"), py::arg("anynans"), py::arg("keep"), py::arg("stream") = 0);
 
     m.def("gather_cells", [](uintptr_t in, int itemsize, int64_t rows, int64_t ld_in, uintptr_t index, int64_t n,
                              uintptr_t out, int64_t ld_out, uintptr_t stream) {
@@ -252,7 +258,10 @@ PYBIND11_MODULE(_xmhw_hip, m) {
         else if (itemsize == 8)
             check(xmhw_gather_cells_f64(static_cast<const double*>(vp(in)), rows, ld_in, static_cast<const int64_t*>(vp(index)),
                                         n, static_cast<double*>(vp(out)), ld_out, vp(stream)));
-        else throw InvalidError("itemsize must be 4 or 8");
+        else if (itemsize == 2)
+            check(xmhw_gather_cells_i16(static_cast<const int16_t*>(vp(in)), rows, ld_in, static_cast<const int64_t*>(vp(index)),
+                                        n, static_cast<int16_t*>(vp(out)), ld_out, vp(stream)));
+        else throw InvalidError("itemsize must be 2, 4 or 8");
     }, py::arg("in"), py::arg("itemsize"), py::arg("rows"), py::arg("ld_in"), py::arg("index"), py::arg("n"),
        py::arg("out"), py::arg("ld_out"), py::arg("stream") = 0);
     m.def("scatter_cells", [](uintptr_t in, int64_t rows, int64_t ld_in, uintptr_t index, int64_t n, uintptr_t out,

@@ -433,10 +433,11 @@ def _staged_upload(dst_ptr, src, file=None):
     st["busy"] = [False, False]
 
 
-def upload_columns(stacked, lo, hi):
+def upload_columns(stacked, lo, hi, raw=False):
     """Columns [lo, hi) of a C-contiguous host (T, N) array as a dense device (T, n) array of the
     DECODED dtype: a pitched upload of the raw bytes, then -- for file views (PackedArray: big-endian
-    and / or CF-packed samples) -- the decode kernel.  Returns (DeviceBuffer, itemsize)."""
+    and / or CF-packed samples) -- the decode kernel.  Returns (DeviceBuffer, itemsize).
+    ``raw=True``: the stored bytes as they are (int16 codes for the kernels that read them in place)."""
     import time as _time
     h = hip()
     T = stacked.shape[0]
@@ -453,7 +454,7 @@ def upload_columns(stacked, lo, hi):
         else:
             h.memcpy2d_h2d(d_raw.ptr, np.asarray(stacked), lo, n)
         _trace(f"upload columns [{lo},{hi}) {raw_isz * T * n / 1e9:.2f} GB", _t0)
-        if not is_packed(stacked):
+        if raw or not is_packed(stacked):
             out, d_raw = d_raw, None
             return out, raw_isz
         d = stacked.decode
@@ -502,6 +503,45 @@ def mask_compact(d_raw, isz, T, n, anynans):
         d_idx = DeviceBuffer.from_array(np.nonzero(keep)[0].astype(np.int64))
         d_out = DeviceBuffer(isz * T * nk)
         h.gather_cells(d_raw.ptr, isz, T, n, d_idx.ptr, nk, d_out.ptr, nk)
+        h.stream_sync(0)
+        out, d_out = d_out, None
+        return out, keep
+    finally:
+        for b in (d_raw, d_mask, d_idx, d_out):
+            if b is not None:
+                b.free()
+
+
+def packed_recipe(stacked):
+    """the CF recipe of an int16 file view as xmhw_clim_raw_i16 / xmhw_land_mask_i16 take it"""
+    d = stacked.decode
+    fill = d.get("fill")
+    if fill is not None and not (float(fill) == int(fill) and -32768 <= int(fill) <= 32767):
+        fill = None                                      # no int16 code equals it: nothing is missing
+    big = stacked.dtype.byteorder == ">" or (stacked.dtype.byteorder == "=" and not np.little_endian)
+    return dict(scale=d.get("scale"), offset=d.get("offset"), fill=None if fill is None else int(fill),
+                decoded=np.dtype(d["out"]).name, big_endian=bool(big))
+
+
+def mask_compact_codes(d_raw, T, n, anynans, recipe):
+    """mask_compact() on int16 codes: a sample is missing when its code is the fill code"""
+    h = hip()
+    d_mask = d_idx = d_out = None
+    try:
+        d_mask = DeviceBuffer(n)
+        h.land_mask_i16(d_raw.ptr, T, n, n, int(recipe["big_endian"]), int(recipe["fill"] is not None),
+                        0 if recipe["fill"] is None else recipe["fill"], int(bool(anynans)), d_mask.ptr)
+        h.stream_sync(0)
+        keep = d_mask.to_array((n,), np.uint8) != 0
+        nk = int(keep.sum())
+        if nk == n:
+            out, d_raw = d_raw, None
+            return out, keep
+        if nk == 0:
+            return None, keep
+        d_idx = DeviceBuffer.from_array(np.nonzero(keep)[0].astype(np.int64))
+        d_out = DeviceBuffer(2 * T * nk)
+        h.gather_cells(d_raw.ptr, 2, T, n, d_idx.ptr, nk, d_out.ptr, nk)
         h.stream_sync(0)
         out, d_out = d_out, None
         return out, keep
@@ -574,9 +614,9 @@ class SlabPrefetcher:
     synchronous for the calling thread (about 54 GB/s on this platform), so overlap takes a second
     thread, not a second stream; the bindings release the GIL during copies."""
 
-    def __init__(self, stacked, slabs):
+    def __init__(self, stacked, slabs, raw=False):
         import threading
-        self._stacked, self._slabs = stacked, list(slabs)
+        self._stacked, self._slabs, self._raw = stacked, list(slabs), bool(raw)
         self._threading = threading
         self._next = None
         self._start(0)
@@ -591,7 +631,7 @@ class SlabPrefetcher:
         def work():
             try:
                 hip().set_device(dev)                      # the device is a per-thread setting
-                box["out"] = upload_columns(self._stacked, *self._slabs[i])
+                box["out"] = upload_columns(self._stacked, *self._slabs[i], raw=self._raw)
             except BaseException as e:                     # noqa: BLE001 -- re-raised in the consumer
                 box["err"] = e
 
@@ -771,14 +811,25 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
             th = np.empty((D, c1 - c0))
             se = np.empty((D, c1 - c0))
             touching = _prefault(th, se)
+        # int16-packed file views on plans and percentiles the sorted-list kernel serves: the CODES stay what is resident --
+        # land mask, compaction and the climatology kernels read them in place (xmhw_clim_raw_i16), no decoded copy, no
+        # decode pass.  Not with maxPadLength (interpolation needs decoded samples) nor when detect() will want the decoded
+        # series next (resident).  XMHW_PACKED_DIRECT=0 turns it off.
+        direct = (is_packed(stacked) and stacked.dtype.kind == "i" and stacked.dtype.itemsize == 2 and pad is None
+                  and resident is None and kernel == "auto" and pctile / 100.0 >= 0.85 and plan.layout_in_use() == LAYOUTS["sorted"]
+                  and _os.environ.get("XMHW_PACKED_DIRECT", "1") != "0")
+        recipe = packed_recipe(stacked) if direct else None
         # slab k+1 is uploaded (and decoded) by a second thread while slab k computes
-        pre = SlabPrefetcher(stacked, slabs)
+        pre = SlabPrefetcher(stacked, slabs, raw=direct)
         import time as _time
         _tl = _time.perf_counter()
         for (lo, hi), (d_up, up_isz) in pre:
             _trace(f"wait for slab [{lo},{hi})", _tl)
             _tl = _time.perf_counter()
-            d_ts, keep = mask_compact(d_up, up_isz, T, hi - lo, anynans)
+            if direct:
+                d_ts, keep = mask_compact_codes(d_up, T, hi - lo, anynans, recipe)
+            else:
+                d_ts, keep = mask_compact(d_up, up_isz, T, hi - lo, anynans)
             _trace("mask + compact", _tl)
             _tl = _time.perf_counter()
             keeps.append(keep)
@@ -800,7 +851,12 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
                     pad.apply(d_ts.ptr, isz, T, n)
                 raw_th, raw_se = DeviceBuffer(8 * D * n), DeviceBuffer(8 * D * n)
                 bufs += [raw_th, raw_se]
-                clim_raw(plan, d_ts, isz, n, pctile / 100.0, coldSpells, raw_th, raw_se)
+                if direct:
+                    clim_raw_packed(plan, d_ts, n, pctile / 100.0, coldSpells, raw_th, raw_se, scale_factor=recipe["scale"],
+                                    add_offset=recipe["offset"], fill=recipe["fill"], decoded=recipe["decoded"],
+                                    big_endian=recipe["big_endian"])
+                else:
+                    clim_raw(plan, d_ts, isz, n, pctile / 100.0, coldSpells, raw_th, raw_se)
                 out_th, out_se = raw_th, raw_se
                 if finish:
                     out_th, out_se = DeviceBuffer(8 * D * n), DeviceBuffer(8 * D * n)
