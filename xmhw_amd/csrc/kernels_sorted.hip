@@ -69,6 +69,18 @@ __device__ __forceinline__ int32_t med3i(int32_t a, int32_t b, int32_t c) {
     asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// bit I of m as a whole-word mask (0 or all ones): one v_bfe_i32 (left to itself the compiler tests the bit and selects:
+// three instructions per key of a window)
+template <int I>
+__device__ __forceinline__ int32_t bit_mask(uint32_t m) {
+    int32_t r;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(m), "n"(I));
+    return r;
+}
+// (a ^ b) & ~c in one v_bitop3 (truth table over bit index a * 4 + b * 2 + c: 0x14)
+__device__ __forceinline__ uint32_t xor_andn(uint32_t a, uint32_t b, int32_t c) {
+    return static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(static_cast<int32_t>(a), static_cast<int32_t>(b), c, 0x14));
+}
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
@@ -126,12 +138,15 @@ __device__ __forceinline__ void sorted_body(
     constexpr int HE = (YPS + 1) / 2 * 2;        // keys per lane, padded to an even count
     constexpr int HH = HE / 2;                   // sorted keys per lane after the exchange
     constexpr int KH = K / 2;                    // keys of the new list a lane ends with
-    constexpr int KW = K + 2;                    // words per list and cell: +inf, K keys, 0
+    constexpr int KW = K;                        // words per list and cell: the K keys, nothing else
     constexpr int NTP = 2 * YPS;
     constexpr uint32_t LSTRIDE = 32 * 4;         // bytes between consecutive positions of a list
     constexpr uint32_t LBYTES = KW * LSTRIDE;    // bytes per list (32 cells)
     static_assert(K <= HE && K % 2 == 0, "a list stores an even number of keys, at most what a lane holds");
-    __shared__ __attribute__((aligned(16))) uint32_t lds[R * KW * 32 + 64];
+    // rows below list 0: where a window that reaches below it reads (and is masked).  LDS is handed out in 512-byte
+    // pieces: 7 waves per CU leave a wave 23,040 bytes = 180 rows, 176 of them lists at K = 16
+    constexpr int PADROWS = 4;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[(R * KW + PADROWS) * 32];
 
     const int lane = threadIdx.x & 63;
     const int sub = lane & 1;
@@ -149,35 +164,45 @@ __device__ __forceinline__ void sorted_body(
     const uint32_t* tab = table + sub;
 
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u32*)lds));
-    const uint32_t lcell = lds0 + static_cast<uint32_t>(cw) * 4u;              // word 0 of list 0 of this cell
-    const uint32_t ldummy = lds0 + R * LBYTES + static_cast<uint32_t>(cw) * 4u; // [+inf][0], LSTRIDE apart
-    // ---- LDS: every list empty (keys 0 = invalid), sentinels in place ------------------------------------
-    for (int i = lane; i < R * KW * 32 + 64; i += 64) {
-        const int pos = (i / 32) % KW;
-        lds[i] = (i < R * KW * 32) ? (pos == 0 ? 0xFFFFFFFFu : 0u) : (i < R * KW * 32 + 32 ? 0xFFFFFFFFu : 0u);
-    }
+    const uint32_t lcell = lds0 + PADROWS * LSTRIDE + static_cast<uint32_t>(cw) * 4u;      // key 0 of list 0 of this cell
+    // ---- LDS: every list empty (keys 0 = invalid).  No sentinels: a window that reaches past either end of its list
+    // is masked after the read (what it read there -- a neighbouring list, or nothing: an LDS read outside the
+    // few rows of padding -- is never looked at); (11 x K + 5) x 128 bytes per wave = 7 waves per CU at K = 16
+    for (int i = lane; i < (R * KW + PADROWS) * 32; i += 64) lds[i] = 0u;
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 
-    // own list slots: global slot g = sub * NL + j; P[j] = byte address of the first key OUTSIDE the top set
+    // own list slots: global slot g = sub * NL + j; P[j] = the list's keys INSIDE the top set = index of the first key outside
     V8 P;
-    uint32_t ltop[NL];                           // address of the list's upper sentinel (word 0)
+    uint32_t lbase[NL];                          // address of the list's key 0
+    uint32_t lk[NL];                             // keys a list can hold: K (lane 1's sixth slot is a dummy: 0)
     // (per own list: its valid keys and the float64 sum of its samples as two words -- register tuples indexed by the
     // wave-uniform slot number through the index register, like P)
     V8 nvl, rs_lo, rs_hi;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
         const int g = sub * NL + j;
-        ltop[j] = (g < R) ? lcell + static_cast<uint32_t>(g) * LBYTES : ldummy;
-        P[j] = (g < R) ? ltop[j] + LSTRIDE : ldummy + LSTRIDE;
+        lbase[j] = lcell + static_cast<uint32_t>(g < R ? g : NL - 1) * LBYTES;      // (the dummy sits in the middle: see inb())
+        lk[j] = g < R ? static_cast<uint32_t>(K) : 0u;
+        P[j] = 0;
     }
     P[6] = 0;
     P[7] = 0;
     nvl = 0;
     rs_lo = 0;
     rs_hi = 0;
-    // (the lower sentinel of the last own list: lane 1's is the dummy's, right behind its upper one)
-    const uint32_t lbot_last = (sub * NL + NL - 1 < R) ? ltop[NL - 1] + (K + 1) * LSTRIDE : ldummy + LSTRIDE;
+    // Every LDS read stays inside the workgroup's allocation: a window reaches at most five positions past an end of its
+    // list, which is inside a neighbouring list (K >= 6) or, below list 0 (slot j = 0 of lane 0), inside the four padding
+    // rows -- the fifth position is clamped to the first of them; above list 10 (slot j = 4 of lane 1) there is no room
+    // for padding: that slot clamps its addresses to the cell's last word.
+    const int32_t lds_first = static_cast<int32_t>(lcell - PADROWS * LSTRIDE);
+    const int32_t lds_last = static_cast<int32_t>(lcell + static_cast<uint32_t>(R * KW - 1) * LSTRIDE);
+    auto inb = [&](int j, int i, uint32_t addr) -> uint32_t {
+        if (j == 0 && i == 4) return static_cast<uint32_t>(max(static_cast<int32_t>(addr), lds_first));
+        if (j == NL - 2) return static_cast<uint32_t>(min(static_cast<int32_t>(addr), lds_last));
+        return addr;
+    };
+    static_assert(K >= 5, "a window of five positions must stay inside the neighbouring list");
     uint32_t truncmask = 0;
     // cell-level state, the same in both lanes
     uint32_t Ctop = 0, n = 0, B = 0;
@@ -398,14 +423,14 @@ __device__ __forceinline__ void sorted_body(
         const bool own_m = sub == m_sub;
         const uint32_t base_m = lcell + static_cast<uint32_t>(m) * LBYTES;
 #pragma unroll
-        for (int i = 0; i < KH; ++i) lds_st(base_m + static_cast<uint32_t>(1 + sub * KH + i) * LSTRIDE, u[i]);
+        for (int i = 0; i < KH; ++i) lds_st(base_m + static_cast<uint32_t>(sub * KH + i) * LSTRIDE, u[i]);
         // what leaves: the evicted list's share of the top set, its valid keys, its sum
         uint32_t c_old = 0, nv_old = 0;
         {
             const uint32_t Pm = P[mj];
             const uint32_t nvm = nvl[mj];
             if (own_m) {
-                c_old = ((Pm - base_m) >> 7) - 1u;
+                c_old = Pm;
                 nv_old = nvm;
             }
         }
@@ -426,7 +451,7 @@ __device__ __forceinline__ void sorted_body(
         din += swp(din);
         Ctop += c_new - c_old;
         n += nvin - nv_old;
-        P[mj] = own_m ? base_m + (1u + c_new) * LSTRIDE : P[mj];
+        P[mj] = own_m ? c_new : P[mj];
         if (own_m) truncmask = (truncmask & ~(1u << mj)) | ((nvin > static_cast<uint32_t>(K) ? 1u : 0u) << mj);
         {
             const uint64_t db = static_cast<uint64_t>(__double_as_longlong(din));
@@ -465,8 +490,21 @@ __device__ __forceinline__ void sorted_body(
         // min over the lists of the smallest key INSIDE the top set (the cells that move nowhere need both sides)
         uint32_t um = 0xFFFFFFFFu;
 #pragma unroll
-        for (int j = 0; j < NL; ++j) um = umin(um, lds_ld(P[j] - LSTRIDE));
+        for (int j = 0; j < NL; ++j) {
+            const uint32_t pj_ = P[j];
+            const uint32_t in_ = lds_ld(inb(j, 0, lbase[j] + (pj_ - 1u) * LSTRIDE));  // (pj_ == 0: nothing inside, the read is ignored)
+            um = umin(um, pj_ != 0u ? in_ : 0xFFFFFFFFu);
+        }
         um = umin(um, swp(um));
+        // (per list, for this row's direction: the address the window starts from when the pointer is 0, and the constant
+        // that turns the pointer into the number of keys left in the window's direction -- K - p growing, p shrinking)
+        const uint32_t dir_s = grow ? 0xFFFFFFFFu : 0u;
+        uint32_t wbase[NL], wleft[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            wbase[j] = lbase[j] - (grow ? 0u : LSTRIDE);
+            wleft[j] = grow ? lk[j] + 1u : 0u;
+        }
         uint32_t TL = 0, TN = 0;       // complemented space: the last key that moved, the key that would move next
         bool flag = false;
         bool pending = true, tn_ok = true;
@@ -481,14 +519,16 @@ __device__ __forceinline__ void sorted_body(
                 // (addresses first, then the 30 reads back to back, then ONE wait: left to itself the compiler
                 // interleaves them and waits for the LDS five times per list)
                 uint32_t ad[NL][5];
+                uint32_t wm[NL];           // bit i: key i of the window does NOT exist
 #pragma unroll
                 for (int j = 0; j < NL; ++j) {
-                    const int32_t topj = static_cast<int32_t>(ltop[j]);
-                    const int32_t botj = j == NL - 1 ? static_cast<int32_t>(lbot_last) : topj + static_cast<int32_t>((K + 1) * LSTRIDE);
-                    const int32_t A0 = static_cast<int32_t>(P[j]) - (grow ? 0 : static_cast<int32_t>(LSTRIDE));
-                    ad[j][0] = static_cast<uint32_t>(A0);
+                    const uint32_t pj_ = P[j];
+                    const uint32_t left = (pj_ ^ dir_s) + wleft[j];            // K - p (growing) or p (shrinking)
+                    wm[j] = 0xFFFFFFFFu << left;                                // (left <= 18)
+                    const int32_t A0 = static_cast<int32_t>(wbase[j] + pj_ * LSTRIDE);
+                    ad[j][0] = inb(j, 0, static_cast<uint32_t>(A0));
 #pragma unroll
-                    for (int i = 1; i < 5; ++i) ad[j][i] = static_cast<uint32_t>(med3i(A0 + i * dstep, topj, botj));
+                    for (int i = 1; i < 5; ++i) ad[j][i] = inb(j, i, static_cast<uint32_t>(A0 + i * dstep));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 uint32_t raw[NL][5];
@@ -499,9 +539,11 @@ __device__ __forceinline__ void sorted_body(
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < NL; ++j) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) a[j][i] = raw[j][i] ^ cm;
-                    F = umax(F, raw[j][4] ^ cm);
+                    a[j][0] = xor_andn(raw[j][0], cm, bit_mask<0>(wm[j]));
+                    a[j][1] = xor_andn(raw[j][1], cm, bit_mask<1>(wm[j]));
+                    a[j][2] = xor_andn(raw[j][2], cm, bit_mask<2>(wm[j]));
+                    a[j][3] = xor_andn(raw[j][3], cm, bit_mask<3>(wm[j]));
+                    F = umax(F, xor_andn(raw[j][4], cm, bit_mask<4>(wm[j])));
                 }
             }
             // -- the lane's 16 largest of its 24, sorted: a tree of merges of sorted runs
@@ -602,7 +644,7 @@ __device__ __forceinline__ void sorted_body(
             moved += swp(moved);
 #pragma unroll
             for (int j = 0; j < NL; ++j)
-                P[j] = static_cast<uint32_t>(static_cast<int32_t>(P[j]) + (move ? static_cast<int32_t>(pj[j]) * dstep : 0));
+                P[j] = move ? (grow ? P[j] + pj[j] : P[j] - pj[j]) : P[j];
             rem -= moved;
             if (dry) {
                 flag = true;
@@ -621,7 +663,12 @@ __device__ __forceinline__ void sorted_body(
             // the key that would move next, from the lists' heads
             uint32_t hx = 0;
 #pragma unroll
-            for (int j = 0; j < NL; ++j) hx = umax(hx, lds_ld(P[j] - (grow ? 0u : LSTRIDE)) ^ cm);
+            for (int j = 0; j < NL; ++j) {
+                const uint32_t pj_ = P[j];
+                const uint32_t left = (pj_ ^ dir_s) + wleft[j];
+                const uint32_t hd = lds_ld(inb(j, 0, wbase[j] + pj_ * LSTRIDE)) ^ cm;
+                hx = umax(hx, left != 0u ? hd : 0u);
+            }
             hx = umax(hx, swp(hx));
             TN = tn_ok ? TN : hx;
         }
@@ -638,11 +685,11 @@ __device__ __forceinline__ void sorted_body(
             uint32_t atb = 0;
 #pragma unroll
             for (int j = 0; j < NL; ++j)
-                atb |= (P[j] == ltop[j] + (K + 1) * LSTRIDE && ((truncmask >> j) & 1u)) ? (1u << j) : 0u;     // (never the dummy: no bit)
+                atb |= (P[j] == static_cast<uint32_t>(K) && ((truncmask >> j) & 1u)) ? (1u << j) : 0u;     // (never the dummy: no bit)
             if (__any(atb != 0u)) {
 #pragma unroll
                 for (int j = 0; j < NL; ++j) {
-                    const uint32_t Uj = lds_ld(P[j] - LSTRIDE);
+                    const uint32_t Uj = lds_ld(lbase[j] + static_cast<uint32_t>(K - 1) * LSTRIDE);
                     flag = flag || (((atb >> j) & 1u) && Uj > a_lo);
                 }
             }
