@@ -408,12 +408,14 @@ def run(args):
         _p = _Plan(doy, w, kernel=args.kernel, nchunks=args.chunks, ring2=args.ring2)      # (host side only: no GPU touched)
         _nch = _p.chunks_in_use(int(args.cells) or ps["cells"])
         _rows_per_wave = float(len(np.unique(doy))) / max(_nch, 1) + 2 * w
+        _waves_cu = 8
         if args.dtype == "f32" and _p.layout_in_use() == 40:
             # the sorted-list kernel: a wave runs ONE of the plan's chunks (warm-up rows + rows with output)
             from xmhw_amd._lib import hip as _hip
             _k, _lds, _pieces = _hip().plan_sorted_info(_p.handle, int(args.cells) or ps["cells"])
             _chunks = np.asarray(_hip().plan_sorted_table(_p.handle, int(_pieces))[0])
             _rows_per_wave = float(np.mean(_chunks[:, 2] - _chunks[:, 0]))
+            _waves_cu = min(8, (160 * 1024) // (512 * ((int(_lds) + 511) // 512)))
         _p.destroy()
         traffic, traffic_src, sq = live_counters(child_argv, _rows_per_wave)
         # the issue floor of the sorted-list kernel: its vector instructions by issue class (from the ISA, hipcc
@@ -427,7 +429,8 @@ def run(args):
                     rounds = float(first["sorted"]["walk_iterations_per_wave_row"])
                 r_ = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "issue_mix.py"),
                                      "--rounds", str(rounds), "--measured-valu", str(sq["valu_per_wave_row"]),
-                                     "--measured-quad-cycles", str(sq["wave_quad_cycles_per_wave_row"])],
+                                     "--measured-quad-cycles", str(sq["wave_quad_cycles_per_wave_row"]),
+                                     "--waves-per-cu", str(_waves_cu)],
                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
                 if r_.returncode == 0:
                     sq["issue_mix"] = json.loads(r_.stdout.decode())
@@ -541,7 +544,8 @@ def run(args):
              ("clim_ring_" + args.dtype if plan.kernel == "ring" else "clim_generic"))
     waves_cu = 8
     if v2 == 40:
-        waves_cu = min(32, (160 * 1024) // int(h.plan_sorted_info(plan.handle, C)[1]))
+        # (LDS is handed out in 512-byte pieces; the kernel's registers -- launch bound (64, 2) -- allow 8 waves per CU)
+        waves_cu = min(8, (160 * 1024) // (512 * ((int(h.plan_sorted_info(plan.handle, C)[1]) + 511) // 512)))
 
     result = {
         "metric": "grid-cells/sec for threshold() on 40yr daily SST",

@@ -42,6 +42,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=float, default=1.26)
     ap.add_argument("--measured-valu", type=float, default=0.0, help="SQ_INSTS_VALU per wave-row of the product kernel")
+    ap.add_argument("--waves-per-cu", type=int, default=7, help="waves of this kernel a CU holds (LDS): 4..8")
     ap.add_argument("--measured-quad-cycles", type=float, default=0.0, help="SQ_WAVE_CYCLES per wave-row (quad-cycles)")
     args = ap.parse_args()
     with tempfile.TemporaryDirectory() as tmp:
@@ -72,9 +73,9 @@ def main():
             continue
         if count(ins, "v_bitop3") >= 15 and "conv" not in tagged:
             tagged["conv"] = (name, ins, 1.0)            # (two copies exist -- heat waves / cold spells; a row runs one)
-        elif count(ins, "ds_write") >= 6 and count(ins, "v_max_u32") + count(ins, "v_min_u32") > 100:
+        elif count(ins, "ds_write") >= 3 and count(ins, "v_max_u32") + count(ins, "v_min_u32") > 100:
             tagged["sort+book"] = (name, ins, 1.0)
-        elif count(ins, "ds_read") >= 20 and count(ins, "v_med3_i32") >= 10:
+        elif count(ins, "ds_read") >= 20 and count(ins, "v_bfe_i32") + count(ins, "v_med3_i32") >= 10:
             tagged["select round"] = (name, ins, args.rounds)
         elif count(ins, "ds_read") >= 5 and count(ins, "ds_read") < 12 and count(ins, "v_min") >= 1 and "direction" not in tagged and v < 80:
             tagged["direction"] = (name, ins, 1.0)
@@ -106,19 +107,20 @@ def main():
            "class_A_share": fa, "class_B_share": fb,
            "cost_cycles": {"A": COST["A"], "B": COST["B"], "source": "profiles/r1_ubench_valu2.txt (>= 2 waves per SIMD, one wave alone)"},
            "issue_floor_cycles_per_wave_row": {"two_or_more_waves_per_simd": floor2, "one_wave_per_simd": floor1,
-                                               # 6 waves per CU: two SIMDs hold two waves, two hold one
-                                               "this_kernel_mixed_occupancy": 0.5 * floor2 + 0.5 * floor1}}
+                                               # 7 waves per CU: three SIMDs hold two waves, one holds one
+                                               "this_kernel_mixed_occupancy": 0.75 * floor2 + 0.25 * floor1}}
     if args.measured_quad_cycles:
         cyc = 4.0 * args.measured_quad_cycles           # cycles a wave spends on one of its rows
         res["measured_wave_cycles_per_wave_row"] = cyc
-        # LDS holds 6 waves per CU: two SIMDs run two waves (a wave-row costs the SIMD floor2 cycles there), two run a wave
-        # alone (floor1).  Wave-rows a CU could retire per cycle at the floor, against what it retires:
-        at_floor = 2.0 * (1.0 / floor2) + 2.0 * (1.0 / floor1)
-        measured = 6.0 / cyc
+        # LDS holds 7 waves per CU (--waves-per-cu): three SIMDs run two waves (a wave-row costs the SIMD floor2 cycles
+        # there), one runs a wave alone (floor1).  Wave-rows a CU could retire per cycle at the floor, against what it retires:
+        two = args.waves_per_cu - 4
+        at_floor = two * (1.0 / floor2) + (4 - two) * (1.0 / floor1)
+        measured = args.waves_per_cu / cyc
         res["frac_of_issue_floor_at_this_occupancy"] = measured / at_floor
         res["frac_of_issue_floor_at_two_waves_per_simd"] = measured / (4.0 / floor2)
-        res["note"] = ("wave-rows per CU-cycle measured (6 waves / wave cycles per row) over wave-rows per CU-cycle if every SIMD issued "
-                       "a vector instruction whenever the class costs allow: at the occupancy LDS gives (2, 2, 1, 1 waves per SIMD) and "
+        res["note"] = ("wave-rows per CU-cycle measured (waves per CU / wave cycles per row) over wave-rows per CU-cycle if every SIMD issued "
+                       "a vector instruction whenever the class costs allow: at the occupancy LDS gives (2, 2, 2, 1 waves per SIMD) and "
                        "if every SIMD had two waves")
     json.dump(res, sys.stdout, indent=1)
     print(file=sys.stdout)

@@ -34,8 +34,8 @@ for tag, out in (("sq", "r5_pmc_sq_prod.txt"), ("lds", "r5_pmc_lds_prod.txt")):
         lines.append(f"{k:24s} {agg[k] / w / rows:10.1f}")
     if 'SQ_ACTIVE_INST_VALU' in agg:
         wc = agg['SQ_WAVE_CYCLES']
-        lines.append('VALU busy quad-cycles / wave quad-cycles %.3f (x 1.5 waves per SIMD = %.3f of the SIMD)  wait_any %.3f  wait_inst_any %.3f' % (
-            agg['SQ_ACTIVE_INST_VALU'] / wc, 1.5 * agg['SQ_ACTIVE_INST_VALU'] / wc, agg['SQ_WAIT_ANY'] / wc, agg['SQ_WAIT_INST_ANY'] / wc))
+        lines.append('VALU busy quad-cycles / wave quad-cycles %.3f (x 1.75 waves per SIMD = %.3f of the SIMD)  wait_any %.3f  wait_inst_any %.3f' % (
+            agg['SQ_ACTIVE_INST_VALU'] / wc, 1.75 * agg['SQ_ACTIVE_INST_VALU'] / wc, agg['SQ_WAIT_ANY'] / wc, agg['SQ_WAIT_INST_ANY'] / wc))
     open('$O/' + out, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
 PY
@@ -57,7 +57,7 @@ import json, subprocess, sys
 d = json.load(open('$O/r5_bench.json')); b = d['roofline']['binding']
 tk = json.loads(open('$O/r5_ticks.jsonl').readline())['sorted']['walk_iterations_per_wave_row'] if __import__('os').path.exists('$O/r5_ticks.jsonl') else 1.26
 out = subprocess.run([sys.executable, '$R/tools/issue_mix.py', '--rounds', str(tk), '--measured-valu', str(b['insts_per_wave_row']['valu']),
-                      '--measured-quad-cycles', str(b['wave_quad_cycles_per_wave_row'])], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                      '--measured-quad-cycles', str(b['wave_quad_cycles_per_wave_row']), '--waves-per-cu', '7'], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
 open('$O/r5_issue_mix.json', 'wb').write(out.stdout); open('$O/r5_issue_mix.txt', 'wb').write(out.stderr)
 print(out.stderr.decode()[-900:])
 PY

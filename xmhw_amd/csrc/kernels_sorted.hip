@@ -138,15 +138,22 @@ __device__ __forceinline__ void sorted_body(
     constexpr int HE = (YPS + 1) / 2 * 2;        // keys per lane, padded to an even count
     constexpr int HH = HE / 2;                   // sorted keys per lane after the exchange
     constexpr int KH = K / 2;                    // keys of the new list a lane ends with
-    constexpr int KW = K;                        // words per list and cell: the K keys, nothing else
+    // Two layouts of a list in LDS.  SENT (K <= 12: LDS holds 8 waves per CU either way, the registers' limit): word 0 =
+    // +inf, K keys, a last word 0 -- a window that reaches past an end of its list has its addresses clamped to these
+    // sentinels and reads the lowest key of its direction.  Without sentinels (K >= 14: LDS is what limits the waves) a
+    // list is its K keys and nothing else, and such a window is masked after the read: 10 % more instructions in the
+    // select for 7 waves per CU instead of 6 at K = 16 (8 / 7 at K = 14, 6 / 5 at K = 18).
+    constexpr bool SENT = K <= 12;
+    constexpr int KW = SENT ? K + 2 : K;         // words per list and cell
     constexpr int NTP = 2 * YPS;
     constexpr uint32_t LSTRIDE = 32 * 4;         // bytes between consecutive positions of a list
     constexpr uint32_t LBYTES = KW * LSTRIDE;    // bytes per list (32 cells)
     static_assert(K <= HE && K % 2 == 0, "a list stores an even number of keys, at most what a lane holds");
     // rows below list 0: where a window that reaches below it reads (and is masked).  LDS is handed out in 512-byte
     // pieces: 7 waves per CU leave a wave 23,040 bytes = 180 rows, 176 of them lists at K = 16
-    constexpr int PADROWS = 4;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[(R * KW + PADROWS) * 32];
+    constexpr int PADROWS = SENT ? 0 : 4;
+    constexpr int TAILROWS = SENT ? 2 : 0;       // SENT: the dummy list of lane 1's sixth slot, [+inf][0]
+    __shared__ __attribute__((aligned(16))) uint32_t lds[(R * KW + PADROWS + TAILROWS) * 32];
 
     const int lane = threadIdx.x & 63;
     const int sub = lane & 1;
@@ -164,11 +171,17 @@ __device__ __forceinline__ void sorted_body(
     const uint32_t* tab = table + sub;
 
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u32*)lds));
-    const uint32_t lcell = lds0 + PADROWS * LSTRIDE + static_cast<uint32_t>(cw) * 4u;      // key 0 of list 0 of this cell
-    // ---- LDS: every list empty (keys 0 = invalid).  No sentinels: a window that reaches past either end of its list
-    // is masked after the read (what it read there -- a neighbouring list, or nothing: an LDS read outside the
-    // few rows of padding -- is never looked at); (11 x K + 5) x 128 bytes per wave = 7 waves per CU at K = 16
-    for (int i = lane; i < (R * KW + PADROWS) * 32; i += 64) lds[i] = 0u;
+    // (word 0 of list 0 of this cell: its key 0, or the sentinel above it)
+    const uint32_t lcell = lds0 + PADROWS * LSTRIDE + static_cast<uint32_t>(cw) * 4u;
+    // ---- LDS: every list empty (keys 0 = invalid); SENT: the sentinels in place ------------------------------
+    for (int i = lane; i < (R * KW + PADROWS + TAILROWS) * 32; i += 64) {
+        uint32_t v = 0u;
+        if constexpr (SENT) {
+            const int row = i / 32;
+            v = (row < R * KW ? row % KW == 0 : row == R * KW) ? 0xFFFFFFFFu : 0u;
+        }
+        lds[i] = v;
+    }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 
@@ -182,7 +195,10 @@ __device__ __forceinline__ void sorted_body(
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
         const int g = sub * NL + j;
-        lbase[j] = lcell + static_cast<uint32_t>(g < R ? g : NL - 1) * LBYTES;      // (the dummy sits in the middle: see inb())
+        if constexpr (SENT)      // (the dummy: the two words behind the last list, its "key 0" is the lower sentinel)
+            lbase[j] = lcell + static_cast<uint32_t>(g < R ? g : R) * LBYTES + LSTRIDE;
+        else                     // (the dummy sits in the middle, never read past the allocation: see inb())
+            lbase[j] = lcell + static_cast<uint32_t>(g < R ? g : NL - 1) * LBYTES;
         lk[j] = g < R ? static_cast<uint32_t>(K) : 0u;
         P[j] = 0;
     }
@@ -198,6 +214,7 @@ __device__ __forceinline__ void sorted_body(
     const int32_t lds_first = static_cast<int32_t>(lcell - PADROWS * LSTRIDE);
     const int32_t lds_last = static_cast<int32_t>(lcell + static_cast<uint32_t>(R * KW - 1) * LSTRIDE);
     auto inb = [&](int j, int i, uint32_t addr) -> uint32_t {
+        if constexpr (SENT) return addr;
         if (j == 0 && i == 4) return static_cast<uint32_t>(max(static_cast<int32_t>(addr), lds_first));
         if (j == NL - 2) return static_cast<uint32_t>(min(static_cast<int32_t>(addr), lds_last));
         return addr;
@@ -421,7 +438,7 @@ __device__ __forceinline__ void sorted_body(
         const int m_sub = m >= NL ? 1 : 0;
         const int mj = __builtin_amdgcn_readfirstlane(m - m_sub * NL);
         const bool own_m = sub == m_sub;
-        const uint32_t base_m = lcell + static_cast<uint32_t>(m) * LBYTES;
+        const uint32_t base_m = lcell + static_cast<uint32_t>(m) * LBYTES + (SENT ? LSTRIDE : 0u);      // key 0 of list m
 #pragma unroll
         for (int i = 0; i < KH; ++i) lds_st(base_m + static_cast<uint32_t>(sub * KH + i) * LSTRIDE, u[i]);
         // what leaves: the evicted list's share of the top set, its valid keys, its sum
@@ -493,7 +510,7 @@ __device__ __forceinline__ void sorted_body(
         for (int j = 0; j < NL; ++j) {
             const uint32_t pj_ = P[j];
             const uint32_t in_ = lds_ld(inb(j, 0, lbase[j] + (pj_ - 1u) * LSTRIDE));  // (pj_ == 0: nothing inside, the read is ignored)
-            um = umin(um, pj_ != 0u ? in_ : 0xFFFFFFFFu);
+            um = umin(um, (SENT || pj_ != 0u) ? in_ : 0xFFFFFFFFu);      // (SENT: the upper sentinel is +inf)
         }
         um = umin(um, swp(um));
         // (per list, for this row's direction: the address the window starts from when the pointer is 0, and the constant
@@ -523,12 +540,21 @@ __device__ __forceinline__ void sorted_body(
 #pragma unroll
                 for (int j = 0; j < NL; ++j) {
                     const uint32_t pj_ = P[j];
-                    const uint32_t left = (pj_ ^ dir_s) + wleft[j];            // K - p (growing) or p (shrinking)
-                    wm[j] = 0xFFFFFFFFu << left;                                // (left <= 18)
                     const int32_t A0 = static_cast<int32_t>(wbase[j] + pj_ * LSTRIDE);
-                    ad[j][0] = inb(j, 0, static_cast<uint32_t>(A0));
+                    if constexpr (SENT) {
+                        const int32_t topj = static_cast<int32_t>(lbase[j] - LSTRIDE);
+                        const int32_t botj = static_cast<int32_t>(lbase[j] + lk[j] * LSTRIDE);
+                        wm[j] = 0;
+                        ad[j][0] = static_cast<uint32_t>(A0);
 #pragma unroll
-                    for (int i = 1; i < 5; ++i) ad[j][i] = inb(j, i, static_cast<uint32_t>(A0 + i * dstep));
+                        for (int i = 1; i < 5; ++i) ad[j][i] = static_cast<uint32_t>(med3i(A0 + i * dstep, topj, botj));
+                    } else {
+                        const uint32_t left = (pj_ ^ dir_s) + wleft[j];            // K - p (growing) or p (shrinking)
+                        wm[j] = 0xFFFFFFFFu << left;                                // (left <= 18)
+                        ad[j][0] = inb(j, 0, static_cast<uint32_t>(A0));
+#pragma unroll
+                        for (int i = 1; i < 5; ++i) ad[j][i] = inb(j, i, static_cast<uint32_t>(A0 + i * dstep));
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 uint32_t raw[NL][5];
@@ -539,11 +565,17 @@ __device__ __forceinline__ void sorted_body(
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < NL; ++j) {
-                    a[j][0] = xor_andn(raw[j][0], cm, bit_mask<0>(wm[j]));
-                    a[j][1] = xor_andn(raw[j][1], cm, bit_mask<1>(wm[j]));
-                    a[j][2] = xor_andn(raw[j][2], cm, bit_mask<2>(wm[j]));
-                    a[j][3] = xor_andn(raw[j][3], cm, bit_mask<3>(wm[j]));
-                    F = umax(F, xor_andn(raw[j][4], cm, bit_mask<4>(wm[j])));
+                    if constexpr (SENT) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a[j][i] = raw[j][i] ^ cm;
+                        F = umax(F, raw[j][4] ^ cm);
+                    } else {
+                        a[j][0] = xor_andn(raw[j][0], cm, bit_mask<0>(wm[j]));
+                        a[j][1] = xor_andn(raw[j][1], cm, bit_mask<1>(wm[j]));
+                        a[j][2] = xor_andn(raw[j][2], cm, bit_mask<2>(wm[j]));
+                        a[j][3] = xor_andn(raw[j][3], cm, bit_mask<3>(wm[j]));
+                        F = umax(F, xor_andn(raw[j][4], cm, bit_mask<4>(wm[j])));
+                    }
                 }
             }
             // -- the lane's 16 largest of its 24, sorted: a tree of merges of sorted runs
@@ -667,7 +699,7 @@ __device__ __forceinline__ void sorted_body(
                 const uint32_t pj_ = P[j];
                 const uint32_t left = (pj_ ^ dir_s) + wleft[j];
                 const uint32_t hd = lds_ld(inb(j, 0, wbase[j] + pj_ * LSTRIDE)) ^ cm;
-                hx = umax(hx, left != 0u ? hd : 0u);
+                hx = umax(hx, (SENT || left != 0u) ? hd : 0u);
             }
             hx = umax(hx, swp(hx));
             TN = tn_ok ? TN : hx;
