@@ -144,6 +144,10 @@ __device__ __forceinline__ void sorted_body(
     // list is its K keys and nothing else, and such a window is masked after the read: 10 % more instructions in the
     // select for 7 waves per CU instead of 6 at K = 16 (8 / 7 at K = 14, 6 / 5 at K = 18).
     constexpr bool SENT = K <= 12;
+#ifndef XMHW_SERIAL_MAX
+#define XMHW_SERIAL_MAX 3
+#endif
+    constexpr uint32_t kSerialMax = XMHW_SERIAL_MAX;   // keys left (worst cell of the wave) up to which a row is finished key by key
     constexpr int KW = SENT ? K + 2 : K;         // words per list and cell
     constexpr int NTP = 2 * YPS;
     constexpr uint32_t LSTRIDE = 32 * 4;         // bytes between consecutive positions of a list
@@ -272,6 +276,8 @@ __device__ __forceinline__ void sorted_body(
         }
     };
     uint32_t st_rows = 0, st_iter = 0, st_flag = 0, st_steps = 0;
+    uint32_t st_serial = 0;
+    uint32_t st_more[4] = {0, 0, 0, 0};     // rounds after a row's first one by the keys still to move (wave maximum): <= 2, <= 4, <= 8, more
 
     // inputs of the epilogue of the row this lane finishes
     uint32_t e_alo = 0, e_ahi = 0, e_n = 0;
@@ -525,8 +531,64 @@ __device__ __forceinline__ void sorted_body(
         uint32_t TL = 0, TN = 0;       // complemented space: the last key that moved, the key that would move next
         bool flag = false;
         bool pending = true, tn_ok = true;
+        bool st_first_done = false;
+        bool first_round = true;
         while (__any(pending)) {
-            if constexpr (STATS) ++st_iter;
+            // After a row's first round two rounds in three have at most three keys left to move in their worst cell (an
+            // unsafe window, more than 15 steps): those are moved ONE BY ONE -- the largest of the 22 list heads, six reads and
+            // ~70 instructions a key instead of a round's 440.
+            if (!first_round && !__any(pending && rem > kSerialMax)) {
+                while (__any(pending)) {
+                    if constexpr (STATS) ++st_serial;
+                    uint32_t hd[NL];
+                    uint32_t hm = 0;
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) {
+                        const uint32_t pj_ = P[j];
+                        const uint32_t left = (pj_ ^ dir_s) + wleft[j];
+                        const uint32_t v = lds_ld(inb(j, 0, wbase[j] + pj_ * LSTRIDE)) ^ cm;
+                        hd[j] = (SENT || left != 0u) ? v : 0u;
+                        hm = umax(hm, hd[j]);
+                    }
+                    const uint32_t ho = swp(hm);
+                    const uint32_t cmax = umax(hm, ho);
+                    const bool act = pending;                           // (a pending cell has keys left to move)
+                    const bool dry_ = act && cmax == 0u;                // nothing left in the lists: give up (flag)
+                    const bool win = act && !dry_ && hm == cmax && (sub == 0 || ho != cmax);     // lane 0 first on a tie
+                    bool found = false;
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) {
+                        const bool sel = win && !found && hd[j] == cmax;
+                        P[j] = sel ? (grow ? P[j] + 1u : P[j] - 1u) : P[j];
+                        found = found || sel;
+                    }
+                    if (act && !dry_) {
+                        TL = cmax;
+                        rem -= 1u;
+                    }
+                    if (dry_) {
+                        flag = true;
+                        Ctop = grow ? Cs - rem : Cs + rem;
+                        rem = 0;
+                    }
+                    if (act) {
+                        tn_ok = dry_;                                   // (the key that would move next: from the heads, below)
+                        pending = !(dry_ || rem == 0u);
+                    }
+                }
+                break;
+            }
+            first_round = false;
+            if constexpr (STATS) {
+                ++st_iter;
+                if (s >= ch.begin && st_first_done) {
+                    uint32_t r_ = pending ? rem : 0u;
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) r_ = umax(r_, static_cast<uint32_t>(__shfl_xor(static_cast<int>(r_), off, 64)));
+                    ++st_more[r_ <= 2u ? 0 : r_ <= 4u ? 1 : r_ <= 8u ? 2 : 3];
+                }
+                st_first_done = true;
+            }
             const uint32_t d = umin(rem, 15u);
             // -- the W = 4 next keys of every own list, in the order they would move (addresses clamped to the
             //    list's sentinels: +inf above, 0 below -- both the LOWEST key in the cell's own order)
@@ -782,6 +844,8 @@ __device__ __forceinline__ void sorted_body(
         if (lane == 0) {
             atomicAdd(&stats[0], static_cast<unsigned long long>(st_rows));
             atomicAdd(&stats[1], static_cast<unsigned long long>(st_iter));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(&stats[4 + i], static_cast<unsigned long long>(st_more[i]));
 #pragma unroll
             for (int i = 0; i < 5; ++i) atomicAdd(&stats[8 + i], tacc[i]);
         }
