@@ -93,7 +93,11 @@ def check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks, msg=""):
     tr, sr, _ = _raw(dev, x, doy, pct / 100.0, cold, nchunks, ring2=-1)
     with np.errstate(invalid="ignore"):
         npt.assert_array_equal(tr, t0, err_msg=f"{msg} round-1 ring")
-        npt.assert_allclose(sr, s0, rtol=1e-12, atol=1e-300, equal_nan=True, err_msg=f"{msg} round-1 ring")
+        # (the round-1 kernel keeps a RUNNING total: a pool whose mean is exactly 0 can come out as a residue of the last
+        # bit of the samples' magnitude -- seed 71 case 9600: 5e-47 against 0 -- hence the absolute term, scaled to the data)
+        fin = np.abs(x[np.isfinite(x)])
+        npt.assert_allclose(sr, s0, rtol=1e-12, atol=1e-13 * float(fin.max()) if fin.size else 0.0, equal_nan=True,
+                            err_msg=f"{msg} round-1 ring")
     seen = set()
     for v in (None, 8, 10, 12, 20, 21, 22, 40):
         try:
