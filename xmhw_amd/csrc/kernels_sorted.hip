@@ -195,6 +195,9 @@ __device__ __forceinline__ void sorted_body(
     uint32_t lk[NL];                             // keys a list can hold: K (lane 1's sixth slot is a dummy: 0)
     // (per own list: its valid keys and the float64 sum of its samples as two words -- register tuples indexed by the
     // wave-uniform slot number through the index register, like P)
+    // (tuple[slot] with the wave-uniform slot number: six selects under scalar conditions, written out -- pick() / put()
+    // below; an eight-element vector indexed by a variable costs the compiler seven selects a read and sixteen a masked
+    // write, and a plain array indexed that way goes to scratch memory)
     V8 nvl, rs_lo, rs_hi;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
@@ -443,6 +446,21 @@ __device__ __forceinline__ void sorted_body(
         // ---- 3. the new list replaces the list in slot m ----------------------------------------------------------
         const int m_sub = m >= NL ? 1 : 0;
         const int mj = __builtin_amdgcn_readfirstlane(m - m_sub * NL);
+        // (the slot's conditions once, as lane masks the selects below share; kept opaque so that the chain of selects is not
+        // turned back into a load from an array with a variable index -- which would put the tuples into scratch memory)
+        bool is_slot[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            int mj_ = mj;
+            asm volatile("" : "+s"(mj_));
+            is_slot[j] = mj_ == j;
+        }
+        auto pick = [&](const V8& t) -> uint32_t {
+            uint32_t v = t[0];
+#pragma unroll
+            for (int j = 1; j < NL; ++j) v = is_slot[j] ? t[j] : v;
+            return v;
+        };
         const bool own_m = sub == m_sub;
         const uint32_t base_m = lcell + static_cast<uint32_t>(m) * LBYTES + (SENT ? LSTRIDE : 0u);      // key 0 of list m
 #pragma unroll
@@ -450,8 +468,8 @@ __device__ __forceinline__ void sorted_body(
         // what leaves: the evicted list's share of the top set, its valid keys, its sum
         uint32_t c_old = 0, nv_old = 0;
         {
-            const uint32_t Pm = P[mj];
-            const uint32_t nvm = nvl[mj];
+            const uint32_t Pm = pick(P);
+            const uint32_t nvm = pick(nvl);
             if (own_m) {
                 c_old = Pm;
                 nv_old = nvm;
@@ -474,13 +492,17 @@ __device__ __forceinline__ void sorted_body(
         din += swp(din);
         Ctop += c_new - c_old;
         n += nvin - nv_old;
-        P[mj] = own_m ? c_new : P[mj];
+        auto put = [&](V8& t, uint32_t x) {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) t[j] = (own_m && is_slot[j]) ? x : t[j];
+        };
+        put(P, c_new);
         if (own_m) truncmask = (truncmask & ~(1u << mj)) | ((nvin > static_cast<uint32_t>(K) ? 1u : 0u) << mj);
         {
             const uint64_t db = static_cast<uint64_t>(__double_as_longlong(din));
-            nvl[mj] = own_m ? nvin : nvl[mj];
-            rs_lo[mj] = own_m ? static_cast<uint32_t>(db) : rs_lo[mj];
-            rs_hi[mj] = own_m ? static_cast<uint32_t>(db >> 32) : rs_hi[mj];
+            put(nvl, nvin);
+            put(rs_lo, static_cast<uint32_t>(db));
+            put(rs_hi, static_cast<uint32_t>(db >> 32));
         }
         {
             // the pool's total: the 11 list sums added in slot order, every row (a running total would round differently
