@@ -534,11 +534,18 @@ __device__ __forceinline__ void sorted_body(
         const int32_t dstep = grow ? static_cast<int32_t>(LSTRIDE) : -static_cast<int32_t>(LSTRIDE);
         // min over the lists of the smallest key INSIDE the top set (the cells that move nowhere need both sides)
         uint32_t um = 0xFFFFFFFFu;
+        {
+            // (addresses, then the six reads back to back, then one wait -- as for the windows below)
+            uint32_t ua[NL], uv[NL];
 #pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const uint32_t pj_ = P[j];
-            const uint32_t in_ = lds_ld(inb(j, 0, lbase[j] + (pj_ - 1u) * LSTRIDE));  // (pj_ == 0: nothing inside, the read is ignored)
-            um = umin(um, (SENT || pj_ != 0u) ? in_ : 0xFFFFFFFFu);      // (SENT: the upper sentinel is +inf)
+            for (int j = 0; j < NL; ++j) ua[j] = inb(j, 0, lbase[j] + (P[j] - 1u) * LSTRIDE);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) uv[j] = lds_ld(ua[j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NL; ++j)      // (P == 0: nothing inside, the read is ignored; SENT: the upper sentinel is +inf)
+                um = umin(um, (SENT || P[j] != 0u) ? uv[j] : 0xFFFFFFFFu);
         }
         um = umin(um, swp(um));
         // (per list, for this row's direction: the address the window starts from when the pointer is 0, and the constant
