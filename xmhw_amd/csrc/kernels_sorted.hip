@@ -6,21 +6,27 @@
 //
 //   * per step the 2 lanes of a cell sort the cell's new samples (a network in registers per lane, one bitonic
 //     exchange between the lanes) and write the K largest keys, descending, into the slot of the evicted list:
-//     lists[slot][1 + k][cell] in LDS, cell-minor, so that per-lane dynamic positions never meet on a bank; word 0 of a
-//     list is +inf, word K + 1 is 0 (an invalid key) -- sentinels;
-//   * per list a POINTER P_i = the position of its first key outside the TOP SET (the Cs largest keys of the pool,
+//     lists[slot][k][cell] in LDS, cell-minor, so that per-lane dynamic positions never meet on a bank.  Up to K = 12 a
+//     list also carries two sentinel words (+inf above its keys, 0 below); from K = 14 it is its keys and nothing else
+//     (7 instead of 6 waves per CU at K = 16): see SENT below;
+//   * per list a POINTER P_i = the number of its keys inside the TOP SET (the Cs largest keys of the pool,
 //     Cs = n - 1 - lo, lo = floor((n - 1) q)): order statistic lo of numpy's linear quantile is the largest key outside
 //     the top set (max over the lists of key[P_i]), lo + 1 the smallest inside (min of key[P_i - 1]);
 //   * a row changes the top set by the evicted list's share and the new list's (counted against the carried boundary
-//     value); the pointers are then WALKED one key at a time -- the list whose head is the largest key outside (the
-//     smallest inside) moves by one -- until the top set has Cs keys again: |c_new - c_evicted| steps, 4 on average.
-//   * `seas` = running float64 total +- per-list sums, as in kernels_ring3.hip.
+//     value); the pointers then move |c_new - c_evicted| keys (4 on average) in ROUNDS of a parallel merge-select: every
+//     lane reads the 4 next keys of each of its lists (+ a fifth that says how far the windows can be trusted), a tree
+//     of merges of sorted runs and one exchange between the lanes give the cell's 16 largest candidates, the d-th of
+//     them is the threshold every list counts its window against.  What one round cannot settle (an unsafe window,
+//     more than 15 keys) takes another round, or -- at most three keys left in the wave's worst cell -- is finished key
+//     by key from the 22 list heads;
+//   * `seas` = (sum of the 11 lists' float64 sums, added in slot order every row) / n: the same bits for every cut of
+//     the row axis.
 //
 // Everything is exact.  What can fail is the capacity of a list: a list whose K stored keys are all inside the top set
 // while it holds more valid keys than K (a steep seasonal slope puts up to ~20 of a list's 40 keys among the 44
-// largest of the pool).  Such cell-rows are FLAGGED in a bitmap and recomputed by clim_generic_flagged
-// (kernels_generic.hip); the list state stays consistent (the hidden keys are all below the stored ones) and the cell
-// carries on by itself once the boundary has moved back.
+// largest of the pool), with its last stored key above the key outside the top set.  Such cell-rows are FLAGGED in a
+// bitmap and recomputed (kernels_redo.hip); the list state stays consistent (the hidden keys are all below the stored
+// ones) and the cell carries on by itself once the boundary has moved back.
 //
 // The kernel runs on its OWN chunks and step-table rows (plan.cpp: sorted_plan): the row axis is cut wherever the set
 // of pooled tracks changes (a held step -- doy 60 --, the ends of partial years); inside a chunk every pooled track
@@ -121,8 +127,7 @@ typedef uint32_t V8 __attribute__((ext_vector_type(8)));
 
 // stats (STATS builds): [0] wave-rows, [1] walk iterations (what the wave pays), [2] flagged cell-rows, [3] walk steps
 // summed over cells, [8..15] shader-clock ticks per section (push, sort, bookkeeping, walk, epilogue)
-// (registers: LDS holds 6 waves per CU at K = 16 and more for shorter lists -- 8 at K = 12, 11 at K = 8: the shorter
-// records are asked to fit three waves per SIMD)
+// and [4..7] rounds after a row's first one by the keys still to move in the wave's worst cell (<= 2, <= 4, <= 8, more)
 // PACKED: the samples are int16 codes read in place (kernels.h: PackedI16, packed_src.h): a row's codes become the float32
 // samples the rest of the row works on -- float(code) * sf + of in mode 1, float(code) in modes 2 and 3 -- and in mode 2 the
 // epilogue decodes the two selected codes and the mean of the codes in float64.
