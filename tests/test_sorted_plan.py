@@ -85,3 +85,22 @@ def test_no_leap_year_in_the_record_is_one_chunk():
 
 def test_record_ending_on_feb_29():
     _check(_daily("1981-03-01", "2020-03-01"))
+
+
+@pytest.mark.parametrize("years,k,lds", [(20, 10, (11 * 12 + 2) * 128), (30, 12, (11 * 14 + 2) * 128), (36, 14, (11 * 14 + 4) * 128),
+                                         (40, 16, (11 * 16 + 4) * 128), (45, 18, (11 * 18 + 4) * 128)])
+def test_keys_per_list_and_lds_bytes_per_wave(years, k, lds):
+    """xmhw_plan_sorted_info: keys stored per row-list and the LDS a wave of 32 cells takes -- lists with two sentinel
+    words and a dummy list up to K = 12, bare lists and four padding rows above (23,040 bytes at K = 16: exactly what 7 waves
+    per CU leave a wave of the 160 KB, handed out in 512-byte pieces)"""
+    from xmhw_amd.device import Plan
+    import xmhw_amd.device as dev
+    time = np.arange("1980-01-01", f"{1980 + years}-01-01", dtype="datetime64[D]")
+    plan = Plan(ora.add_doy(time), 5)
+    try:
+        got_k, got_lds, pieces = dev.hip().plan_sorted_info(plan.handle, 1036800)
+        assert (got_k, got_lds) == (k, lds) and pieces >= 1
+        if k == 16:
+            assert (160 * 1024) // (512 * ((got_lds + 511) // 512)) == 7
+    finally:
+        plan.destroy()
