@@ -232,3 +232,46 @@ def test_threshold_from_a_packed_file_reads_the_codes_in_place(tmp_path, dev, mo
     assert calls == []
     npt.assert_array_equal(off["thresh"], ref["thresh"])
     npt.assert_array_equal(off["seas"], ref["seas"])
+
+
+def test_encode_land_mask_and_gather_on_codes(dev):
+    """xmhw_encode_i16 against numpy's rint / clip, xmhw_land_mask_i16 (all codes the fill code: land; anynans: any) for both
+    byte orders, xmhw_gather_cells_i16"""
+    h = dev.hip()
+    rng = np.random.default_rng(3)
+    T, C = 500, 70
+    x = (15 + 8 * rng.normal(size=(T, C))).astype(np.float32)
+    x[:, 3] = np.nan
+    x[10:20, 7] = np.nan
+    x[0, 0], x[1, 0] = 1e6, -1e6                       # clamped to the ends of the int16 range (without the lowest code)
+    d_x = dev.DeviceBuffer.from_array(x)
+    d_c = dev.DeviceBuffer(2 * T * C)
+    h.encode_i16(d_x.ptr, T, C, C, d_c.ptr, C, 0.01, 10.0, -32768, 0)
+    h.stream_sync(0)
+    codes = d_c.to_array((T, C), np.int16)
+    with np.errstate(invalid="ignore"):
+        want = np.clip(np.rint((x.astype(np.float64) - 10.0) / 0.01), -32767, 32767)
+    want = np.where(np.isnan(x), -32768, want).astype(np.int16)
+    npt.assert_array_equal(codes, want)
+    for big in (False, True):
+        stored = np.ascontiguousarray(codes.astype(">i2") if big else codes).view(np.int16)
+        d_s = dev.DeviceBuffer.from_array(stored)
+        d_m = dev.DeviceBuffer(C)
+        for anynans in (0, 1):
+            h.land_mask_i16(d_s.ptr, T, C, C, int(big), 1, -32768, anynans, d_m.ptr)
+            h.stream_sync(0)
+            keep = d_m.to_array((C,), np.uint8) != 0
+            miss = codes == -32768
+            npt.assert_array_equal(keep, ~miss.any(axis=0) if anynans else ~miss.all(axis=0))
+        h.land_mask_i16(d_s.ptr, T, C, C, int(big), 0, 0, 0, d_m.ptr)          # no fill code: every cell stays
+        h.stream_sync(0)
+        assert d_m.to_array((C,), np.uint8).all()
+        idx = np.array([1, 5, 6, 40, 69], dtype=np.int64)
+        d_i = dev.DeviceBuffer.from_array(idx)
+        d_g = dev.DeviceBuffer(2 * T * idx.size)
+        h.gather_cells(d_s.ptr, 2, T, C, d_i.ptr, idx.size, d_g.ptr, idx.size)
+        h.stream_sync(0)
+        npt.assert_array_equal(d_g.to_array((T, idx.size), np.int16), stored[:, idx])
+        for b in (d_s, d_m, d_i, d_g):
+            b.free()
+    d_x.free(); d_c.free()
