@@ -88,7 +88,8 @@ struct xmhw_plan {
     uint32_t* d_sflags_s = nullptr;
     xmhw::DevChunk* d_chunks_i = nullptr;
     int32_t nchunks_s = 0, nchunks_i = 0;
-    int64_t sorted_waves = -1;              // the grid width the sorted chunks were cut for
+    int64_t sorted_pieces = -1;             // the number of pieces the sorted chunks were cut into
+    int32_t sorted_built = 0;               // chunks in d_chunks_s (nchunks_s = that, or 0 while the plan is not sorted-usable)
     uint32_t* d_redo = nullptr;
     size_t redo_words = 0;
     // optional timing of the main kernel of every raw-climatology call (xmhw_plan_set_timing): a ring of event pairs
@@ -299,37 +300,68 @@ bool sorted_usable(const xmhw_plan* p) {
     return resolve_kernel(p, 4) == XMHW_KERNEL_RING;
 }
 
+// The sorted-list kernel's lists rely on LDS reads outside the workgroup's allocation returning 0 (kernels_sorted.hip).
+// Checked once per device of this process before the kernel is used there; a device that answers otherwise keeps the ring
+// kernels.  -1 = not probed yet, 1 = holds, 0 = does not.
+int sorted_device_ok() {
+    static std::mutex mu;
+    static int state[64];
+    static bool init = false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!init) { for (int& v : state) v = -1; init = true; }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (state[dev] >= 0) return state[dev];
+    uint32_t* d_bad = nullptr;
+    uint32_t bad = 1;
+    if (hipMalloc(&d_bad, sizeof(uint32_t)) != hipSuccess) return 0;
+    const bool ran = xmhw::sorted_lds_probe(d_bad, nullptr) == hipSuccess &&
+                     hipMemcpy(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d_bad);
+    if (!ran) return 0;          // (not cached: a transient failure is probed again)
+    state[dev] = bad == 0 ? 1 : 0;
+    return state[dev];
+}
+
 // tables, chunks and the redo bitmap of the sorted-list kernel (under the plan's lock)
 int upload_sorted(xmhw_plan* p, int64_t C) {
     const xmhw::Plan& h = p->host;
-    if (!sorted_usable(p)) { p->nchunks_s = 0; return XMHW_OK; }
+    if (!sorted_usable(p) || sorted_device_ok() != 1) { p->nchunks_s = 0; return XMHW_OK; }
     const int32_t yps = xmhw::sorted_pick_yps(h.w, h.ntracks);
     const int64_t waves = (C + 31) / 32;
-    if (!p->d_table_s || p->yps_s != yps || p->sorted_waves != waves) {
-        // the kernel's own chunks and table rows (plan.h: sorted_plan); a small grid is cut into more pieces so that it
-        // still fills the chip (6 waves per CU; every piece pays R - 1 warm-up rows)
+    // the kernel's own chunks and table rows (plan.h: sorted_plan); a small grid is cut into more pieces so that it still
+    // fills the chip (7 waves per CU; every piece pays R - 1 warm-up rows).  The tables depend on (tracks per lane, pieces)
+    // only: the slabs of one threshold() call -- a different cell count each -- share them.
+    const int64_t pieces = h.nchunks_req > 0 ? h.nchunks_req : (1536 + waves - 1) / std::max<int64_t>(waves, 1);
+    if (!p->d_table_s || p->yps_s != yps || p->sorted_pieces != pieces) {
         HIP_TRY(hipDeviceSynchronize());
         for (void** q : {reinterpret_cast<void**>(&p->d_table_s), reinterpret_cast<void**>(&p->d_sflags_s),
                          reinterpret_cast<void**>(&p->d_chunks_s), reinterpret_cast<void**>(&p->d_chunks_i)})
             if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
-        const int64_t pieces = h.nchunks_req > 0 ? h.nchunks_req : (1536 + waves - 1) / std::max<int64_t>(waves, 1);
         const xmhw::Plan::SortedPlan sp = h.sorted_plan(2 * yps, 24, pieces);
-        p->nchunks_s = 0;
+        p->sorted_built = 0;
         p->nchunks_i = 0;
         if (!sp.chunks.empty()) {
+            // longest chunk first: workgroups start in the order of their index, blockIdx.y = the chunk, so the launch ends
+            // with the short chunks (a 40-year daily plan: rows [60, 366), then [0, 59), then the Feb-29 row) instead of a
+            // tail of 316-row waves
             std::vector<xmhw::DevSortedChunk> cs(sp.chunks.size());
             for (size_t i = 0; i < cs.size(); ++i) cs[i] = {sp.chunks[i].warm_start, sp.chunks[i].begin, sp.chunks[i].end, sp.chunks[i].trow0};
+            std::stable_sort(cs.begin(), cs.end(), [](const xmhw::DevSortedChunk& a, const xmhw::DevSortedChunk& b) {
+                return a.end - a.warm_start > b.end - b.warm_start;
+            });
             HIP_TRY(hipMalloc(&p->d_table_s, sizeof(uint32_t) * sp.table.size()));
             HIP_TRY(hipMemcpy(p->d_table_s, sp.table.data(), sizeof(uint32_t) * sp.table.size(), hipMemcpyHostToDevice));
             HIP_TRY(hipMalloc(&p->d_sflags_s, sizeof(uint32_t) * sp.flags.size()));
             HIP_TRY(hipMemcpy(p->d_sflags_s, sp.flags.data(), sizeof(uint32_t) * sp.flags.size(), hipMemcpyHostToDevice));
             HIP_TRY(hipMalloc(&p->d_chunks_s, sizeof(xmhw::DevSortedChunk) * cs.size()));
             HIP_TRY(hipMemcpy(p->d_chunks_s, cs.data(), sizeof(xmhw::DevSortedChunk) * cs.size(), hipMemcpyHostToDevice));
-            p->nchunks_s = static_cast<int32_t>(cs.size());
+            p->sorted_built = static_cast<int32_t>(cs.size());
         }
         p->yps_s = yps;
-        p->sorted_waves = waves;
+        p->sorted_pieces = pieces;
     }
+    p->nchunks_s = p->sorted_built;
     const size_t words = static_cast<size_t>(h.D) * static_cast<size_t>(waves);
     if (p->nchunks_s > 0 && words > p->redo_words) {
         if (p->d_redo) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p->d_redo)); p->d_redo = nullptr; p->redo_words = 0; }

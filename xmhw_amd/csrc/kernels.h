@@ -83,6 +83,8 @@ hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
 // [row * redo_ld + (cell >> 5)] for launch_generic_flagged
 int32_t sorted_pick_yps(int32_t w, int32_t ntracks);     // tracks per lane, 0 if not instantiated
 int32_t sorted_pick_k(int32_t w, int32_t ntracks);       // keys stored per row-list, 0 if not instantiated
+// the device behaviour the kernel's rank-major lists rely on (an LDS read outside the allocation returns 0): *d_bad = 0 if it holds
+hipError_t sorted_lds_probe(uint32_t* d_bad, hipStream_t stream);
 hipError_t launch_sorted_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
                              const uint32_t* sflags, const DevSortedChunk* chunks, int32_t nchunks,
                              int32_t w, int32_t yps, int32_t ntracks, double q, int negate, double* thresh, double* seas,

@@ -5,10 +5,12 @@
 // and a row-list is evicted WHOLE when its slot is overwritten, so nothing is ever needed per key after its push:
 //
 //   * per step the 2 lanes of a cell sort the cell's new samples (a network in registers per lane, one bitonic
-//     exchange between the lanes) and write the K largest keys, descending, into the slot of the evicted list:
-//     lists[slot][k][cell] in LDS, cell-minor, so that per-lane dynamic positions never meet on a bank.  Up to K = 12 a
-//     list also carries two sentinel words (+inf above its keys, 0 below); from K = 14 it is its keys and nothing else
-//     (7 instead of 6 waves per CU at K = 16): see SENT below;
+//     exchange between the lanes) and write the K largest keys, descending, into the slot of the evicted list.  LDS is
+//     RANK-MAJOR (round 6): the key of rank r of the list in slot g sits in row r * R + g, a row = the 32 cells of the
+//     wave (cell-minor: per-lane dynamic positions never meet on a bank).  A window that reaches past the last rank of
+//     its list -- or above rank 0: the address wraps around -- leaves the workgroup's LDS allocation, and an LDS read
+//     outside the allocation returns 0 on gfx950 (tools/ubench_ldsoob.hip; the library checks it once per device
+//     before it uses this kernel): 0 is the "no key" value, so no list needs sentinels, clamps or masks;
 //   * per list a POINTER P_i = the number of its keys inside the TOP SET (the Cs largest keys of the pool,
 //     Cs = n - 1 - lo, lo = floor((n - 1) q)): order statistic lo of numpy's linear quantile is the largest key outside
 //     the top set (max over the lists of key[P_i]), lo + 1 the smallest inside (min of key[P_i - 1]);
@@ -70,23 +72,6 @@ __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ int32_t med3i(int32_t a, int32_t b, int32_t c) {
-    int32_t r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-// bit I of m as a whole-word mask (0 or all ones): one v_bfe_i32 (left to itself the compiler tests the bit and selects:
-// three instructions per key of a window)
-template <int I>
-__device__ __forceinline__ int32_t bit_mask(uint32_t m) {
-    int32_t r;
-    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(m), "n"(I));
-    return r;
-}
-// (a ^ b) & ~c in one v_bitop3 (truth table over bit index a * 4 + b * 2 + c: 0x14)
-__device__ __forceinline__ uint32_t xor_andn(uint32_t a, uint32_t b, int32_t c) {
-    return static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(static_cast<int32_t>(a), static_cast<int32_t>(b), c, 0x14));
-}
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
@@ -122,6 +107,9 @@ __device__ __forceinline__ uint32_t count_ge4(uint32_t a0, uint32_t a1, uint32_t
 }
 
 typedef uint32_t V8 __attribute__((ext_vector_type(8)));
+// LDS is handed out in pieces of 1,280 bytes on gfx950 (160 KB / 128; tools/ubench_ldsoob.hip: a read at the first byte
+// behind an allocation rounded up to that returns 0, the bytes between the declared size and that do not)
+constexpr int kLdsGranule = 1280;
 
 }  // namespace
 
@@ -143,26 +131,21 @@ __device__ __forceinline__ void sorted_body(
     constexpr int HE = (YPS + 1) / 2 * 2;        // keys per lane, padded to an even count
     constexpr int HH = HE / 2;                   // sorted keys per lane after the exchange
     constexpr int KH = K / 2;                    // keys of the new list a lane ends with
-    // Two layouts of a list in LDS.  SENT (K <= 12: LDS holds 8 waves per CU either way, the registers' limit): word 0 =
-    // +inf, K keys, a last word 0 -- a window that reaches past an end of its list has its addresses clamped to these
-    // sentinels and reads the lowest key of its direction.  Without sentinels (K >= 14: LDS is what limits the waves) a
-    // list is its K keys and nothing else, and such a window is masked after the read: 10 % more instructions in the
-    // select for 7 waves per CU instead of 6 at K = 16 (8 / 7 at K = 14, 6 / 5 at K = 18).
-    constexpr bool SENT = K <= 12;
 #ifndef XMHW_SERIAL_MAX
 #define XMHW_SERIAL_MAX 3
 #endif
     constexpr uint32_t kSerialMax = XMHW_SERIAL_MAX;   // keys left (worst cell of the wave) up to which a row is finished key by key
-    constexpr int KW = SENT ? K + 2 : K;         // words per list and cell
     constexpr int NTP = 2 * YPS;
-    constexpr uint32_t LSTRIDE = 32 * 4;         // bytes between consecutive positions of a list
-    constexpr uint32_t LBYTES = KW * LSTRIDE;    // bytes per list (32 cells)
+    // LDS, rank-major: row r * R + g = rank r of the list in slot g, a row = 32 cells.  The allocation is rounded up to the
+    // 1,280-byte piece LDS is handed out in on gfx950 (K = 16: 176 rows of lists + 4 rows that stay 0 = 23,040 bytes, 7
+    // waves per CU), so that the first byte behind it is the first byte the hardware answers with 0.
+    constexpr uint32_t LSTRIDE = 32 * 4;         // bytes between the lists of one rank
+    constexpr uint32_t RSTRIDE = R * LSTRIDE;    // bytes between consecutive ranks of a list
+    constexpr int LDS_BYTES = (R * K * static_cast<int>(LSTRIDE) + kLdsGranule - 1) / kLdsGranule * kLdsGranule;
     static_assert(K <= HE && K % 2 == 0, "a list stores an even number of keys, at most what a lane holds");
-    // rows below list 0: where a window that reaches below it reads (and is masked).  LDS is handed out in 512-byte
-    // pieces: 7 waves per CU leave a wave 23,040 bytes = 180 rows, 176 of them lists at K = 16
-    constexpr int PADROWS = SENT ? 0 : 4;
-    constexpr int TAILROWS = SENT ? 2 : 0;       // SENT: the dummy list of lane 1's sixth slot, [+inf][0]
-    __shared__ __attribute__((aligned(16))) uint32_t lds[(R * KW + PADROWS + TAILROWS) * 32];
+    static_assert(LDS_BYTES == 8960 || LDS_BYTES == 11520 || LDS_BYTES == 14080 || LDS_BYTES == 17920 || LDS_BYTES == 20480 ||
+                  LDS_BYTES == 23040 || LDS_BYTES == 25600, "sorted_lds_probe() checks these allocation sizes");
+    __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_BYTES / 4];
 
     const int lane = threadIdx.x & 63;
     const int sub = lane & 1;
@@ -180,24 +163,18 @@ __device__ __forceinline__ void sorted_body(
     const uint32_t* tab = table + sub;
 
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u32*)lds));
-    // (word 0 of list 0 of this cell: its key 0, or the sentinel above it)
-    const uint32_t lcell = lds0 + PADROWS * LSTRIDE + static_cast<uint32_t>(cw) * 4u;
-    // ---- LDS: every list empty (keys 0 = invalid); SENT: the sentinels in place ------------------------------
-    for (int i = lane; i < (R * KW + PADROWS + TAILROWS) * 32; i += 64) {
-        uint32_t v = 0u;
-        if constexpr (SENT) {
-            const int row = i / 32;
-            v = (row < R * KW ? row % KW == 0 : row == R * KW) ? 0xFFFFFFFFu : 0u;
-        }
-        lds[i] = v;
-    }
+    // (the array must start the workgroup's allocation: a window above rank 0 relies on its address wrapping around)
+    if (lds0 != 0u) __builtin_trap();
+    // (rank 0 of list 0 of this cell)
+    const uint32_t lcell = static_cast<uint32_t>(cw) * 4u;
+    // ---- LDS: every list empty (key 0 = no key), the rows behind the lists 0 for good -------------------------
+    for (int i = lane; i < LDS_BYTES / 4; i += 64) lds[i] = 0u;
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 
     // own list slots: global slot g = sub * NL + j; P[j] = the list's keys INSIDE the top set = index of the first key outside
     V8 P;
-    uint32_t lbase[NL];                          // address of the list's key 0
-    uint32_t lk[NL];                             // keys a list can hold: K (lane 1's sixth slot is a dummy: 0)
+    uint32_t lbase[NL];                          // address of the list's rank 0
     // (per own list: its valid keys and the float64 sum of its samples as two words -- register tuples indexed by the
     // wave-uniform slot number through the index register, like P)
     // (tuple[slot] with the wave-uniform slot number: six selects under scalar conditions, written out -- pick() / put()
@@ -207,11 +184,8 @@ __device__ __forceinline__ void sorted_body(
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
         const int g = sub * NL + j;
-        if constexpr (SENT)      // (the dummy: the two words behind the last list, its "key 0" is the lower sentinel)
-            lbase[j] = lcell + static_cast<uint32_t>(g < R ? g : R) * LBYTES + LSTRIDE;
-        else                     // (the dummy sits in the middle, never read past the allocation: see inb())
-            lbase[j] = lcell + static_cast<uint32_t>(g < R ? g : NL - 1) * LBYTES;
-        lk[j] = g < R ? static_cast<uint32_t>(K) : 0u;
+        // (lane 1's sixth slot is a dummy: every rank of it is far outside the allocation and reads 0)
+        lbase[j] = g < R ? lcell + static_cast<uint32_t>(g) * LSTRIDE : 0x40000000u + lcell;
         P[j] = 0;
     }
     P[6] = 0;
@@ -219,22 +193,13 @@ __device__ __forceinline__ void sorted_body(
     nvl = 0;
     rs_lo = 0;
     rs_hi = 0;
-    // Every LDS read stays inside the workgroup's allocation: a window reaches at most five positions past an end of its
-    // list, which is inside a neighbouring list (K >= 6) or, below list 0 (slot j = 0 of lane 0), inside the four padding
-    // rows -- the fifth position is clamped to the first of them; above list 10 (slot j = 4 of lane 1) there is no room
-    // for padding: that slot clamps its addresses to the cell's last word.
-    const int32_t lds_first = static_cast<int32_t>(lcell - PADROWS * LSTRIDE);
-    const int32_t lds_last = static_cast<int32_t>(lcell + static_cast<uint32_t>(R * KW - 1) * LSTRIDE);
-    auto inb = [&](int j, int i, uint32_t addr) -> uint32_t {
-        if constexpr (SENT) return addr;
-        if (j == 0 && i == 4) return static_cast<uint32_t>(max(static_cast<int32_t>(addr), lds_first));
-        if (j == NL - 2) return static_cast<uint32_t>(min(static_cast<int32_t>(addr), lds_last));
-        return addr;
-    };
-    static_assert(K >= 5, "a window of five positions must stay inside the neighbouring list");
+    static_assert(K >= 5, "a list holds a window");
     uint32_t truncmask = 0;
     // cell-level state, the same in both lanes
-    uint32_t Ctop = 0, n = 0, B = 0;
+    // (B = the carried boundary: the key outside the top set.  During a chunk's warm-up rows nothing is selected -- the lists
+    // are only built --, the top set stays empty and no new key counts as above the boundary; the chunk's first output row
+    // then grows the top set from nothing: four or five rounds instead of R - 1 rows of selection)
+    uint32_t Ctop = 0, n = 0, B = 0xFFFFFFFFu;
     double total = 0.0;
 
     // ---- sample addresses: a 64-bit pointer per track ------------------------------------------------------
@@ -293,6 +258,8 @@ __device__ __forceinline__ void sorted_body(
     uint32_t e_flag = 0;
 
     bool nan_mode = false;         // (wave-uniform) the last plain row had a NaN sample
+    uint32_t vi_n = 0xFFFFFFFFu, vi_lo = 0;      // the pool size the quantile position below was computed for
+    double vi_g = 0.0;
     // (the slot of a step is a function of the step itself, not of the chunk: with the fixed-order total below the
     // outputs do not depend on how the row axis is cut -- a grid split over N ranks is bit-identical to the whole)
     int m = ((ch.warm_start % R) + R) % R;
@@ -467,9 +434,10 @@ __device__ __forceinline__ void sorted_body(
             return v;
         };
         const bool own_m = sub == m_sub;
-        const uint32_t base_m = lcell + static_cast<uint32_t>(m) * LBYTES + (SENT ? LSTRIDE : 0u);      // key 0 of list m
+        // (this lane's first rank of list m: lane 0 holds ranks 0 .. K/2-1, lane 1 the rest)
+        const uint32_t base_m = lcell + static_cast<uint32_t>(m) * LSTRIDE + static_cast<uint32_t>(sub * KH) * RSTRIDE;
 #pragma unroll
-        for (int i = 0; i < KH; ++i) lds_st(base_m + static_cast<uint32_t>(sub * KH + i) * LSTRIDE, u[i]);
+        for (int i = 0; i < KH; ++i) lds_st(base_m + static_cast<uint32_t>(i) * RSTRIDE, u[i]);
         // what leaves: the evicted list's share of the top set, its valid keys, its sum
         uint32_t c_old = 0, nv_old = 0;
         {
@@ -522,55 +490,65 @@ __device__ __forceinline__ void sorted_body(
         tick(2);
 
         // ---- 4. move the pointers until the top set holds Cs keys: a parallel merge-select ------------------------
+        // (warm-up rows only build the lists: see B above)
+        uint32_t a_lo = 0, a_hi = 0;
+        double g = 0.0;
+        bool flag = false;
+        if (s >= ch.begin) {
+        // (n is the same for every cell on every row of gap-free data: the float64 position is redone only when some cell's
+        // count has changed)
+        if (__any(n != vi_n)) {
+            vi_n = n;
+            const uint32_t nn_ = n ? n : 1u;
+            const double vi = static_cast<double>(nn_ - 1) * q;
+            const double fl = floor(vi);
+            vi_g = vi - fl;
+            vi_lo = static_cast<uint32_t>(fl);
+        }
         const uint32_t nn = n ? n : 1u;
-        const double vi = static_cast<double>(nn - 1) * q;
-        const double fl = floor(vi);
-        const double g = vi - fl;
-        const uint32_t lo = static_cast<uint32_t>(fl);
+        g = vi_g;
+        const uint32_t lo = vi_lo;
         const bool need2 = lo + 1 < nn;
         const uint32_t Cs = n ? n - 1u - lo : 0u;
         // Direction of the cell: GROW (keys join the top set, largest first) or SHRINK (keys leave it, smallest first).
-        // Shrinking cells work on COMPLEMENTED keys, so that "the key that moves next" is the largest one for everybody.
+        // Shrinking cells work on NEGATED keys (2^32 - key), so that "the key that moves next" is the largest one for
+        // everybody and 0 -- no key: an invalid sample, a position outside the list -- stays the lowest for both.
         // (a cell whose top set is right already counts as growing by 0)
         const bool grow = Ctop <= Cs;
         uint32_t rem = grow ? Cs - Ctop : Ctop - Cs;
         const uint32_t steps0 = rem;
         const uint32_t cm = grow ? 0u : 0xFFFFFFFFu;
-        const int32_t dstep = grow ? static_cast<int32_t>(LSTRIDE) : -static_cast<int32_t>(LSTRIDE);
+        const uint32_t cneg = grow ? 0u : 1u;
+        auto cpl = [&](uint32_t v) -> uint32_t { return (v ^ cm) + cneg; };      // (its own inverse)
+        const int32_t dstep = grow ? static_cast<int32_t>(RSTRIDE) : -static_cast<int32_t>(RSTRIDE);
         // min over the lists of the smallest key INSIDE the top set (the cells that move nowhere need both sides)
         uint32_t um = 0xFFFFFFFFu;
         {
             // (addresses, then the six reads back to back, then one wait -- as for the windows below)
             uint32_t ua[NL], uv[NL];
 #pragma unroll
-            for (int j = 0; j < NL; ++j) ua[j] = inb(j, 0, lbase[j] + (P[j] - 1u) * LSTRIDE);
+            for (int j = 0; j < NL; ++j) ua[j] = lbase[j] + (P[j] - 1u) * RSTRIDE;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NL; ++j) uv[j] = lds_ld(ua[j]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < NL; ++j)      // (P == 0: nothing inside, the read is ignored; SENT: the upper sentinel is +inf)
-                um = umin(um, (SENT || P[j] != 0u) ? uv[j] : 0xFFFFFFFFu);
+            for (int j = 0; j < NL; ++j)      // (P == 0: nothing inside, the read left the allocation: 0 - 1 = the largest word)
+                um = umin(um, uv[j] - 1u);
         }
-        um = umin(um, swp(um));
-        // (per list, for this row's direction: the address the window starts from when the pointer is 0, and the constant
-        // that turns the pointer into the number of keys left in the window's direction -- K - p growing, p shrinking)
-        const uint32_t dir_s = grow ? 0xFFFFFFFFu : 0u;
-        uint32_t wbase[NL], wleft[NL];
+        um = umin(um, swp(um)) + 1u;
+        // (per list, for this row's direction: the address the window starts from when the pointer is 0)
+        uint32_t wbase[NL];
 #pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            wbase[j] = lbase[j] - (grow ? 0u : LSTRIDE);
-            wleft[j] = grow ? lk[j] + 1u : 0u;
-        }
-        uint32_t TL = 0, TN = 0;       // complemented space: the last key that moved, the key that would move next
-        bool flag = false;
+        for (int j = 0; j < NL; ++j) wbase[j] = lbase[j] - (grow ? 0u : RSTRIDE);
+        uint32_t TL = 0, TN = 0;       // negated space: the last key that moved, the key that would move next
         bool pending = true, tn_ok = true;
         bool st_first_done = false;
         bool first_round = true;
         while (__any(pending)) {
             // After a row's first round two rounds in three have at most three keys left to move in their worst cell (an
             // unsafe window, more than 15 steps): those are moved ONE BY ONE -- the largest of the 22 list heads, six reads and
-            // ~70 instructions a key instead of a round's 440.
+            // ~70 instructions a key instead of a round's 390.
             if (!first_round && !__any(pending && rem > kSerialMax)) {
                 while (__any(pending)) {
                     if constexpr (STATS) ++st_serial;
@@ -578,10 +556,7 @@ __device__ __forceinline__ void sorted_body(
                     uint32_t hm = 0;
 #pragma unroll
                     for (int j = 0; j < NL; ++j) {
-                        const uint32_t pj_ = P[j];
-                        const uint32_t left = (pj_ ^ dir_s) + wleft[j];
-                        const uint32_t v = lds_ld(inb(j, 0, wbase[j] + pj_ * LSTRIDE)) ^ cm;
-                        hd[j] = (SENT || left != 0u) ? v : 0u;
+                        hd[j] = cpl(lds_ld(wbase[j] + P[j] * RSTRIDE));
                         hm = umax(hm, hd[j]);
                     }
                     const uint32_t ho = swp(hm);
@@ -615,7 +590,7 @@ __device__ __forceinline__ void sorted_body(
             first_round = false;
             if constexpr (STATS) {
                 ++st_iter;
-                if (s >= ch.begin && st_first_done) {
+                if (st_first_done) {
                     uint32_t r_ = pending ? rem : 0u;
 #pragma unroll
                     for (int off = 32; off >= 1; off >>= 1) r_ = umax(r_, static_cast<uint32_t>(__shfl_xor(static_cast<int>(r_), off, 64)));
@@ -624,33 +599,19 @@ __device__ __forceinline__ void sorted_body(
                 st_first_done = true;
             }
             const uint32_t d = umin(rem, 15u);
-            // -- the W = 4 next keys of every own list, in the order they would move (addresses clamped to the
-            //    list's sentinels: +inf above, 0 below -- both the LOWEST key in the cell's own order)
+            // -- the W = 4 next keys of every own list, in the order they would move.  A position past the last rank of
+            //    the list, or above rank 0, is outside the allocation and reads 0 -- the LOWEST key in the cell's own order
             uint32_t a[NL][4];
             uint32_t F = 0;            // the largest FIFTH key: whatever the lists hold beyond the windows is not above it
             {
                 // (addresses first, then the 30 reads back to back, then ONE wait: left to itself the compiler
                 // interleaves them and waits for the LDS five times per list)
                 uint32_t ad[NL][5];
-                uint32_t wm[NL];           // bit i: key i of the window does NOT exist
 #pragma unroll
                 for (int j = 0; j < NL; ++j) {
-                    const uint32_t pj_ = P[j];
-                    const int32_t A0 = static_cast<int32_t>(wbase[j] + pj_ * LSTRIDE);
-                    if constexpr (SENT) {
-                        const int32_t topj = static_cast<int32_t>(lbase[j] - LSTRIDE);
-                        const int32_t botj = static_cast<int32_t>(lbase[j] + lk[j] * LSTRIDE);
-                        wm[j] = 0;
-                        ad[j][0] = static_cast<uint32_t>(A0);
+                    ad[j][0] = wbase[j] + P[j] * RSTRIDE;
 #pragma unroll
-                        for (int i = 1; i < 5; ++i) ad[j][i] = static_cast<uint32_t>(med3i(A0 + i * dstep, topj, botj));
-                    } else {
-                        const uint32_t left = (pj_ ^ dir_s) + wleft[j];            // K - p (growing) or p (shrinking)
-                        wm[j] = 0xFFFFFFFFu << left;                                // (left <= 18)
-                        ad[j][0] = inb(j, 0, static_cast<uint32_t>(A0));
-#pragma unroll
-                        for (int i = 1; i < 5; ++i) ad[j][i] = inb(j, i, static_cast<uint32_t>(A0 + i * dstep));
-                    }
+                    for (int i = 1; i < 5; ++i) ad[j][i] = ad[j][i - 1] + static_cast<uint32_t>(dstep);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 uint32_t raw[NL][5];
@@ -661,17 +622,9 @@ __device__ __forceinline__ void sorted_body(
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < NL; ++j) {
-                    if constexpr (SENT) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) a[j][i] = raw[j][i] ^ cm;
-                        F = umax(F, raw[j][4] ^ cm);
-                    } else {
-                        a[j][0] = xor_andn(raw[j][0], cm, bit_mask<0>(wm[j]));
-                        a[j][1] = xor_andn(raw[j][1], cm, bit_mask<1>(wm[j]));
-                        a[j][2] = xor_andn(raw[j][2], cm, bit_mask<2>(wm[j]));
-                        a[j][3] = xor_andn(raw[j][3], cm, bit_mask<3>(wm[j]));
-                        F = umax(F, xor_andn(raw[j][4], cm, bit_mask<4>(wm[j])));
-                    }
+                    for (int i = 0; i < 4; ++i) a[j][i] = cpl(raw[j][i]);
+                    F = umax(F, cpl(raw[j][4]));
                 }
             }
             // -- the lane's 16 largest of its 24, sorted: a tree of merges of sorted runs
@@ -791,19 +744,14 @@ __device__ __forceinline__ void sorted_body(
             // the key that would move next, from the lists' heads
             uint32_t hx = 0;
 #pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                const uint32_t pj_ = P[j];
-                const uint32_t left = (pj_ ^ dir_s) + wleft[j];
-                const uint32_t hd = lds_ld(inb(j, 0, wbase[j] + pj_ * LSTRIDE)) ^ cm;
-                hx = umax(hx, (SENT || left != 0u) ? hd : 0u);
-            }
+            for (int j = 0; j < NL; ++j) hx = umax(hx, cpl(lds_ld(wbase[j] + P[j] * RSTRIDE)));
             hx = umax(hx, swp(hx));
             TN = tn_ok ? TN : hx;
         }
         if (!flag) Ctop = Cs;
-        const uint32_t kl = TL ^ cm, kn = TN ^ cm;
-        const uint32_t a_lo = grow ? kn : kl;
-        uint32_t a_hi = grow ? (steps0 != 0u ? kl : um) : kn;
+        const uint32_t kl = cpl(TL), kn = cpl(TN);
+        a_lo = grow ? kn : kl;
+        a_hi = grow ? (steps0 != 0u ? kl : um) : kn;
         a_hi = need2 ? a_hi : a_lo;
         B = a_lo;
         {
@@ -817,7 +765,7 @@ __device__ __forceinline__ void sorted_body(
             if (__any(atb != 0u)) {
 #pragma unroll
                 for (int j = 0; j < NL; ++j) {
-                    const uint32_t Uj = lds_ld(lbase[j] + static_cast<uint32_t>(K - 1) * LSTRIDE);
+                    const uint32_t Uj = lds_ld(lbase[j] + static_cast<uint32_t>(K - 1) * RSTRIDE);
                     flag = flag || (((atb >> j) & 1u) && Uj > a_lo);
                 }
             }
@@ -828,13 +776,14 @@ __device__ __forceinline__ void sorted_body(
             const uint32_t fl_ = flag ? 1u : 0u;
             flag = (fl_ | swp(fl_)) != 0u;
         }
+        if constexpr (STATS) st_steps += (sub == 0 && cell_ok) ? steps0 : 0u;
+        }
         tick(3);
 
         // ---- 5. output ---------------------------------------------------------------------------------------------
         if (s >= ch.begin) {
             if constexpr (STATS) {
                 ++st_rows;
-                st_steps += (sub == 0 && cell_ok) ? steps0 : 0u;
                 st_flag += (sub == 0 && cell_ok && flag) ? 1u : 0u;
             }
             // The epilogue (key -> value, numpy's lerp, the float64 division, the stores) is the same ~60 instructions for
@@ -929,9 +878,13 @@ struct SortedEntry { int yps, k; SortedKernel fn, fn_stats; SortedKernelI16 fn_i
 // is a tenth of the tracks on average and reaches three to four times that on a steep seasonal slope), even, at most
 // what a lane holds.  9..48 tracks.
 const SortedEntry kSorted[] = {
+#ifdef XMHW_SORTED_ONLY      // (tools/isa_sorted.sh: one instantiation, for a quick look at the ISA)
+    XMHW_S(20, 16),
+#else
     XMHW_S(5, 6),   XMHW_S(6, 6),   XMHW_S(7, 8),   XMHW_S(8, 8),   XMHW_S(9, 10),  XMHW_S(10, 10), XMHW_S(11, 10),
     XMHW_S(12, 10), XMHW_S(13, 12), XMHW_S(14, 12), XMHW_S(15, 12), XMHW_S(16, 12), XMHW_S(17, 14), XMHW_S(18, 14),
     XMHW_S(19, 16), XMHW_S(20, 16), XMHW_S(21, 18), XMHW_S(22, 18), XMHW_S(23, 18), XMHW_S(24, 18),
+#endif
 };
 #undef XMHW_S
 #undef XMHW_SS
@@ -941,6 +894,54 @@ const SortedEntry* find_sorted(int32_t yps) {
     return nullptr;
 }
 }  // namespace
+
+// ---------------------------------------------------------------------------
+// What the rank-major lists rely on, checked on the device itself: a workgroup fills an allocation of BYTES with a
+// pattern and reads where the kernel's windows can end up -- the first row behind the allocation and the rows after it
+// (past the last rank of a list), the rows "above" address 0 (above rank 0: the address wraps around), the dummy list's
+// base.  Every such read must return 0.  Many workgroups per CU, so that the bytes behind an allocation belong to a
+// neighbour that has just written its own pattern.
+namespace {
+template <int BYTES>
+__global__ __launch_bounds__(64) void lds_outside_probe(uint32_t* __restrict__ bad) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[BYTES / 4];
+    for (int i = threadIdx.x; i < BYTES / 4; i += 64) lds[i] = 0x80000000u | (blockIdx.x << 16) | static_cast<uint32_t>(i);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u32*)lds));
+    uint32_t wrong = base != 0u ? 1u : 0u;
+    const uint32_t lane4 = threadIdx.x * 4u;
+    constexpr uint32_t RS = 11u * 128u;
+    for (uint32_t r = 0; r < 6; ++r) {
+        // (all 32 cells of a row, rows 0 .. 10 behind the allocation and r ranks further; the same above address 0)
+        for (uint32_t gofs = 0; gofs + 256u <= 10u * 128u; gofs += 256u) {      // (gofs + lane4 stays inside one rank's rows)
+            wrong |= lds_ld(static_cast<uint32_t>(BYTES) + r * RS + gofs + lane4);
+            wrong |= lds_ld(0u - (r + 1u) * RS + gofs + lane4);
+        }
+        wrong |= lds_ld(0x40000000u + r * RS + lane4);
+        wrong |= lds_ld(0x40000000u - (r + 1u) * RS + lane4);
+    }
+    // ... and a read inside the allocation returns what was stored (the probe would otherwise pass on a part that reads 0 everywhere)
+    if (lds_ld(static_cast<uint32_t>(BYTES) - 256u + lane4) != (0x80000000u | (blockIdx.x << 16) | static_cast<uint32_t>(BYTES / 4 - 64 + threadIdx.x)))
+        wrong = 1u;
+    if (wrong != 0u) atomicAdd(bad, 1u);
+}
+}  // namespace
+
+// 0 = every probe read 0 (the sorted-list kernel may run on this device), otherwise the number of lanes that did not
+hipError_t sorted_lds_probe(uint32_t* d_bad, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    // (the allocation sizes of the instantiations: K = 6 .. 18 keys per list, each rounded up to the 1,280-byte piece)
+    hipLaunchKernelGGL(lds_outside_probe<8960>, dim3(2048), dim3(64), 0, stream, d_bad);
+    hipLaunchKernelGGL(lds_outside_probe<11520>, dim3(2048), dim3(64), 0, stream, d_bad);
+    hipLaunchKernelGGL(lds_outside_probe<14080>, dim3(2048), dim3(64), 0, stream, d_bad);
+    hipLaunchKernelGGL(lds_outside_probe<17920>, dim3(2048), dim3(64), 0, stream, d_bad);
+    hipLaunchKernelGGL(lds_outside_probe<20480>, dim3(2048), dim3(64), 0, stream, d_bad);
+    hipLaunchKernelGGL(lds_outside_probe<23040>, dim3(2048), dim3(64), 0, stream, d_bad);
+    hipLaunchKernelGGL(lds_outside_probe<25600>, dim3(2048), dim3(64), 0, stream, d_bad);
+    return hipGetLastError();
+}
 
 int32_t sorted_pick_yps(int32_t w, int32_t ntracks) {
     if (w != 5) return 0;
