@@ -98,7 +98,8 @@ def main():
                              "walk_steps_per_cell_row": round(float(st[3]) / cellrows, 3),
                              "flagged_cell_rows_frac": float(st[2]) / cellrows,
                              "extra_rounds_per_wave_row_by_keys_left_le2_le4_le8_more": [round(float(x) / rows, 4) for x in st[4:8]],
-                             "ticks_per_wave_row_push_sort_book_walk_epilogue": [round(float(x) / rows, 1) for x in st[8:13]]}
+                             "ticks_per_wave_row_push_sort_book_walk_epilogue": [round(float(x) / rows, 1) for x in st[8:13]],
+                             "ticks_per_wave_row_wait_samples_convert_redo": [round(float(x) / rows, 1) for x in st[13:16]]}
         print(json.dumps(out), flush=True)
         for b in (th, se, sub):
             b.free()

@@ -90,15 +90,10 @@ struct xmhw_plan {
     int32_t nchunks_s = 0, nchunks_i = 0;
     int64_t sorted_pieces = -1;             // the number of pieces the sorted chunks were cut into
     int32_t sorted_built = 0;               // chunks in d_chunks_s (nchunks_s = that, or 0 while the plan is not sorted-usable)
-    uint32_t* d_redo = nullptr;
-    size_t redo_words = 0;
     // optional timing of the main kernel of every raw-climatology call (xmhw_plan_set_timing): a ring of event pairs
     bool timing = false;
     hipEvent_t tev[32] = {};
     uint64_t tcalls = 0;
-    unsigned long long* d_redo_list = nullptr;   // (row, cell) entries of the flagged cell-rows + their counter
-    uint32_t* d_redo_count = nullptr;
-    uint32_t redo_cap = 0;
 
     ~xmhw_plan() {
         if (d_stats) (void)hipFree(d_stats);
@@ -107,9 +102,6 @@ struct xmhw_plan {
         if (d_chunks_s) (void)hipFree(d_chunks_s);
         if (d_sflags_s) (void)hipFree(d_sflags_s);
         if (d_chunks_i) (void)hipFree(d_chunks_i);
-        if (d_redo) (void)hipFree(d_redo);
-        if (d_redo_list) (void)hipFree(d_redo_list);
-        if (d_redo_count) (void)hipFree(d_redo_count);
         if (d_narrow_flag) (void)hipFree(d_narrow_flag);
         if (d_tablex) (void)hipFree(d_tablex);
         if (d_table) (void)hipFree(d_table);
@@ -323,7 +315,7 @@ int sorted_device_ok() {
     return state[dev];
 }
 
-// tables, chunks and the redo bitmap of the sorted-list kernel (under the plan's lock)
+// tables and chunks of the sorted-list kernel (under the plan's lock)
 int upload_sorted(xmhw_plan* p, int64_t C) {
     const xmhw::Plan& h = p->host;
     if (!sorted_usable(p) || sorted_device_ok() != 1) { p->nchunks_s = 0; return XMHW_OK; }
@@ -362,24 +354,6 @@ int upload_sorted(xmhw_plan* p, int64_t C) {
         p->sorted_pieces = pieces;
     }
     p->nchunks_s = p->sorted_built;
-    const size_t words = static_cast<size_t>(h.D) * static_cast<size_t>(waves);
-    if (p->nchunks_s > 0 && words > p->redo_words) {
-        if (p->d_redo) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p->d_redo)); p->d_redo = nullptr; p->redo_words = 0; }
-        HIP_TRY(hipMalloc(&p->d_redo, sizeof(uint32_t) * words));
-        p->redo_words = words;
-    }
-    if (p->nchunks_s > 0) {
-        // the work list of the flagged cell-rows: one entry per 16 cell-rows (the sorted kernel flags well under 0.1 %
-        // of them on SST-like data; what does not fit goes the slow way, kernels_redo.hip)
-        if (!p->d_redo_count) HIP_TRY(hipMalloc(&p->d_redo_count, sizeof(uint32_t)));
-        const size_t want = std::max<size_t>(4096, static_cast<size_t>(h.D) * static_cast<size_t>(C) / 16);
-        const uint32_t cap = static_cast<uint32_t>(std::min<size_t>(want, size_t(1) << 28));
-        if (cap > p->redo_cap) {
-            if (p->d_redo_list) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(p->d_redo_list)); p->d_redo_list = nullptr; p->redo_cap = 0; }
-            HIP_TRY(hipMalloc(&p->d_redo_list, sizeof(unsigned long long) * cap));
-            p->redo_cap = cap;
-        }
-    }
     return XMHW_OK;
 }
 
@@ -493,7 +467,6 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
             const int32_t rn = sorted ? plan->nchunks_i : plan->nchunks;
             unsigned long long* rstats = sorted ? nullptr : plan->d_stats;
             e = hipSuccess;
-            const int64_t redo_ld = (C + 31) / 32;
             hipEvent_t t0 = nullptr, t1 = nullptr;
             if (plan->timing) {
                 const int slot = static_cast<int>(plan->tcalls % 16);
@@ -504,13 +477,11 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
                 plan->tcalls++;
             }
             if (sorted) {
-                e = hipMemsetAsync(plan->d_redo, 0, sizeof(uint32_t) * static_cast<size_t>(h.D) * static_cast<size_t>(redo_ld), st);
-                if (e == hipSuccess && t0) e = hipEventRecord(t0, st);
+                if (t0) e = hipEventRecord(t0, st);
                 if (e == hipSuccess)
                     e = xmhw::launch_sorted_f32(reinterpret_cast<const float*>(ts), C, ld, h.T, plan->d_table_s,
                                                 plan->d_sflags_s, plan->d_chunks_s, plan->nchunks_s, h.w,
-                                                plan->yps_s, h.ntracks, q, negate, thresh, seas, ldo, plan->d_redo, redo_ld,
-                                                st, plan->d_stats);
+                                                plan->yps_s, h.ntracks, q, negate, thresh, seas, ldo, st, plan->d_stats);
                 if (e == hipSuccess && t1) e = hipEventRecord(t1, st);
             } else if (t0) {
                 e = hipEventRecord(t0, st);
@@ -527,12 +498,6 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
                                       h.step_min, rchunks, rn, h.w, plan->yps, plan->subs, q,
                                       negate, thresh, seas, ldo, st, rstats);
             if (e == hipSuccess && !sorted && t1) e = hipEventRecord(t1, st);
-            // (XMHW_SORTED_NOREDO=1: timing experiments only -- flagged cell-rows keep the sorted kernel's own answer)
-            static const bool noredo = [] { const char* v = std::getenv("XMHW_SORTED_NOREDO"); return v && v[0] == '1'; }();
-            if (e == hipSuccess && sorted && !noredo)
-                e = xmhw::launch_redo(reinterpret_cast<const float*>(ts), h.T, C, ld, plan->d_row_ptr, plan->d_centres, h.D,
-                                      h.w, q, negate, thresh, seas, ldo, plan->d_redo, redo_ld, plan->d_redo_list,
-                                      plan->d_redo_count, plan->redo_cap, st);
         } else {
             // float64 input: if every sample is float32-representable (decoded int16 / float32
             // archives) the float32 kernel gives the same pools at 2.7x the rate.  All decisions are
@@ -1451,7 +1416,6 @@ int xmhw_clim_raw_i16(xmhw_plan* plan, const int16_t* codes, int64_t C, int64_t 
     pk.key_neg = kneg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const xmhw::Plan& h = plan->host;
-    const int64_t redo_ld = (C + 31) / 32;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (plan->timing) {
         const int slot = static_cast<int>(plan->tcalls % 16);
@@ -1461,15 +1425,12 @@ int xmhw_clim_raw_i16(xmhw_plan* plan, const int16_t* codes, int64_t C, int64_t 
         t1 = plan->tev[2 * slot + 1];
         plan->tcalls++;
     }
-    hipError_t e = hipMemsetAsync(plan->d_redo, 0, sizeof(uint32_t) * static_cast<size_t>(h.D) * static_cast<size_t>(redo_ld), st);
-    if (e == hipSuccess && t0) e = hipEventRecord(t0, st);
+    hipError_t e = hipSuccess;
+    if (t0) e = hipEventRecord(t0, st);
     if (e == hipSuccess)
         e = xmhw::launch_sorted_i16(codes, pk, C, ld, h.T, plan->d_table_s, plan->d_sflags_s, plan->d_chunks_s, plan->nchunks_s,
-                                    h.w, plan->yps_s, h.ntracks, q, kneg, thresh, seas, ldo, plan->d_redo, redo_ld, st);
+                                    h.w, plan->yps_s, h.ntracks, q, kneg, thresh, seas, ldo, st);
     if (e == hipSuccess && t1) e = hipEventRecord(t1, st);
-    if (e == hipSuccess)
-        e = xmhw::launch_redo_packed(codes, pk, h.T, C, ld, plan->d_row_ptr, plan->d_centres, h.D, h.w, q, kneg, thresh, seas,
-                                     ldo, plan->d_redo, redo_ld, plan->d_redo_list, plan->d_redo_count, plan->redo_cap, st);
     if (e != hipSuccess) return hip_fail(e, "packed climatology launch");
     return XMHW_OK;
 }

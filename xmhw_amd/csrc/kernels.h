@@ -78,9 +78,9 @@ hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
                             double* thresh, double* seas, int64_t ldo, hipStream_t stream,
                             unsigned long long* stats = nullptr);
 
-// fifth generation (kernels_sorted.hip): sorted row-lists in LDS + a pointer walk; 2 lanes per cell, w = 5, float32,
-// on its own chunks and table rows (plan.h: sorted_plan); cell-rows it cannot settle are flagged in redo_bits
-// [row * redo_ld + (cell >> 5)] for launch_generic_flagged
+// fifth generation (kernels_sorted.hip): sorted row-lists in LDS + a parallel merge-select; 2 lanes per cell, w = 5,
+// float32 (or int16 codes read in place), on its own chunks and table rows (plan.h: sorted_plan).  A cell-row the select
+// cannot settle (a row-list too short for it) is recomputed exactly inside the kernel, by the whole wave, from the samples.
 int32_t sorted_pick_yps(int32_t w, int32_t ntracks);     // tracks per lane, 0 if not instantiated
 int32_t sorted_pick_k(int32_t w, int32_t ntracks);       // keys stored per row-list, 0 if not instantiated
 // the device behaviour the kernel's rank-major lists rely on (an LDS read outside the allocation returns 0): *d_bad = 0 if it holds
@@ -88,33 +88,12 @@ hipError_t sorted_lds_probe(uint32_t* d_bad, hipStream_t stream);
 hipError_t launch_sorted_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
                              const uint32_t* sflags, const DevSortedChunk* chunks, int32_t nchunks,
                              int32_t w, int32_t yps, int32_t ntracks, double q, int negate, double* thresh, double* seas,
-                             int64_t ldo, uint32_t* redo_bits, int64_t redo_ld, hipStream_t stream,
-                             unsigned long long* stats = nullptr);
-template <typename T>
-hipError_t launch_generic_flagged(const T* ts, int64_t Tn, int64_t C, int64_t ld, const int32_t* row_ptr,
-                                  const int32_t* centres, int32_t row0, int32_t nrows, int32_t w, double q, int negate,
-                                  double* thresh, double* seas, int64_t ldo, const uint32_t* bits, int64_t ldb,
-                                  hipStream_t stream);
-
-// the cell-rows flagged in `bits` recomputed exactly (kernels_redo.hip): work list (cap entries) + counter are scratch
-hipError_t launch_redo(const float* ts, int64_t Tn, int64_t C, int64_t ld, const int32_t* row_ptr, const int32_t* centres,
-                       int32_t D, int32_t w, double q, int negate, double* thresh, double* seas, int64_t ldo,
-                       uint32_t* bits, int64_t ldb, unsigned long long* list, uint32_t* count, uint32_t cap,
-                       hipStream_t stream);
-
-hipError_t launch_redo_packed(const int16_t* codes, const PackedI16& pk, int64_t Tn, int64_t C, int64_t ld,
-                              const int32_t* row_ptr, const int32_t* centres, int32_t D, int32_t w, double q, int negate,
-                              double* thresh, double* seas, int64_t ldo, uint32_t* bits, int64_t ldb,
-                              unsigned long long* list, uint32_t* count, uint32_t cap, hipStream_t stream);
-hipError_t launch_generic_flagged_packed(const int16_t* codes, const PackedI16& pk, int64_t Tn, int64_t C, int64_t ld,
-                                         const int32_t* row_ptr, const int32_t* centres, int32_t nrows, int32_t w, double q,
-                                         int negate, double* thresh, double* seas, int64_t ldo, const uint32_t* bits,
-                                         int64_t ldb, hipStream_t stream);
+                             int64_t ldo, hipStream_t stream, unsigned long long* stats = nullptr);
 // the sorted-list kernel on int16 codes (instantiated for the same records as launch_sorted_f32)
 hipError_t launch_sorted_i16(const int16_t* codes, const PackedI16& pk, int64_t C, int64_t ld, int64_t Tn,
                              const uint32_t* table, const uint32_t* sflags, const DevSortedChunk* chunks, int32_t nchunks,
                              int32_t w, int32_t yps, int32_t ntracks, double q, int negate, double* thresh, double* seas,
-                             int64_t ldo, uint32_t* redo_bits, int64_t redo_ld, hipStream_t stream);
+                             int64_t ldo, hipStream_t stream);
 
 // fourth-generation float32 ring kernel (kernels_ring4.hip): a windowed key store in LDS instead of histogram + band
 // compaction; same lane layouts and step tables as the third generation (ring2 variants 30 / 31 / 32 = 8 / 4 / 2 lanes)

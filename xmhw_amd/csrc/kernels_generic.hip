@@ -109,33 +109,6 @@ __global__ __launch_bounds__(256) void clim_generic(const T* __restrict__ ts, in
     seas[static_cast<int64_t>(row) * ldo + c] = se;
 }
 
-// The same for the cell-rows still FLAGGED in the sorted-list kernel's bitmap after kernels_redo.hip has taken what
-// fits its work list: bits[row * ldb + (c >> 5)] bit (c & 31).  Thread per bitmap WORD (the bitmap is nearly always
-// empty by now: the launch costs one read of it); a thread walks the set bits of its word one cell-row after the other.
-template <typename Src>
-__global__ __launch_bounds__(256) void clim_generic_flagged(Src src, int64_t Tn, int64_t C,
-                                                            int64_t ld, const int32_t* __restrict__ row_ptr,
-                                                            const int32_t* __restrict__ centres, int32_t w,
-                                                            double q, int negate, double* __restrict__ thresh,
-                                                            double* __restrict__ seas, int64_t ldo,
-                                                            const uint32_t* __restrict__ bits, int64_t ldb,
-                                                            int64_t nwords) {
-    const int64_t wi = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (wi >= nwords) return;
-    uint32_t word = bits[wi];
-    const int32_t row = static_cast<int32_t>(wi / ldb);
-    const int64_t c0 = (wi % ldb) * 32;
-    while (word != 0u) {
-        const int64_t c = c0 + __builtin_ctz(word);
-        word &= word - 1u;
-        if (c >= C) break;
-        double th, se;
-        generic_cell_row(src, c, Tn, ld, row_ptr, centres, row, w, q, negate, th, se);
-        thresh[static_cast<int64_t>(row) * ldo + c] = th;
-        seas[static_cast<int64_t>(row) * ldo + c] = se;
-    }
-}
-
 template <typename T>
 hipError_t launch_generic(const T* ts, int64_t Tn, int64_t C, int64_t ld, const int32_t* row_ptr,
                           const int32_t* centres, int32_t D, int32_t w, double q, int negate,
@@ -147,31 +120,6 @@ hipError_t launch_generic(const T* ts, int64_t Tn, int64_t C, int64_t ld, const 
                        q, negate, thresh, seas, ldo, run_flag);
     return hipGetLastError();
 }
-template <typename T>
-hipError_t launch_generic_flagged(const T* ts, int64_t Tn, int64_t C, int64_t ld, const int32_t* row_ptr,
-                                  const int32_t* centres, int32_t row0, int32_t nrows, int32_t w, double q, int negate,
-                                  double* thresh, double* seas, int64_t ldo, const uint32_t* bits, int64_t ldb,
-                                  hipStream_t stream) {
-    if (C <= 0 || nrows <= 0) return hipSuccess;
-    (void)row0;      // (the bitmap covers rows [0, nrows))
-    const int64_t nwords = static_cast<int64_t>(nrows) * ldb;
-    hipLaunchKernelGGL(clim_generic_flagged<PlainSrc<T>>, dim3(static_cast<unsigned>((nwords + 255) / 256)), dim3(256), 0, stream,
-                       PlainSrc<T>{ts}, Tn, C, ld, row_ptr, centres, w, q, negate, thresh, seas, ldo, bits, ldb, nwords);
-    return hipGetLastError();
-}
-hipError_t launch_generic_flagged_packed(const int16_t* codes, const PackedI16& pk, int64_t Tn, int64_t C, int64_t ld,
-                                         const int32_t* row_ptr, const int32_t* centres, int32_t nrows, int32_t w, double q,
-                                         int negate, double* thresh, double* seas, int64_t ldo, const uint32_t* bits,
-                                         int64_t ldb, hipStream_t stream) {
-    if (C <= 0 || nrows <= 0) return hipSuccess;
-    const int64_t nwords = static_cast<int64_t>(nrows) * ldb;
-    hipLaunchKernelGGL(clim_generic_flagged<PackedSrc>, dim3(static_cast<unsigned>((nwords + 255) / 256)), dim3(256), 0, stream,
-                       PackedSrc{codes, pk}, Tn, C, ld, row_ptr, centres, w, q, negate, thresh, seas, ldo, bits, ldb, nwords);
-    return hipGetLastError();
-}
-template hipError_t launch_generic_flagged<float>(const float*, int64_t, int64_t, int64_t, const int32_t*,
-                                                  const int32_t*, int32_t, int32_t, int32_t, double, int, double*,
-                                                  double*, int64_t, const uint32_t*, int64_t, hipStream_t);
 template hipError_t launch_generic<float>(const float*, int64_t, int64_t, int64_t, const int32_t*,
                                           const int32_t*, int32_t, int32_t, double, int, double*,
                                           double*, int64_t, hipStream_t, const uint32_t*);

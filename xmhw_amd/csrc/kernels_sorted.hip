@@ -26,9 +26,10 @@
 //
 // Everything is exact.  What can fail is the capacity of a list: a list whose K stored keys are all inside the top set
 // while it holds more valid keys than K (a steep seasonal slope puts up to ~20 of a list's 40 keys among the 44
-// largest of the pool), with its last stored key above the key outside the top set.  Such cell-rows are FLAGGED in a
-// bitmap and recomputed (kernels_redo.hip); the list state stays consistent (the hidden keys are all below the stored
-// ones) and the cell carries on by itself once the boundary has moved back.
+// largest of the pool), with its last stored key above the key outside the top set.  Such a cell-row is recomputed on the
+// spot, by the whole wave, from the cell's samples (pool_order_stats below: exact for any pool); the list state stays
+// consistent (the hidden keys are all below the stored ones) and the cell carries on by itself once the boundary has
+// moved back.
 //
 // The kernel runs on its OWN chunks and step-table rows (plan.cpp: sorted_plan): the row axis is cut wherever the set
 // of pooled tracks changes (a held step -- doy 60 --, the ends of partial years); inside a chunk every pooled track
@@ -111,10 +112,109 @@ typedef uint32_t V8 __attribute__((ext_vector_type(8)));
 // behind an allocation rounded up to that returns 0, the bytes between the declared size and that do not)
 constexpr int kLdsGranule = 1280;
 
+
+// ---- a flagged cell-row, recomputed by the whole wave from the samples themselves (round 6) ----------------------------
+// The select above can fail on one cell of the wave (a row-list too short for the row).  Instead of leaving the cell-row to
+// a second kernel (rounds 5: a bitmap, a work list, 11.6 ns per flagged cell-row) the wave stops for it: the 64 lanes load
+// the cell's pool -- the R last table rows of its chunk x the tracks: the samples the wave itself read over the last R
+// rows, L2 / Infinity-Cache hits --, key them as the main path does and find order statistics lo and lo + 1 by stepping
+// from the select's own answer (wrong, but a few ranks away), key to neighbouring key, with wave-wide counts (ballot +
+// popcount: every count and every decision is scalar).  Exact for any pool; what it costs is two memory latencies and
+// ~300 instructions per flagged cell-row, and only waves that have one pay it.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = umin(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(-1, static_cast<int>(v), 0xB1, 0xF, 0xF, false)));    // quad_perm [1,0,3,2]
+    v = umin(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(-1, static_cast<int>(v), 0x4E, 0xF, 0xF, false)));    // quad_perm [2,3,0,1]
+    v = umin(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(-1, static_cast<int>(v), 0x141, 0xF, 0xF, false)));   // row_half_mirror
+    v = umin(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(-1, static_cast<int>(v), 0x140, 0xF, 0xF, false)));   // row_mirror
+    const uint32_t a = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 0));
+    const uint32_t b = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 16));
+    const uint32_t c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 32));
+    const uint32_t d = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 48));
+    return umin(umin(a, b), umin(c, d));
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
+
+// keys: KPL per lane, 0 = no key.  n valid keys, lo = floor((n - 1) q) (ascending order statistic), guess = a key near it
+// (0: none).  Returns the keys of order statistics lo and min(lo + 1, n - 1) -- wave-uniform.
+template <int KPL>
+__device__ __forceinline__ void pool_order_stats(const uint32_t (&key)[KPL], uint32_t n, uint32_t lo, uint32_t guess,
+                                                 uint32_t& out_lo, uint32_t& out_hi) {
+    auto count_lt = [&](uint32_t v) -> uint32_t {       // valid keys below v
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i)
+            cnt += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(key[i] != 0u && key[i] < v)));
+        return cnt;
+    };
+    auto count_eq = [&](uint32_t v) -> uint32_t {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i)
+            cnt += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(key[i] == v)));
+        return cnt;
+    };
+    auto next_above = [&](uint32_t v) -> uint32_t {     // the smallest key above v (all ones if none)
+        uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) m = (key[i] > v && key[i] < m) ? key[i] : m;
+        return wave_min_u32(m);
+    };
+    auto next_below = [&](uint32_t v) -> uint32_t {     // the largest valid key below v (0 if none)
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) m = (key[i] < v && key[i] > m) ? key[i] : m;
+        return wave_max_u32(m);
+    };
+    uint32_t v = guess;
+    bool found = false;
+    uint32_t cl = 0, ev = 0;                            // keys below v, keys equal to v
+    if (v != 0u) {
+        cl = count_lt(v);
+        ev = count_eq(v);
+        for (int it = 0; it < 32 && !found; ++it) {
+            if (cl <= lo && lo < cl + ev) {
+                found = true;
+            } else if (lo < cl) {
+                v = next_below(v);
+                if (v == 0u) break;
+                ev = count_eq(v);
+                cl -= ev;
+            } else {
+                const uint32_t nv = next_above(v);
+                if (nv == 0xFFFFFFFFu) break;
+                cl += ev;
+                v = nv;
+                ev = count_eq(v);
+            }
+        }
+    }
+    if (!found) {
+        // the whole key, bit by bit: the largest v with #{valid keys < v} <= lo   (key 0 = no key: (0 - 1) wraps high)
+        v = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = v | (1u << bit);
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int i = 0; i < KPL; ++i)
+                cnt += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(key[i] - 1u < cand - 1u)));
+            if (cnt <= lo) v = cand;
+        }
+        cl = count_lt(v);
+        ev = count_eq(v);
+    }
+    // v = the key of a[lo]; a[lo + 1]: v again if it is duplicated past lo, else the smallest key above v
+    uint32_t vhi = v;
+    if (lo + 1 < n && lo + 1 >= cl + ev) vhi = next_above(v);
+    out_lo = v;
+    out_hi = vhi;
+}
+
 }  // namespace
 
 // stats (STATS builds): [0] wave-rows, [1] walk iterations (what the wave pays), [2] flagged cell-rows, [3] walk steps
 // summed over cells, [8..15] shader-clock ticks per section (push, sort, bookkeeping, walk, epilogue)
+// ([13] the wait for the row's samples, [14] their conversion; [8] then is the requests of the next row alone; [15] the
+// recomputation of flagged cell-rows inside the kernel)
 // and [4..7] rounds after a row's first one by the keys still to move in the wave's worst cell (<= 2, <= 4, <= 8, more)
 // PACKED: the samples are int16 codes read in place (kernels.h: PackedI16, packed_src.h): a row's codes become the float32
 // samples the rest of the row works on -- float(code) * sf + of in mode 1, float(code) in modes 2 and 3 -- and in mode 2 the
@@ -124,7 +224,7 @@ __device__ __forceinline__ void sorted_body(
     const void* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, const DevSortedChunk* __restrict__ chunks, double q, int negate,
     int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
-    uint32_t* __restrict__ redo_bits, int64_t redo_ld, unsigned long long* __restrict__ stats, const PackedI16& pk) {
+    unsigned long long* __restrict__ stats, const PackedI16& pk) {
     constexpr int R = 11;
     constexpr uint32_t ES = PACKED ? 2u : 4u;    // bytes per stored sample                        // w = 5
     constexpr int NL = 6;                        // list slots per lane (lane 1 owns 5 and a dummy)
@@ -235,7 +335,7 @@ __device__ __forceinline__ void sorted_body(
     point_at(ch.warm_start);
     request();
 
-    unsigned long long tacc[5] = {0, 0, 0, 0, 0};
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = 0;
     if constexpr (STATS) tlast = __builtin_amdgcn_s_memtime();
     auto tick = [&](int idx) {
@@ -255,7 +355,6 @@ __device__ __forceinline__ void sorted_body(
     // inputs of the epilogue of the row this lane finishes
     uint32_t e_alo = 0, e_ahi = 0, e_n = 0;
     double e_total = 0.0, e_g = 0.0;
-    uint32_t e_flag = 0;
 
     bool nan_mode = false;         // (wave-uniform) the last plain row had a NaN sample
     uint32_t vi_n = 0xFFFFFFFFu, vi_lo = 0;      // the pool size the quantile position below was computed for
@@ -274,6 +373,10 @@ __device__ __forceinline__ void sorted_body(
         double din = 0.0;
         uint32_t nvin = 0;
         float xv[YPS];
+        if constexpr (STATS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tick(5);
+        }
         if constexpr (PACKED) {
             // (codes -> samples: xmhw_decode()'s arithmetic, the fill code -> NaN; big-endian codes swapped first.  Every
             // wave-uniform choice -- byte order, float32 recipe, "a lane holds a fill code" -- is ONE branch around a block
@@ -382,6 +485,7 @@ __device__ __forceinline__ void sorted_body(
         }
 #pragma unroll
         for (int y = YPS; y < HE; ++y) k[y] = 0u;
+        tick(6);
         // prefetch: the samples of step s + 1, into the same registers
         if (s + 1 < ch.end) {
             if (sf_nxt & 2u) advance();
@@ -776,16 +880,70 @@ __device__ __forceinline__ void sorted_body(
             const uint32_t fl_ = flag ? 1u : 0u;
             flag = (fl_ | swp(fl_)) != 0u;
         }
+        if constexpr (STATS) st_flag += (sub == 0 && cell_ok && flag) ? 1u : 0u;
+        tick(3);
+        if (__any(flag)) {
+            // ---- 4b. the flagged cells of this row, one after the other, by the whole wave (pool_order_stats above) ---------
+            constexpr int KPL = (NTP * R + 63) / 64;
+            unsigned long long fm = __builtin_amdgcn_ballot_w64(flag && sub == 0 && cell_ok);
+            while (fm != 0ull) {
+                const int L = __builtin_ctzll(fm);
+                fm &= fm - 1ull;
+                const int64_t cc = static_cast<int64_t>(blockIdx.x) * 32 + (L >> 1);
+                const uint32_t n_c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(n), L));
+                const uint32_t lo_c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lo), L));
+                const uint32_t guess = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(a_lo), L));
+                uint32_t key[KPL];
+                {
+                    // (two sweeps -- table entries, samples -- so that the loads of a sweep are in flight together)
+                    uint32_t ent[KPL];
+#pragma unroll
+                    for (int i = 0; i < KPL; ++i) {
+                        const int e = lane + 64 * i;
+                        const int j = e / NTP, trk = e - j * NTP;
+                        ent[i] = e < NTP * R ? table[static_cast<int64_t>(s - j - step_min) * NTP + trk] : (kCodeInvalid << 1);
+                    }
+                    const char* colc = static_cast<const char*>(ts) + cc * static_cast<int64_t>(ES);
+                    typename std::conditional<PACKED, int32_t, float>::type raw[KPL];
+#pragma unroll
+                    for (int i = 0; i < KPL; ++i) {
+                        const uint32_t t = umin((ent[i] >> 1) - 2u, tmax);
+                        const char* a_ = colc + static_cast<uint64_t>(t) * ld4;
+                        if constexpr (PACKED) raw[i] = static_cast<int32_t>(*reinterpret_cast<const int16_t*>(a_));
+                        else raw[i] = *reinterpret_cast<const float*>(a_);
+                    }
+#pragma unroll
+                    for (int i = 0; i < KPL; ++i) {
+                        float xs;
+                        if constexpr (PACKED) {
+                            int32_t c_ = raw[i];
+                            if (pk.swap) c_ = static_cast<int32_t>(static_cast<int16_t>(__builtin_bswap16(static_cast<uint16_t>(c_))));
+                            xs = packed_sample(pk, c_);
+                        } else {
+                            xs = raw[i];
+                        }
+                        const bool ok = xs == xs && (ent[i] >> 1) >= 2u;
+                        const uint32_t kk = negate ? key_fast<true>(__float_as_uint(xs)) : key_fast<false>(__float_as_uint(xs));
+                        key[i] = ok ? kk : 0u;
+                    }
+                }
+                uint32_t r_lo = 0, r_hi = 0;
+                pool_order_stats<KPL>(key, n_c, lo_c, guess, r_lo, r_hi);
+                const bool mine = (lane >> 1) == (L >> 1);
+                a_lo = mine ? r_lo : a_lo;
+                a_hi = mine ? r_hi : a_hi;
+                flag = mine ? false : flag;
+            }
+            B = a_lo;
+        }
+        tick(7);
         if constexpr (STATS) st_steps += (sub == 0 && cell_ok) ? steps0 : 0u;
         }
         tick(3);
 
         // ---- 5. output ---------------------------------------------------------------------------------------------
         if (s >= ch.begin) {
-            if constexpr (STATS) {
-                ++st_rows;
-                st_flag += (sub == 0 && cell_ok && flag) ? 1u : 0u;
-            }
+            if constexpr (STATS) ++st_rows;
             // The epilogue (key -> value, numpy's lerp, the float64 division, the stores) is the same ~60 instructions for
             // both lanes of a cell: they take turns -- lane `sub` keeps the inputs of the rows with (s - begin) % 2 == sub
             // and every second row (and at the end of the chunk) each lane finishes ITS row.
@@ -796,7 +954,6 @@ __device__ __forceinline__ void sorted_body(
                 e_n = n;
                 e_total = total;
                 e_g = g;
-                e_flag = flag ? 1u : 0u;
             }
             if (eph == 1u || s + 1 == ch.end) {
                 double th = make_nan(), se = make_nan();
@@ -815,7 +972,6 @@ __device__ __forceinline__ void sorted_body(
                     const int64_t row = static_cast<int64_t>(s) - static_cast<int64_t>(eph) + sub;
                     thresh[row * ldo + cell] = th;
                     seas[row * ldo + cell] = se;
-                    if (e_flag != 0u && e_n > 0) atomicOr(&redo_bits[row * redo_ld + (cell >> 5)], 1u << (cell & 31));
                 }
             }
         }
@@ -830,7 +986,7 @@ __device__ __forceinline__ void sorted_body(
 #pragma unroll
             for (int i = 0; i < 4; ++i) atomicAdd(&stats[4 + i], static_cast<unsigned long long>(st_more[i]));
 #pragma unroll
-            for (int i = 0; i < 5; ++i) atomicAdd(&stats[8 + i], tacc[i]);
+            for (int i = 0; i < 8; ++i) atomicAdd(&stats[8 + i], tacc[i]);
         }
         if (sub == 0) {
             atomicAdd(&stats[2], static_cast<unsigned long long>(st_flag));
@@ -845,28 +1001,25 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
     const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, const DevSortedChunk* __restrict__ chunks, double q, int negate,
     int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
-    uint32_t* __restrict__ redo_bits, int64_t redo_ld, unsigned long long* __restrict__ stats) {
-    sorted_body<YPS, K, STATS, false>(ts, C, ld, Tn, table, sflags, chunks, q, negate, ntracks, thresh, seas, ldo, redo_bits,
-                                      redo_ld, stats, PackedI16{});
+    unsigned long long* __restrict__ stats) {
+    sorted_body<YPS, K, STATS, false>(ts, C, ld, Tn, table, sflags, chunks, q, negate, ntracks, thresh, seas, ldo, stats,
+                                      PackedI16{});
 }
 // the same on int16 codes (no counter twin)
 template <int YPS, int K>
 __global__ __launch_bounds__(64, 2) void clim_sorted_i16(
     const int16_t* __restrict__ codes, PackedI16 pk, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, const DevSortedChunk* __restrict__ chunks, double q, int negate,
-    int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
-    uint32_t* __restrict__ redo_bits, int64_t redo_ld) {
-    sorted_body<YPS, K, false, true>(codes, C, ld, Tn, table, sflags, chunks, q, negate, ntracks, thresh, seas, ldo, redo_bits,
-                                     redo_ld, nullptr, pk);
+    int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo) {
+    sorted_body<YPS, K, false, true>(codes, C, ld, Tn, table, sflags, chunks, q, negate, ntracks, thresh, seas, ldo, nullptr, pk);
 }
 
 // ---------------------------------------------------------------------------
 namespace {
 typedef void (*SortedKernel)(const float*, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*,
-                             const DevSortedChunk*, double, int, int32_t, double*, double*, int64_t, uint32_t*, int64_t,
-                             unsigned long long*);
+                             const DevSortedChunk*, double, int, int32_t, double*, double*, int64_t, unsigned long long*);
 typedef void (*SortedKernelI16)(const int16_t*, PackedI16, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*,
-                                const DevSortedChunk*, double, int, int32_t, double*, double*, int64_t, uint32_t*, int64_t);
+                                const DevSortedChunk*, double, int, int32_t, double*, double*, int64_t);
 struct SortedEntry { int yps, k; SortedKernel fn, fn_stats; SortedKernelI16 fn_i16; };
 #ifdef XMHW_RING_STATS
 #define XMHW_SS(Y, K) clim_sorted_f32<Y, K, true>
@@ -877,13 +1030,16 @@ struct SortedEntry { int yps, k; SortedKernel fn, fn_stats; SortedKernelI16 fn_i
 // tracks per lane -> keys stored per list: about 0.4 x the tracks of the record (a list's share of the pool's top tenth
 // is a tenth of the tracks on average and reaches three to four times that on a steep seasonal slope), even, at most
 // what a lane holds.  9..48 tracks.
+#ifndef XMHW_K40
+#define XMHW_K40 16      // (keys per list of the 37..40-track records; experiments: tools/mkvariant.sh k14 -DXMHW_K40=14)
+#endif
 const SortedEntry kSorted[] = {
 #ifdef XMHW_SORTED_ONLY      // (tools/isa_sorted.sh: one instantiation, for a quick look at the ISA)
-    XMHW_S(20, 16),
+    XMHW_S(20, XMHW_K40),
 #else
     XMHW_S(5, 6),   XMHW_S(6, 6),   XMHW_S(7, 8),   XMHW_S(8, 8),   XMHW_S(9, 10),  XMHW_S(10, 10), XMHW_S(11, 10),
     XMHW_S(12, 10), XMHW_S(13, 12), XMHW_S(14, 12), XMHW_S(15, 12), XMHW_S(16, 12), XMHW_S(17, 14), XMHW_S(18, 14),
-    XMHW_S(19, 16), XMHW_S(20, 16), XMHW_S(21, 18), XMHW_S(22, 18), XMHW_S(23, 18), XMHW_S(24, 18),
+    XMHW_S(19, XMHW_K40), XMHW_S(20, XMHW_K40), XMHW_S(21, 18), XMHW_S(22, 18), XMHW_S(23, 18), XMHW_S(24, 18),
 #endif
 };
 #undef XMHW_S
@@ -958,28 +1114,27 @@ int32_t sorted_pick_k(int32_t w, int32_t ntracks) {
 hipError_t launch_sorted_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
                              const uint32_t* sflags, const DevSortedChunk* chunks, int32_t nchunks,
                              int32_t w, int32_t yps, int32_t ntracks, double q, int negate, double* thresh, double* seas,
-                             int64_t ldo, uint32_t* redo_bits, int64_t redo_ld, hipStream_t stream,
-                             unsigned long long* stats) {
+                             int64_t ldo, hipStream_t stream, unsigned long long* stats) {
     const SortedEntry* e = w == 5 ? find_sorted(yps) : nullptr;
-    if (!e || ld >= (int64_t(1) << 30) || !redo_bits) return hipErrorInvalidValue;
+    if (!e || ld >= (int64_t(1) << 30)) return hipErrorInvalidValue;
     if (C <= 0 || nchunks <= 0) return hipSuccess;
     dim3 grid(static_cast<unsigned>((C + 31) / 32), static_cast<unsigned>(nchunks));
     const bool twin = stats != nullptr && e->fn_stats != nullptr;
     hipLaunchKernelGGL(twin ? e->fn_stats : e->fn, grid, dim3(64), 0, stream, ts, C, ld, Tn, table, sflags, chunks, q,
-                       negate, ntracks, thresh, seas, ldo, redo_bits, redo_ld, twin ? stats : nullptr);
+                       negate, ntracks, thresh, seas, ldo, twin ? stats : nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_sorted_i16(const int16_t* codes, const PackedI16& pk, int64_t C, int64_t ld, int64_t Tn,
                              const uint32_t* table, const uint32_t* sflags, const DevSortedChunk* chunks, int32_t nchunks,
                              int32_t w, int32_t yps, int32_t ntracks, double q, int negate, double* thresh, double* seas,
-                             int64_t ldo, uint32_t* redo_bits, int64_t redo_ld, hipStream_t stream) {
+                             int64_t ldo, hipStream_t stream) {
     const SortedEntry* e = w == 5 ? find_sorted(yps) : nullptr;
-    if (!e || !e->fn_i16 || ld >= (int64_t(1) << 30) || !redo_bits || pk.mode < 1 || pk.mode > 3) return hipErrorInvalidValue;
+    if (!e || !e->fn_i16 || ld >= (int64_t(1) << 30) || pk.mode < 1 || pk.mode > 3) return hipErrorInvalidValue;
     if (C <= 0 || nchunks <= 0) return hipSuccess;
     dim3 grid(static_cast<unsigned>((C + 31) / 32), static_cast<unsigned>(nchunks));
     hipLaunchKernelGGL(e->fn_i16, grid, dim3(64), 0, stream, codes, pk, C, ld, Tn, table, sflags, chunks, q, negate, ntracks,
-                       thresh, seas, ldo, redo_bits, redo_ld);
+                       thresh, seas, ldo);
     return hipGetLastError();
 }
 
