@@ -226,3 +226,37 @@ def test_random_cases_equal_generic_kernel(dev):
         x = _series(doy.shape[0], C, 100 + it, nanfrac=float(rng.choice([0.0, 0.02, 0.3])),
                     quant=float(rng.choice([0.0, 0.01, 0.5])) or None, amp=(0.1, float(rng.choice([3, 10, 25]))))
         _check(dev, x, doy, q=float(rng.choice([0.9, 0.86, 0.97])), negate=bool(rng.integers(0, 2)))
+
+
+def test_fuzz_generator_cases_on_the_two_tier_lists(dev):
+    """40 draws of tools/fuzz_ring2.py's generator restricted to records of 37..40 years (the instantiations whose lists keep
+    14 ranks in LDS and two in registers, round 6) and percentiles >= 85: partial years, quantised values (heaps of ties),
+    NaN shares up to 95 %, infinities, constant cells, clusters of adjacent keys, cold spells, forced chunk counts --
+    against the generic kernel, thresh bit for bit.  Draw 485 of seed 601 is the case that caught a wrong carried boundary
+    after a recomputed cell-row (quantised cold-spell data on a 38.5-year record): it is replayed first."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import fuzz_ring2 as fz
+
+    def draws(seed, want):
+        rng = np.random.default_rng(seed)
+        i = 0
+        while True:
+            x, doy, pct, tstep, cold, nchunks = fz.random_ring2_case(rng, (37, 41))
+            if pct < 85:
+                continue
+            plan = dev.Plan(doy, 5)
+            ok = plan.layout_in_use() == 40
+            plan.destroy()
+            if not ok:
+                continue
+            if i in want:
+                yield i, x, doy, pct, tstep, cold, nchunks
+            i += 1
+            if i > max(want):
+                return
+
+    for seed, want in ((601, {485}), (77, set(range(40)))):
+        for i, x, doy, pct, tstep, cold, nchunks in draws(seed, want):
+            fz.check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks, sorted_only=True, msg=f"seed {seed} draw {i}")

@@ -97,7 +97,8 @@ def main():
             out["sorted"] = {"wave_rows": int(st[0]), "walk_iterations_per_wave_row": round(float(st[1]) / rows, 2),
                              "walk_steps_per_cell_row": round(float(st[3]) / cellrows, 3),
                              "flagged_cell_rows_frac": float(st[2]) / cellrows,
-                             "extra_rounds_per_wave_row_by_keys_left_le2_le4_le8_more": [round(float(x) / rows, 4) for x in st[4:8]],
+                             "register_rank_corrections_per_wave_row": round(float(st[4]) / rows, 4),
+                             "extra_rounds_per_wave_row_by_keys_left_le4_le8_more": [round(float(x) / rows, 4) for x in st[5:8]],
                              "ticks_per_wave_row_push_sort_book_walk_epilogue": [round(float(x) / rows, 1) for x in st[8:13]],
                              "ticks_per_wave_row_wait_samples_convert_redo": [round(float(x) / rows, 1) for x in st[13:16]]}
         print(json.dumps(out), flush=True)

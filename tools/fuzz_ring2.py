@@ -87,8 +87,16 @@ def random_ring2_case(rng, years=(9, 49)):
     return x, doy, pct, tstep, bool(rng.integers(0, 2)), int(rng.integers(0, 4))
 
 
-def check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks, msg=""):
+def check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks, msg="", sorted_only=False):
     t0, s0, _ = _raw(dev, x, doy, pct / 100.0, cold, kernel="generic")
+    if sorted_only:
+        fin = np.abs(x[np.isfinite(x)])
+        t1, s1, st = _raw(dev, x, doy, pct / 100.0, cold, nchunks, ring2=40)
+        with np.errstate(invalid="ignore"):
+            npt.assert_array_equal(t1, t0, err_msg=f"{msg} variant 40")
+            npt.assert_allclose(s1, s0, rtol=1e-12, atol=1e-13 * float(fin.max()) if fin.size else 0.0, equal_nan=True,
+                                err_msg=f"{msg} variant 40")
+        return {40}
     # the round-1 float32 ring kernel (what other windows and longer records still run on) rides along
     tr, sr, _ = _raw(dev, x, doy, pct / 100.0, cold, nchunks, ring2=-1)
     with np.errstate(invalid="ignore"):
@@ -213,6 +221,10 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64", "i16"])
     ap.add_argument("--kernel", default="auto", help="f64 mode: 'ring' with XMHW_RING2_F64=0 exercises the round-1 float64 ring")
     ap.add_argument("--long", action="store_true", help="records of 49..120 years: the 16- and 32-lane round-1 float32 rings")
+    ap.add_argument("--years", type=int, nargs=2, default=None, metavar=("FIRST", "PAST_LAST"),
+                    help="record lengths drawn (default 9 49); 37 41 = the sorted-list kernel's two-tier lists (round 6)")
+    ap.add_argument("--sorted-only", action="store_true",
+                    help="f32: percentiles >= 85 and the sorted-list layout (40) against the generic kernel only -- five times the cases per minute")
     args = ap.parse_args()
     from xmhw_amd._lib import require_gpu
     require_gpu()
@@ -245,10 +257,21 @@ def main():
         print(f"{args.cases} random float64 cases: 0 mismatches against the generic kernel ({time.perf_counter() - t0:.0f} s)")
         return
     layouts = {0: 0, 7: 0, 8: 0, 10: 0, 20: 0, 21: 0, 31: 0}
-    for i in range(args.cases):
-        x, doy, pct, tstep, cold, nchunks = random_ring2_case(rng, (49, 121) if args.long else (9, 49))
-        seen = check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks,
+    yrs = tuple(args.years) if args.years else ((49, 121) if args.long else (9, 49))
+    i = 0
+    while i < args.cases:
+        x, doy, pct, tstep, cold, nchunks = random_ring2_case(rng, yrs)
+        if args.sorted_only:
+            if pct < 85:
+                continue
+            plan = dev.Plan(doy, 5)
+            ok = plan.ring2_in_use() == 40
+            plan.destroy()
+            if not ok:
+                continue
+        seen = check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks, sorted_only=args.sorted_only,
                                 msg=f"seed {args.seed} case {i}: T={x.shape[0]} C={x.shape[1]} pct={pct} tstep={tstep} cold={cold}")
+        i += 1
         for v in seen:
             layouts[v] = layouts.get(v, 0) + 1
     print(f"{args.cases} random cases, runs per layout {layouts}: 0 mismatches against the generic kernel "

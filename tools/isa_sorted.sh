@@ -9,7 +9,7 @@ mkdir -p /tmp/isa
 python3 - <<'PY'
 import re
 txt = open('/tmp/isa/k.s').read()
-sym = "_ZN4xmhw15clim_sorted_f32ILi20ELi16ELb0EEE"
+sym = "_ZN4xmhw15clim_sorted_f32ILi20ELi16ELi14ELb0EEE"
 i = txt.index(sym); i = txt.index(sym, i + 10)
 body = txt[i:txt.index(".Lfunc_end", i)]
 open('/tmp/isa/k20.s', 'w').write(body)
@@ -26,4 +26,4 @@ for name, ins, ln in blocks:
     if v >= 15:
         print(f"{name:12s} line {ln:5d} valu {v:4d} ds {sum(1 for o in ins if o.startswith('ds_')):3d} salu {sum(1 for o in ins if o.startswith('s_') and not o.startswith('s_waitcnt') and not o.startswith('s_nop')):3d} nop {sum(1 for o in ins if o.startswith('s_nop')):2d} vmem {sum(1 for o in ins if o.startswith('global')):2d}")
 PY
-grep -A12 "clim_sorted_f32ILi20ELi16ELb0" /tmp/isa/res.txt | grep -E "VGPRs:|SGPRs:|Occupancy|LDS Size|Scratch" | head -6
+grep -A12 "clim_sorted_f32ILi20ELi16ELi14ELb0" /tmp/isa/res.txt | grep -E "VGPRs:|SGPRs:|Occupancy|LDS Size|Scratch" | head -6

@@ -51,7 +51,7 @@ def main():
                                "-fno-fast-math", "--cuda-device-only", "-S", "-o", out,
                                os.path.join(ROOT, "xmhw_amd", "csrc", "kernels_sorted.hip")], stderr=subprocess.DEVNULL)
         txt = open(out).read()
-    sym = "_ZN4xmhw15clim_sorted_f32ILi20ELi16ELb0EEE"
+    sym = "_ZN4xmhw15clim_sorted_f32ILi20ELi16ELi14ELb0EEE"
     i = txt.index(sym)
     i = txt.index(sym, i + 10)
     body = txt[i:txt.index(".Lfunc_end", i)]

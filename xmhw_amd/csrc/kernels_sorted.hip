@@ -215,11 +215,14 @@ __device__ __forceinline__ void pool_order_stats(const uint32_t (&key)[KPL], uin
 // summed over cells, [8..15] shader-clock ticks per section (push, sort, bookkeeping, walk, epilogue)
 // ([13] the wait for the row's samples, [14] their conversion; [8] then is the requests of the next row alone; [15] the
 // recomputation of flagged cell-rows inside the kernel)
-// and [4..7] rounds after a row's first one by the keys still to move in the wave's worst cell (<= 2, <= 4, <= 8, more)
+// and [5..7] rounds after a row's first one by the keys still to move in the wave's worst cell (<= 4, <= 8, more), [4] wave-rows
+// that ran the correction for the register ranks (4c)
 // PACKED: the samples are int16 codes read in place (kernels.h: PackedI16, packed_src.h): a row's codes become the float32
 // samples the rest of the row works on -- float(code) * sf + of in mode 1, float(code) in modes 2 and 3 -- and in mode 2 the
 // epilogue decodes the two selected codes and the mean of the codes in float64.
-template <int YPS, int K, bool STATS, bool PACKED>
+// K = keys a cell keeps of every row-list, KL <= K of them in LDS; the K - KL (0 or 2) last ranks of a list stay in
+// registers of the lane that owns its slot (EXT below)
+template <int YPS, int K, int KL, bool STATS, bool PACKED>
 __device__ __forceinline__ void sorted_body(
     const void* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, const DevSortedChunk* __restrict__ chunks, double q, int negate,
@@ -241,8 +244,15 @@ __device__ __forceinline__ void sorted_body(
     // waves per CU), so that the first byte behind it is the first byte the hardware answers with 0.
     constexpr uint32_t LSTRIDE = 32 * 4;         // bytes between the lists of one rank
     constexpr uint32_t RSTRIDE = R * LSTRIDE;    // bytes between consecutive ranks of a list
-    constexpr int LDS_BYTES = (R * K * static_cast<int>(LSTRIDE) + kLdsGranule - 1) / kLdsGranule * kLdsGranule;
+    constexpr int LDS_BYTES = (R * KL * static_cast<int>(LSTRIDE) + kLdsGranule - 1) / kLdsGranule * kLdsGranule;
     static_assert(K <= HE && K % 2 == 0, "a list stores an even number of keys, at most what a lane holds");
+    // Two tiers (K = 16, KL = 14: the 37..40-track records).  LDS is what limits the waves: 11 lists x 16 ranks are 7 waves
+    // per CU, 11 x 14 are 8 -- and the eighth wave is worth 9 % (an issue-bound kernel with two waves on every SIMD).  Ranks
+    // 14 and 15 of every list are kept in two register tuples instead.  The select works on the LDS ranks alone; a list
+    // whose 14 LDS keys are all inside the top set and whose 15th key lies above the boundary is then put right by a
+    // short correction (4c below): its register keys join the top set and as many of the smallest keys leave it.
+    constexpr int EXT = K - KL;
+    static_assert(EXT == 0 || (EXT == 2 && KL >= KH), "two register ranks, both from lane 1's half");
     static_assert(LDS_BYTES == 8960 || LDS_BYTES == 11520 || LDS_BYTES == 14080 || LDS_BYTES == 17920 || LDS_BYTES == 20480 ||
                   LDS_BYTES == 23040 || LDS_BYTES == 25600, "sorted_lds_probe() checks these allocation sizes");
     __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_BYTES / 4];
@@ -293,13 +303,20 @@ __device__ __forceinline__ void sorted_body(
     nvl = 0;
     rs_lo = 0;
     rs_hi = 0;
-    static_assert(K >= 5, "a list holds a window");
+    static_assert(KL >= 5, "a list holds a window");
+    V8 ex0, ex1;                                 // EXT: ranks KL and KL + 1 of the own lists
+    ex0 = 0;
+    ex1 = 0;
     uint32_t truncmask = 0;
     // cell-level state, the same in both lanes
     // (B = the carried boundary: the key outside the top set.  During a chunk's warm-up rows nothing is selected -- the lists
     // are only built --, the top set stays empty and no new key counts as above the boundary; the chunk's first output row
     // then grows the top set from nothing: four or five rounds instead of R - 1 rows of selection)
+#ifdef XMHW_WARM_SELECT      // (experiment: the select runs on warm-up rows too, as in round 5)
+    uint32_t Ctop = 0, n = 0, B = 0u;
+#else
     uint32_t Ctop = 0, n = 0, B = 0xFFFFFFFFu;
+#endif
     double total = 0.0;
 
     // ---- sample addresses: a 64-bit pointer per track ------------------------------------------------------
@@ -349,7 +366,7 @@ __device__ __forceinline__ void sorted_body(
         }
     };
     uint32_t st_rows = 0, st_iter = 0, st_flag = 0, st_steps = 0;
-    uint32_t st_serial = 0;
+    uint32_t st_serial = 0, st_ext = 0;
     uint32_t st_more[4] = {0, 0, 0, 0};     // rounds after a row's first one by the keys still to move (wave maximum): <= 2, <= 4, <= 8, more
 
     // inputs of the epilogue of the row this lane finishes
@@ -541,7 +558,10 @@ __device__ __forceinline__ void sorted_body(
         // (this lane's first rank of list m: lane 0 holds ranks 0 .. K/2-1, lane 1 the rest)
         const uint32_t base_m = lcell + static_cast<uint32_t>(m) * LSTRIDE + static_cast<uint32_t>(sub * KH) * RSTRIDE;
 #pragma unroll
-        for (int i = 0; i < KH; ++i) lds_st(base_m + static_cast<uint32_t>(i) * RSTRIDE, u[i]);
+        for (int i = 0; i < KH; ++i) {
+            // (EXT: lane 1's last two keys -- ranks KL, KL + 1 -- are not for LDS: the rows behind the lists stay 0)
+            if (EXT == 0 || i < KH - EXT || sub == 0) lds_st(base_m + static_cast<uint32_t>(i) * RSTRIDE, u[i]);
+        }
         // what leaves: the evicted list's share of the top set, its valid keys, its sum
         uint32_t c_old = 0, nv_old = 0;
         {
@@ -561,7 +581,7 @@ __device__ __forceinline__ void sorted_body(
             uint32_t po = (c_old << 16) | nv_old;
             pk += swp(pk);
             po += swp(po);
-            c_new = umin(pk >> 16, static_cast<uint32_t>(K));
+            c_new = umin(pk >> 16, static_cast<uint32_t>(KL));      // (the pointer counts LDS ranks)
             nvin = pk & 0xFFFFu;
             c_old = po >> 16;
             nv_old = po & 0xFFFFu;
@@ -574,6 +594,12 @@ __device__ __forceinline__ void sorted_body(
             for (int j = 0; j < NL; ++j) t[j] = (own_m && is_slot[j]) ? x : t[j];
         };
         put(P, c_new);
+        if constexpr (EXT > 0) {
+            // (ranks KL and KL + 1 are lane 1's last two keys; the lane that owns slot m keeps them)
+            const uint32_t r0_ = swp(u[KH - 2]), r1_ = swp(u[KH - 1]);
+            put(ex0, sub ? u[KH - 2] : r0_);
+            put(ex1, sub ? u[KH - 1] : r1_);
+        }
         if (own_m) truncmask = (truncmask & ~(1u << mj)) | ((nvin > static_cast<uint32_t>(K) ? 1u : 0u) << mj);
         {
             const uint64_t db = static_cast<uint64_t>(__double_as_longlong(din));
@@ -598,7 +624,11 @@ __device__ __forceinline__ void sorted_body(
         uint32_t a_lo = 0, a_hi = 0;
         double g = 0.0;
         bool flag = false;
+#ifdef XMHW_WARM_SELECT
+        if (true) {
+#else
         if (s >= ch.begin) {
+#endif
         // (n is the same for every cell on every row of gap-free data: the float64 position is redone only when some cell's
         // count has changed)
         if (__any(n != vi_n)) {
@@ -857,8 +887,78 @@ __device__ __forceinline__ void sorted_body(
         a_lo = grow ? kn : kl;
         a_hi = grow ? (steps0 != 0u ? kl : um) : kn;
         a_hi = need2 ? a_hi : a_lo;
-        B = a_lo;
-        {
+        if constexpr (EXT > 0) {
+            // ---- 4c. the register ranks.  The select above knows the LDS ranks only: its top set is the Cs largest of THOSE
+            // keys.  A register key can belong to the true top set only if its list's KL LDS keys are all inside (it is below
+            // them) and it lies above the boundary.  Such keys join (pv[j] of list j, largest first) and as many keys -- the
+            // smallest of the enlarged set, one by one: LDS heads or register keys -- leave.  Ctop keeps counting LDS keys
+            // only, so the next row starts from the same kind of state.
+            uint32_t pv[NL];
+            uint32_t need = 0;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const bool sat = P[j] == static_cast<uint32_t>(KL) && !flag;
+                pv[j] = sat ? ((ex0[j] > a_lo ? 1u : 0u) + (ex1[j] > a_lo ? 1u : 0u)) : 0u;
+                need += pv[j];
+            }
+            need += swp(need);
+            if (__any(need != 0u)) {
+                asm volatile("" ::: "memory");
+                if constexpr (STATS) ++st_ext;
+                const bool fix = need != 0u;
+                auto heads = [&](uint32_t (&hd)[NL]) -> uint32_t {     // own lists' smallest inside keys - 1 (none: all ones), their minimum
+                    uint32_t lv[NL];
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) lv[j] = lds_ld(lbase[j] + (P[j] - 1u) * RSTRIDE);
+                    uint32_t hm = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) {
+                        const uint32_t ev = pv[j] == 2u ? ex1[j] : ex0[j];
+                        hd[j] = (pv[j] != 0u ? ev : lv[j]) - 1u;
+                        hm = umin(hm, hd[j]);
+                    }
+                    return hm;
+                };
+                uint32_t vlast = a_lo;
+                while (__any(need != 0u)) {
+                    uint32_t hd[NL];
+                    const uint32_t hm = heads(hd);
+                    const uint32_t ho = swp(hm);
+                    const uint32_t cmin = umin(hm, ho);
+                    const bool act = need != 0u;
+                    const bool win = act && hm == cmin && (sub == 0 || ho != cmin);     // lane 0 first on a tie
+                    bool found = false;
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) {
+                        const bool sel = win && !found && hd[j] == cmin;
+                        const bool reg = pv[j] != 0u;
+                        P[j] = (sel && !reg) ? P[j] - 1u : P[j];
+                        pv[j] = (sel && reg) ? pv[j] - 1u : pv[j];
+                        found = found || sel;
+                    }
+                    if (act) {
+                        vlast = cmin + 1u;
+                        need -= 1u;
+                    }
+                }
+                uint32_t hd[NL];
+                uint32_t hm = heads(hd);
+                hm = umin(hm, swp(hm)) + 1u;
+                uint32_t pvs = 0;
+#pragma unroll
+                for (int j = 0; j < NL; ++j) pvs += pv[j];
+                pvs += swp(pvs);
+                if (fix) {
+                    a_lo = vlast;
+                    a_hi = need2 ? hm : vlast;
+                    Ctop = Cs - pvs;
+                    // both register keys of a list inside and more valid keys than the K the cell keeps: the list may hide keys
+                    // above the boundary (its last kept key lies above it) -- the row goes to the recomputation
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) flag = flag || (pv[j] == 2u && ((truncmask >> j) & 1u));
+                }
+            }
+        } else {
             // a list stored to its last key, all of it inside the top set, with keys that were not stored: what was not
             // stored is not above the list's last stored key U -- the row is wrong only if U lies above the key outside
             // the top set (a tie with it is harmless: sea-ice plateaus, quantised values)
@@ -874,6 +974,7 @@ __device__ __forceinline__ void sorted_body(
                 }
             }
         }
+        B = a_lo;
         {
             // (NOT `flag || swp(...)`: the short-circuit would run the exchange with the flagged lanes switched off, and
             // a DPP read of a lane that is switched off returns 0 -- the partner lane would never see the flag)
@@ -882,7 +983,7 @@ __device__ __forceinline__ void sorted_body(
         }
         if constexpr (STATS) st_flag += (sub == 0 && cell_ok && flag) ? 1u : 0u;
         tick(3);
-        if (__any(flag)) {
+        if (s >= ch.begin && __any(flag)) {
             // ---- 4b. the flagged cells of this row, one after the other, by the whole wave (pool_order_stats above) ---------
             constexpr int KPL = (NTP * R + 63) / 64;
             unsigned long long fm = __builtin_amdgcn_ballot_w64(flag && sub == 0 && cell_ok);
@@ -934,7 +1035,8 @@ __device__ __forceinline__ void sorted_body(
                 a_hi = mine ? r_hi : a_hi;
                 flag = mine ? false : flag;
             }
-            B = a_lo;
+            // (B stays the select's own boundary: the pointers of a flagged cell describe THAT top set, and the next row's new
+            // keys must be counted against the same value -- the exact answer is for the output only)
         }
         tick(7);
         if constexpr (STATS) st_steps += (sub == 0 && cell_ok) ? steps0 : 0u;
@@ -984,7 +1086,8 @@ __device__ __forceinline__ void sorted_body(
             atomicAdd(&stats[0], static_cast<unsigned long long>(st_rows));
             atomicAdd(&stats[1], static_cast<unsigned long long>(st_iter));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) atomicAdd(&stats[4 + i], static_cast<unsigned long long>(st_more[i]));
+            for (int i = 1; i < 4; ++i) atomicAdd(&stats[4 + i], static_cast<unsigned long long>(st_more[i]));
+            atomicAdd(&stats[4], static_cast<unsigned long long>(st_ext));      // (st_more[0] is always 0: such rows are finished key by key)
 #pragma unroll
             for (int i = 0; i < 8; ++i) atomicAdd(&stats[8 + i], tacc[i]);
         }
@@ -996,22 +1099,22 @@ __device__ __forceinline__ void sorted_body(
 }
 
 // (registers: LDS holds 6 waves per CU at K = 16 and more for shorter lists: two waves per SIMD is what the body is asked to fit)
-template <int YPS, int K, bool STATS>
+template <int YPS, int K, int KL, bool STATS>
 __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
     const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, const DevSortedChunk* __restrict__ chunks, double q, int negate,
     int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
     unsigned long long* __restrict__ stats) {
-    sorted_body<YPS, K, STATS, false>(ts, C, ld, Tn, table, sflags, chunks, q, negate, ntracks, thresh, seas, ldo, stats,
+    sorted_body<YPS, K, KL, STATS, false>(ts, C, ld, Tn, table, sflags, chunks, q, negate, ntracks, thresh, seas, ldo, stats,
                                       PackedI16{});
 }
 // the same on int16 codes (no counter twin)
-template <int YPS, int K>
+template <int YPS, int K, int KL>
 __global__ __launch_bounds__(64, 2) void clim_sorted_i16(
     const int16_t* __restrict__ codes, PackedI16 pk, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, const DevSortedChunk* __restrict__ chunks, double q, int negate,
     int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo) {
-    sorted_body<YPS, K, false, true>(codes, C, ld, Tn, table, sflags, chunks, q, negate, ntracks, thresh, seas, ldo, nullptr, pk);
+    sorted_body<YPS, K, KL, false, true>(codes, C, ld, Tn, table, sflags, chunks, q, negate, ntracks, thresh, seas, ldo, nullptr, pk);
 }
 
 // ---------------------------------------------------------------------------
@@ -1020,29 +1123,34 @@ typedef void (*SortedKernel)(const float*, int64_t, int64_t, int64_t, const uint
                              const DevSortedChunk*, double, int, int32_t, double*, double*, int64_t, unsigned long long*);
 typedef void (*SortedKernelI16)(const int16_t*, PackedI16, int64_t, int64_t, int64_t, const uint32_t*, const uint32_t*,
                                 const DevSortedChunk*, double, int, int32_t, double*, double*, int64_t);
-struct SortedEntry { int yps, k; SortedKernel fn, fn_stats; SortedKernelI16 fn_i16; };
+struct SortedEntry { int yps, k, kl; SortedKernel fn, fn_stats; SortedKernelI16 fn_i16; };
 #ifdef XMHW_RING_STATS
-#define XMHW_SS(Y, K) clim_sorted_f32<Y, K, true>
+#define XMHW_SS(Y, K, KL) clim_sorted_f32<Y, K, KL, true>
 #else
-#define XMHW_SS(Y, K) nullptr
+#define XMHW_SS(Y, K, KL) nullptr
 #endif
-#define XMHW_S(Y, K) {Y, K, clim_sorted_f32<Y, K, false>, XMHW_SS(Y, K), clim_sorted_i16<Y, K>}
+#define XMHW_S2(Y, K, KL) {Y, K, KL, clim_sorted_f32<Y, K, KL, false>, XMHW_SS(Y, K, KL), clim_sorted_i16<Y, K, KL>}
+#define XMHW_S(Y, K) XMHW_S2(Y, K, K)
 // tracks per lane -> keys stored per list: about 0.4 x the tracks of the record (a list's share of the pool's top tenth
 // is a tenth of the tracks on average and reaches three to four times that on a steep seasonal slope), even, at most
 // what a lane holds.  9..48 tracks.
 #ifndef XMHW_K40
-#define XMHW_K40 16      // (keys per list of the 37..40-track records; experiments: tools/mkvariant.sh k14 -DXMHW_K40=14)
+#define XMHW_K40 16      // (keys per list of the 37..40-track records ...
+#endif
+#ifndef XMHW_KL40
+#define XMHW_KL40 14     //  ... and how many of them live in LDS: 14 = 8 waves per CU, the other two in registers)
 #endif
 const SortedEntry kSorted[] = {
 #ifdef XMHW_SORTED_ONLY      // (tools/isa_sorted.sh: one instantiation, for a quick look at the ISA)
-    XMHW_S(20, XMHW_K40),
+    XMHW_S2(20, XMHW_K40, XMHW_KL40),
 #else
     XMHW_S(5, 6),   XMHW_S(6, 6),   XMHW_S(7, 8),   XMHW_S(8, 8),   XMHW_S(9, 10),  XMHW_S(10, 10), XMHW_S(11, 10),
     XMHW_S(12, 10), XMHW_S(13, 12), XMHW_S(14, 12), XMHW_S(15, 12), XMHW_S(16, 12), XMHW_S(17, 14), XMHW_S(18, 14),
-    XMHW_S(19, XMHW_K40), XMHW_S(20, XMHW_K40), XMHW_S(21, 18), XMHW_S(22, 18), XMHW_S(23, 18), XMHW_S(24, 18),
+    XMHW_S2(19, XMHW_K40, XMHW_KL40), XMHW_S2(20, XMHW_K40, XMHW_KL40), XMHW_S(21, 18), XMHW_S(22, 18), XMHW_S(23, 18), XMHW_S(24, 18),
 #endif
 };
 #undef XMHW_S
+#undef XMHW_S2
 #undef XMHW_SS
 const SortedEntry* find_sorted(int32_t yps) {
     for (const auto& e : kSorted)
