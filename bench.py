@@ -415,20 +415,15 @@ def run(args):
             _k, _lds, _pieces = _hip().plan_sorted_info(_p.handle, int(args.cells) or ps["cells"])
             _chunks = np.asarray(_hip().plan_sorted_table(_p.handle, int(_pieces))[0])
             _rows_per_wave = float(np.mean(_chunks[:, 2] - _chunks[:, 0]))
-            _waves_cu = min(8, (160 * 1024) // (512 * ((int(_lds) + 511) // 512)))
+            _waves_cu = min(8, (160 * 1024) // (1280 * ((int(_lds) + 1279) // 1280)))      # (LDS is handed out in 1,280-byte pieces)
         _p.destroy()
         traffic, traffic_src, sq = live_counters(child_argv, _rows_per_wave)
         # the issue floor of the sorted-list kernel: its vector instructions by issue class (from the ISA, hipcc
         # -S on this box: no GPU) priced with the measured per-class costs, against the live counters -- tools/issue_mix.py
         if sq is not None and "clim_sorted" in str(sq.get("kernel", "")):
             try:
-                rounds = 1.26
-                tk = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r5_ticks.jsonl")
-                if os.path.exists(tk):
-                    first = json.loads(open(tk).readline())
-                    rounds = float(first["sorted"]["walk_iterations_per_wave_row"])
                 r_ = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "issue_mix.py"),
-                                     "--rounds", str(rounds), "--measured-valu", str(sq["valu_per_wave_row"]),
+                                     "--measured-valu", str(sq["valu_per_wave_row"]),
                                      "--measured-quad-cycles", str(sq["wave_quad_cycles_per_wave_row"]),
                                      "--waves-per-cu", str(_waves_cu)],
                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
@@ -576,7 +571,7 @@ def run(args):
             "algorithmic_bytes_per_launch": cells_per_launch * bytes_per_cell,
             "algorithmic_bytes_per_cell": bytes_per_cell, "cells_per_launch": cells_per_launch,
             "avg_launch_ms": ring_avg_ms,
-            # the whole raw-climatology call: that kernel + the recomputation of the cell-rows it flagged (kernels_redo.hip)
+            # the whole raw-climatology call (round 6: the same thing -- flagged cell-rows are recomputed inside the kernel)
             "raw_call_avg_ms": float(np.mean(raw_ms)),
             # what actually binds this kernel: vector-instruction issue.  The waves of a SIMD share one issue port; the
             # share of the SIMD's cycles its vector ALU is busy is (waves per SIMD) x the per-wave share measured by
@@ -593,6 +588,7 @@ def run(args):
                 "frac_of_issue_peak": min((waves_cu / 4.0 if v2 == 40 else 2.0) * sq["valu_busy_of_wave_cycles"], 1.0),
                 # priced per issue class (tools/issue_mix.py): SIMD cycles a wave-row needs at least, and how close the kernel is
                 "issue_floor_cycles_per_wave_row": None if "issue_mix" not in sq else sq["issue_mix"]["issue_floor_cycles_per_wave_row"],
+                "issue_floor_inputs": None if "issue_mix" not in sq else {k: sq["issue_mix"].get(k) for k in ("cost_cycles", "select_round_equivalents_per_wave_row", "select_round_equivalents_source", "valu_of_blocks_that_run_once_per_row", "valu_of_a_select_round")},
                 "class_B_share_of_valu": None if "issue_mix" not in sq else sq["issue_mix"]["class_B_share"],
                 "frac_of_issue_floor": None if "issue_mix" not in sq else sq["issue_mix"].get("frac_of_issue_floor_at_this_occupancy"),
                 "frac_of_issue_floor_at_two_waves_per_simd": None if "issue_mix" not in sq else sq["issue_mix"].get("frac_of_issue_floor_at_two_waves_per_simd"),

@@ -136,10 +136,12 @@ int xmhw_plan_set_kernel(xmhw_plan *plan, int32_t kernel);  /* tests / fallback 
  * default; xmhw_plan_narrowed() reports (synchronously) whether the last float64 call of this
  * plan stayed on the float32 kernel.                                                         */
 int xmhw_plan_set_narrowing(xmhw_plan *plan, int32_t enable);
-/* measurement (bench.py): with timing on, every float32 xmhw_clim_raw_f32 call records a HIP event on its stream right
- * before and right after its MAIN kernel (the sorted-list kernel or the ring kernel; not the recomputation of flagged
- * cell-rows behind it); xmhw_plan_kernel_ms returns the elapsed time of the call `calls_back` calls ago (0 = the last
- * one, up to 15), waiting for it to finish.                                                                       */
+/* measurement (bench.py): with timing on, every xmhw_clim_raw_f32 / xmhw_clim_raw_i16 call records a HIP event on its
+ * stream right before and right after its MAIN kernel (the sorted-list kernel -- which since round 6 also recomputes the
+ * cell-rows its select cannot settle -- or the ring kernel); xmhw_plan_kernel_ms returns the elapsed time of the call
+ * `calls_back` calls ago (0 = the last one, up to 15), waiting for it to finish.
+ * A plan is used from ONE stream at a time: the timing events and the lazily uploaded tables belong to the plan, not to
+ * the call.  Two calls on the same plan may be in flight only if they were issued on the same stream.               */
 int xmhw_plan_set_timing(xmhw_plan *plan, int32_t enable);
 int xmhw_plan_kernel_ms(xmhw_plan *plan, int32_t calls_back, float *ms);
 int xmhw_plan_narrowed(xmhw_plan *plan, int32_t *narrowed_out);
@@ -151,17 +153,19 @@ int xmhw_plan_chunks_in_use(const xmhw_plan *plan, int64_t C, int32_t *nchunks);
  * table[nsteps][ntracks_padded] (see csrc/plan.h for the encoding)            */
 int xmhw_plan_table(const xmhw_plan *plan, int32_t years_per_lane, uint32_t *table_out,
                     int32_t *ntracks_padded);
+/* the sorted-list kernel on this plan: keys a cell keeps of every row-list (for 37..40 tracks 16: 14 ranks in LDS, two in
+ * registers), LDS bytes of a wave (32 cells; handed out in 1,280-byte pieces: 20,480 = 8 waves per CU), and the `pieces`
+ * a launch over C cells asks xmhw_plan_sorted_table for (the automatic choice or xmhw_plan_set_chunks)            */
+int xmhw_plan_sorted_info(const xmhw_plan *plan, int64_t C, int32_t *keys_per_list, int32_t *lds_bytes_per_wave,
+                          int32_t *pieces);
 /* host copy of the sorted-list kernel's chunks and step table (XMHW_LAYOUT_SORTED; csrc/plan.h: sorted_plan) for
  * inspection: the row axis cut wherever the set of pooled tracks changes (doy 60, the ends of partial years), every
  * chunk with its own table rows -- what window_roll() + groupby("doy") pool (xmhw/identify.py:184-209, :233) restated
  * per chunk.  `pieces` = how many pieces the whole row axis is cut into at least (1: only the cuts the calendar asks
  * for).  Call with NULL outputs for the sizes: nchunks, nrows (table / flag rows), ntp (entries per row, track k at
- * index k); then chunks_out[nchunks][4] = {warm_start, begin, end, trow0}, table_out[nrows][ntp], flags_out[nrows].
+ * index k); then chunks_out[nchunks][4] = {warm_start, begin, end, trow0}, table_out[nrows][ntp], flags_out[nrows]
+ * (in calendar order; a launch runs them longest first).
  * XMHW_ERR_UNSUPPORTED if the kernel is not instantiated for this plan.                                          */
-/* the sorted-list kernel on this plan: keys stored per row-list, LDS bytes of a wave (32 cells), and the `pieces` a
- * launch over C cells asks xmhw_plan_sorted_table for (the automatic choice or xmhw_plan_set_chunks)             */
-int xmhw_plan_sorted_info(const xmhw_plan *plan, int64_t C, int32_t *keys_per_list, int32_t *lds_bytes_per_wave,
-                          int32_t *pieces);
 int xmhw_plan_sorted_table(const xmhw_plan *plan, int32_t pieces, int32_t *nchunks, int32_t *nrows, int32_t *ntp,
                            int32_t *chunks_out, uint32_t *table_out, uint32_t *flags_out);
 
@@ -199,12 +203,14 @@ enum {
     XMHW_LAYOUT_RING3_8LANE = 20,    /* third generation, 8 cells per wave */
     XMHW_LAYOUT_RING3_4LANE = 21,    /* third generation, 16 cells per wave: the headline layout (40 tracks) */
     XMHW_LAYOUT_RING3_2LANE = 22,    /* third generation, 32 cells per wave */
-    XMHW_LAYOUT_SORTED = 40          /* round 5 (csrc/kernels_sorted.hip): sorted row-lists in LDS + a pointer walk, 32
-                                        cells per wave, on the rows that pool every track at every step; the other
-                                        rows (around doy 60, around the ends of partial years) on the automatic ring
-                                        layout; cell-rows whose lists are too short on the generic kernel.  float32,
-                                        w = 5, 9..48 tracks,
-                                        quantiles >= 0.85 (others run on the ring layout) */
+    XMHW_LAYOUT_SORTED = 40          /* rounds 5-6 (csrc/kernels_sorted.hip): sorted row-lists in LDS + a parallel
+                                        merge-select, 32 cells per wave, every row of the plan (chunks with their own
+                                        table rows: plan.h); a cell-row whose lists are too short is recomputed inside
+                                        the kernel.  float32 (or int16 codes), w = 5, 9..48 tracks.  NOTE: 40 means
+                                        "sorted for quantiles >= 0.85": a call with a smaller quantile runs the same plan
+                                        on its ring layout (xmhw_plan_layout_in_use cannot know the call's quantile).
+                                        Needs a device whose LDS reads outside the allocation return 0 (gfx950; probed
+                                        once per device, otherwise the ring layouts serve the plan) */
 };
 int xmhw_plan_set_layout(xmhw_plan *plan, int32_t layout);
 /* the layout float32 input of this plan will run on (XMHW_LAYOUT_RING1 if the round-1 / generic kernel) */

@@ -12,10 +12,11 @@ T / D / window / percentile / NaN fraction / tstep axis / smoothing width (singl
 
 configs[0] (single point, 30-yr daily) goes through the public point path.
 
-Kernels this file is the evidence for (kernel trace of the device half, tools/trace_configs.py:
-profiles/r2_configs_kernel_stats.csv):
-the untiled ``clim_finish`` (D = 1460 > 511, config 5), the 25-32-track ring (30 years, configs 1-2)
-and the 20-track ring (config 5).
+Kernels this file is the evidence for: every float32 config runs on the sorted-list layout (XMHW_LAYOUT_SORTED = 40,
+csrc/kernels_sorted.hip) -- asserted per config together with the instantiation it picks: 30 tracks -> 12 keys per list
+(configs[1]), 40 tracks -> 16 keys per list, 14 of them in LDS = 20,480 bytes per wave (configs[2], [3]), 20 tracks on
+the 6-hourly axis -> 10 keys per list (configs[4]); and on the untiled ``clim_finish`` for D = 1460 > 511 (configs[4]).
+A plan silently falling back to a ring layout would fail here, not just run slower.
 """
 import numpy as np
 import numpy.testing as npt
@@ -79,6 +80,11 @@ def _run_config(dev, index, C, doy, nan_frac, tstep, width, skipna, expect_yps=N
     plan1 = dev.Plan(doy, w, nchunks=1)
     D = plan.D
     assert plan.kernel == "ring"
+    # the layout and the instantiation this config is measured on
+    assert plan.layout_in_use() == 40 and plan1.layout_in_use() == 40, (plan.layout_in_use(), plan1.layout_in_use())
+    keys, lds, _ = h.plan_sorted_info(plan.handle, C)
+    assert (plan.ntracks, int(keys), int(lds)) == {30: (30, 12, 17920), 40: (40, 16, 20480), 20: (20, 10, 14080)}[plan.ntracks], \
+        (plan.ntracks, keys, lds)
     bufs = []
     try:
         ts = dev.DeviceBuffer(4 * T * C); bufs.append(ts)

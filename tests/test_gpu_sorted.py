@@ -1,7 +1,7 @@
 """Sorted-list kernel (kernels_sorted.hip, XMHW_LAYOUT_SORTED = 40): the K largest keys of every row-list sorted in
 LDS, a pointer per list, a parallel merge-select that moves the pointers per row.  It serves every row of a plan on its
 own chunks and step-table rows (doy 60, partial years: tests/test_sorted_plan.py); cell-rows whose lists are too short
-are flagged and recomputed (kernels_redo.hip).  Raw thresh must be bit-identical to the generic kernel (an independent
+are recomputed inside the kernel by the whole wave (pool_order_stats).  Raw thresh must be bit-identical to the generic kernel (an independent
 algorithm) and to the oracle; seas is a float64 sum of the same samples in another order.
 """
 import numpy as np

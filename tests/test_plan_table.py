@@ -106,7 +106,7 @@ def test_ring2_layout_choice():
         return Plan(ora.add_doy(t), w, ring2=ring2)
 
     # round 5: records of 9..48 tracks run on the sorted-list kernel (layout 40); the ring layouts below are what the same
-    # plans run on for quantiles below 0.75, for float64 input and when forced (XMHW_SORTED=0 / layout=...)
+    # plans run on for quantiles below 0.85, for float64 input and when forced (XMHW_SORTED=0 / layout=...)
     assert years(40).ring2_in_use() == 40 and years(39).ring2_in_use() == 40 and years(9).ring2_in_use() == 40
     assert years(48).ring2_in_use() == 40 and years(20).ring2_in_use() == 40
     assert Plan(np.tile(np.arange(1, 1461), 20), 5).ring2_in_use() == 40     # config 5's tstep axis

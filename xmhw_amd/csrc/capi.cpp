@@ -1336,8 +1336,7 @@ int xmhw_plan_sorted_info(const xmhw_plan* plan, int64_t C, int32_t* keys_per_li
     const int32_t k = xmhw::sorted_pick_k(plan->host.w, plan->host.ntracks);
     if (k == 0) return fail(XMHW_ERR_UNSUPPORTED, "the sorted-list kernel is not instantiated for this window / record length");
     if (keys_per_list) *keys_per_list = k;
-    // (kernels_sorted.hip: lists with two sentinel words and a dummy list up to K = 12, bare lists and four padding rows above)
-    if (lds_bytes_per_wave) *lds_bytes_per_wave = (k <= 12 ? plan->host.R * (k + 2) + 2 : plan->host.R * k + 4) * 32 * 4;
+    if (lds_bytes_per_wave) *lds_bytes_per_wave = xmhw::sorted_lds_bytes(plan->host.w, plan->host.ntracks);
     if (pieces) {
         const int64_t waves = (std::max<int64_t>(C, 1) + 31) / 32;
         *pieces = static_cast<int32_t>(plan->host.nchunks_req > 0 ? plan->host.nchunks_req : (1536 + waves - 1) / waves);

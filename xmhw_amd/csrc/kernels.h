@@ -82,7 +82,8 @@ hipError_t launch_ring3_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, 
 // float32 (or int16 codes read in place), on its own chunks and table rows (plan.h: sorted_plan).  A cell-row the select
 // cannot settle (a row-list too short for it) is recomputed exactly inside the kernel, by the whole wave, from the samples.
 int32_t sorted_pick_yps(int32_t w, int32_t ntracks);     // tracks per lane, 0 if not instantiated
-int32_t sorted_pick_k(int32_t w, int32_t ntracks);       // keys stored per row-list, 0 if not instantiated
+int32_t sorted_pick_k(int32_t w, int32_t ntracks);       // keys kept per row-list, 0 if not instantiated
+int32_t sorted_lds_bytes(int32_t w, int32_t ntracks);    // LDS of a wave (32 cells): 11 lists x the ranks kept in LDS, in 1,280-byte pieces
 // the device behaviour the kernel's rank-major lists rely on (an LDS read outside the allocation returns 0): *d_bad = 0 if it holds
 hipError_t sorted_lds_probe(uint32_t* d_bad, hipStream_t stream);
 hipError_t launch_sorted_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,

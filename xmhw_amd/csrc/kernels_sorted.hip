@@ -373,6 +373,28 @@ __device__ __forceinline__ void sorted_body(
     uint32_t e_alo = 0, e_ahi = 0, e_n = 0;
     double e_total = 0.0, e_g = 0.0;
 
+    int32_t ep_s = -1;             // (wave-uniform) the row whose epilogue is due (-1: none), and its parity in the chunk
+    uint32_t ep_eph = 0;
+    auto finish_rows = [&]() {
+        double th = make_nan(), se = make_nan();
+        if (e_n > 0) {
+            double v_lo = static_cast<double>(key_f32(e_alo));
+            double v_hi = static_cast<double>(key_f32(e_ahi));
+            se = e_total / static_cast<double>(e_n);
+            if constexpr (PACKED) {
+                v_lo = packed_value(pk, v_lo);
+                v_hi = packed_value(pk, v_hi);
+                se = packed_value(pk, se);
+            }
+            th = numpy_lerp(v_lo, v_hi, e_g);
+        }
+        if (static_cast<uint32_t>(sub) <= ep_eph && cell_ok) {
+            const int64_t row = static_cast<int64_t>(ep_s) - static_cast<int64_t>(ep_eph) + sub;
+            thresh[row * ldo + cell] = th;
+            seas[row * ldo + cell] = se;
+        }
+        ep_s = -1;
+    };
     bool nan_mode = false;         // (wave-uniform) the last plain row had a NaN sample
     uint32_t vi_n = 0xFFFFFFFFu, vi_lo = 0;      // the pool size the quantile position below was computed for
     double vi_g = 0.0;
@@ -503,6 +525,7 @@ __device__ __forceinline__ void sorted_body(
 #pragma unroll
         for (int y = YPS; y < HE; ++y) k[y] = 0u;
         tick(6);
+        if (ep_s >= 0) finish_rows();        // the outputs of the two rows before this one (see 5. below)
         // prefetch: the samples of step s + 1, into the same registers
         if (s + 1 < ch.end) {
             if (sf_nxt & 2u) advance();
@@ -1057,30 +1080,19 @@ __device__ __forceinline__ void sorted_body(
                 e_total = total;
                 e_g = g;
             }
+            // (... at the START of the next row, between its key conversion and the requests for the row after: a wave waits for
+            // its samples with s_waitcnt vmcnt, which counts loads and stores alike in issue order -- stores issued here, behind
+            // the requests, are what the next row's wait for its last sample would have to sit out as well)
             if (eph == 1u || s + 1 == ch.end) {
-                double th = make_nan(), se = make_nan();
-                if (e_n > 0) {
-                    double v_lo = static_cast<double>(key_f32(e_alo));
-                    double v_hi = static_cast<double>(key_f32(e_ahi));
-                    se = e_total / static_cast<double>(e_n);
-                    if constexpr (PACKED) {
-                        v_lo = packed_value(pk, v_lo);
-                        v_hi = packed_value(pk, v_hi);
-                        se = packed_value(pk, se);
-                    }
-                    th = numpy_lerp(v_lo, v_hi, e_g);
-                }
-                if (static_cast<uint32_t>(sub) <= eph && cell_ok) {
-                    const int64_t row = static_cast<int64_t>(s) - static_cast<int64_t>(eph) + sub;
-                    thresh[row * ldo + cell] = th;
-                    seas[row * ldo + cell] = se;
-                }
+                ep_s = s;
+                ep_eph = eph;
             }
         }
         tick(4);
         sf_cur = sf_nxt;
         sf_nxt = __builtin_amdgcn_readfirstlane(sf_nn);
     }
+    if (ep_s >= 0) finish_rows();
     if (STATS && stats != nullptr) {
         if (lane == 0) {
             atomicAdd(&stats[0], static_cast<unsigned long long>(st_rows));
@@ -1217,6 +1229,12 @@ int32_t sorted_pick_k(int32_t w, int32_t ntracks) {
     if (w != 5) return 0;
     const SortedEntry* e = find_sorted((ntracks + 1) / 2);
     return e ? e->k : 0;
+}
+
+int32_t sorted_lds_bytes(int32_t w, int32_t ntracks) {
+    if (w != 5) return 0;
+    const SortedEntry* e = find_sorted((ntracks + 1) / 2);
+    return e ? (11 * e->kl * 128 + kLdsGranule - 1) / kLdsGranule * kLdsGranule : 0;
 }
 
 hipError_t launch_sorted_f32(const float* ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* table,
