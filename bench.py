@@ -92,7 +92,10 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N>1: strong = one grid split over the ranks (default); weak = a full grid per rank")
     ap.add_argument("--cells", type=int, default=0, help="total cells (strong) / cells per GPU (weak, N=1); 0: the preset's")
-    ap.add_argument("--slabs", type=int, default=0, help="launches per step (0: 1 at N=1, 4 at N>1)")
+    ap.add_argument("--slabs", type=int, default=0, help="launches per step (0: 1 at N=1, max(4, N) at N>1)")
+    ap.add_argument("--single-gather", action="store_true",
+                    help="N>1: ONE launch and ONE xmhw_gather_blocks per step (north_star's single RCCL gather; nothing of it is "
+                         "hidden behind compute) instead of a gather per slab behind the later slabs' kernels")
     ap.add_argument("--finish-stream", type=int, default=-1,
                     help="1: the finish kernel of a slab runs on a second stream behind its ring kernel and overlaps the "
                          "next slab's ring kernel (default: on when a step has more than one slab)")
@@ -459,7 +462,9 @@ def run(args):
     main_timed = args.dtype == "f32" and plan.kernel == "ring"
     if main_timed:
         h.plan_set_timing(plan.handle, 1)
-    nslab = args.slabs or (4 if use_dist else 1)
+    # N > 1: the last slab's gather is the part of the exchange nothing hides -- more slabs make it smaller (8 at N = 8:
+    # 1/8 of a rank's block instead of 1/4); --single-gather: one launch, one gather, all of it exposed
+    nslab = 1 if args.single_gather else (args.slabs or (max(4, world) if use_dist else 1))
     edges = [C * i // nslab for i in range(nslab + 1)]
     slabs = [(edges[i], edges[i + 1]) for i in range(nslab) if edges[i + 1] > edges[i]]
 
@@ -562,7 +567,8 @@ def run(args):
                         + f", {ps['years'][0]}-{ps['years'][1]} (T={T}), windowHalfWidth={w}, pctile={pctile}, "
                           f"smoothPercentileWidth={width}, nan_frac={ps['nan']}, skipna={ps['skipna']}",
             "cells_per_step": cells_per_step, "cells_rank0": C, "T": T, "D": D, "kernel": kname, "slabs": len(slabs),
-            "gather": "xmhw_gather_blocks (RCCL send/recv) to rank 0, per slab on a second stream" if use_dist else "none",
+            "gather": ("none" if not use_dist else "ONE xmhw_gather_blocks (RCCL send/recv) to rank 0 per step (--single-gather)" if args.single_gather
+                       else "xmhw_gather_blocks (RCCL send/recv) to rank 0, per slab on a second stream"),
         },
         "roofline": {
             "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -207,7 +207,7 @@ enum {
                                         merge-select, 32 cells per wave, every row of the plan (chunks with their own
                                         table rows: plan.h); a cell-row whose lists are too short is recomputed inside
                                         the kernel.  float32 (or int16 codes), w = 5, 9..48 tracks.  NOTE: 40 means
-                                        "sorted for quantiles >= 0.85": a call with a smaller quantile runs the same plan
+                                        "sorted for quantiles >= 0.85 or <= 0.15": a call with a quantile in between runs the same plan
                                         on its ring layout (xmhw_plan_layout_in_use cannot know the call's quantile).
                                         Needs a device whose LDS reads outside the allocation return 0 (gfx950; probed
                                         once per device, otherwise the ring layouts serve the plan) */

@@ -230,7 +230,7 @@ def test_random_cases_equal_generic_kernel(dev):
 
 def test_fuzz_generator_cases_on_the_two_tier_lists(dev):
     """40 draws of tools/fuzz_ring2.py's generator restricted to records of 37..40 years (the instantiations whose lists keep
-    14 ranks in LDS and two in registers, round 6) and percentiles >= 85: partial years, quantised values (heaps of ties),
+    14 ranks in LDS and two in registers, round 6) and percentiles >= 85 or <= 15 (mirrored): partial years, quantised values (heaps of ties),
     NaN shares up to 95 %, infinities, constant cells, clusters of adjacent keys, cold spells, forced chunk counts --
     against the generic kernel, thresh bit for bit.  Draw 485 of seed 601 is the case that caught a wrong carried boundary
     after a recomputed cell-row (quantised cold-spell data on a 38.5-year record): it is replayed first."""
@@ -239,12 +239,12 @@ def test_fuzz_generator_cases_on_the_two_tier_lists(dev):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     import fuzz_ring2 as fz
 
-    def draws(seed, want):
+    def draws(seed, want, low):
         rng = np.random.default_rng(seed)
         i = 0
         while True:
             x, doy, pct, tstep, cold, nchunks = fz.random_ring2_case(rng, (37, 41))
-            if pct < 85:
+            if pct < 85 and not (low and pct <= 15):      # (the replayed draw was numbered among the high percentiles only)
                 continue
             plan = dev.Plan(doy, 5)
             ok = plan.layout_in_use() == 40
@@ -257,6 +257,24 @@ def test_fuzz_generator_cases_on_the_two_tier_lists(dev):
             if i > max(want):
                 return
 
-    for seed, want in ((601, {485}), (77, set(range(40)))):
-        for i, x, doy, pct, tstep, cold, nchunks in draws(seed, want):
+    for seed, want, low in ((601, {485}, False), (77, set(range(40)), True)):
+        for i, x, doy, pct, tstep, cold, nchunks in draws(seed, want, low):
             fz.check_ring2_case(dev, x, doy, pct, tstep, cold, nchunks, sorted_only=True, msg=f"seed {seed} draw {i}")
+
+
+@pytest.mark.parametrize("q", [0.10, 0.05, 0.15, 0.0, 0.013])
+@pytest.mark.parametrize("years,negate", [(40, False), (40, True), (30, False), (13, True)])
+def test_low_percentiles_run_mirrored_on_the_sorted_kernel(dev, q, years, negate):
+    """q <= 0.15 (round 6): the lists keep the K SMALLEST samples of a step (keys of the negated samples), the top set is the
+    lo + 1 smallest of the pool.  Against the generic kernel and the oracle: thresh bit for bit -- position and weight come
+    from the caller's q, so numpy's interpolation is reproduced, not its mirror image.  NaN holes, quantised values (ties),
+    a steep cycle that overflows lists, an all-NaN cell."""
+    doy = _daily(1980, 1980 + years - 1)
+    x = _series(doy.shape[0], 45, 900 + years, nanfrac=0.02, quant=0.01 if years == 30 else None, amp=(0.5, 14))
+    x[:, 7] = np.nan
+    x[100:180, 3] = np.nan
+    tg, sg, _ = _check(dev, x, doy, q=q, negate=negate)
+    xs = -x.astype(np.float64) if negate else x.astype(np.float64)
+    _, th, se = fast.raw_clim(xs, doy, q, 5)
+    npt.assert_array_equal(tg, th)
+    npt.assert_allclose(sg, se, rtol=1e-12, equal_nan=True)

@@ -224,7 +224,7 @@ def main():
     ap.add_argument("--years", type=int, nargs=2, default=None, metavar=("FIRST", "PAST_LAST"),
                     help="record lengths drawn (default 9 49); 37 41 = the sorted-list kernel's two-tier lists (round 6)")
     ap.add_argument("--sorted-only", action="store_true",
-                    help="f32: percentiles >= 85 and the sorted-list layout (40) against the generic kernel only -- five times the cases per minute")
+                    help="f32: percentiles >= 85 or <= 15 and the sorted-list layout (40) against the generic kernel only -- five times the cases per minute")
     args = ap.parse_args()
     from xmhw_amd._lib import require_gpu
     require_gpu()
@@ -236,7 +236,7 @@ def main():
         done = refused = 0
         while done < args.cases:
             x, doy, pct, tstep, cold, nchunks = random_ring2_case(rng, (9, 49))
-            if pct < 85:
+            if 15 < pct < 85:
                 continue
             try:
                 check_packed_case(dev, x, doy, pct, cold, rng, msg=f"seed {args.seed} case {done}: T={x.shape[0]} C={x.shape[1]} pct={pct} cold={cold}")
@@ -262,7 +262,7 @@ def main():
     while i < args.cases:
         x, doy, pct, tstep, cold, nchunks = random_ring2_case(rng, yrs)
         if args.sorted_only:
-            if pct < 85:
+            if 15 < pct < 85:
                 continue
             plan = dev.Plan(doy, 5)
             ok = plan.ring2_in_use() == 40

@@ -24,7 +24,7 @@ def main():
     while True:
         x, doy, pct, tstep, cold, nchunks = fz.random_ring2_case(rng, tuple(args.years))
         if args.sorted_only:
-            if pct < 85:
+            if 15 < pct < 85:
                 continue
             plan = dev.Plan(doy, 5)
             ok = plan.ring2_in_use() == 40

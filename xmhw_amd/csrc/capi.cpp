@@ -51,8 +51,10 @@ namespace {
 
 constexpr int kSubs = 8;
 // the sorted-list kernel keeps the K largest keys of a row-list, K sized for the top tenth of the pool (four times a list's
-// average share): quantiles from here up.  Below, a list's share outgrows K and too many cell-rows would be recomputed.
+// average share): quantiles from here up -- and, mirrored (the K smallest keys: round 6), from 1 - that down.  In between a
+// list's share outgrows K and too many cell-rows would be recomputed: those calls run on the ring layout.
 constexpr double kSortedMinQ = 0.85;
+inline bool sorted_serves(double q) { return q >= kSortedMinQ || q <= 1.0 - kSortedMinQ; }
 
 }  // namespace
 
@@ -462,7 +464,7 @@ int clim_raw(xmhw_plan* plan, const T* ts, int64_t C, int64_t ld, double q, int 
         if constexpr (sizeof(T) == 4) {
             // float32: the sorted-list kernel on the regular rows (high percentiles: a list keeps its K largest keys),
             // the ring kernel on the others, the generic kernel on the cell-rows the sorted kernel flagged
-            const bool sorted = plan->nchunks_s > 0 && q >= kSortedMinQ;
+            const bool sorted = plan->nchunks_s > 0 && sorted_serves(q);
             const xmhw::DevChunk* rchunks = sorted ? plan->d_chunks_i : plan->d_chunks;
             const int32_t rn = sorted ? plan->nchunks_i : plan->nchunks;
             unsigned long long* rstats = sorted ? nullptr : plan->d_stats;
@@ -1389,8 +1391,8 @@ int xmhw_clim_raw_i16(xmhw_plan* plan, const int16_t* codes, int64_t C, int64_t 
     // serve (w = 5, 9..48 tracks, quantile >= 0.85).  Anything else: xmhw_decode() + xmhw_clim_raw_f32 / _f64.
     int rc = upload(plan, C);
     if (rc != XMHW_OK) return rc;
-    if (!(plan->nchunks_s > 0 && q >= kSortedMinQ))
-        return fail(XMHW_ERR_UNSUPPORTED, "packed input runs on the sorted-list kernel only (w = 5, 9..48 tracks, quantile >= 0.85): "
+    if (!(plan->nchunks_s > 0 && sorted_serves(q)))
+        return fail(XMHW_ERR_UNSUPPORTED, "packed input runs on the sorted-list kernel only (w = 5, 9..48 tracks, quantile >= 0.85 or <= 0.15): "
                                          "decode the series (xmhw_decode) and call xmhw_clim_raw_f32 / _f64");
     xmhw::PackedI16 pk;
     pk.swap = big_endian ? 1 : 0;

@@ -266,7 +266,12 @@ __device__ __forceinline__ void sorted_body(
     // (the chunk's own table and flag rows: row of step s = trow0 + s - warm_start)
     const int32_t step_min = ch.warm_start - ch.trow0;
     const char* col = static_cast<const char*>(ts) + (cell_ok ? cell : C - 1) * static_cast<int64_t>(ES);
-    const uint32_t sgnflip = negate ? 0x80000000u : 0u;
+    // LOW quantiles (q <= 0.15: the launchers admit q >= 0.85 and q <= 0.15) run MIRRORED: the lists keep the K SMALLEST
+    // samples of a step -- the keys are those of the negated samples, so "largest" means smallest --, the top set is the
+    // lo + 1 smallest of the pool, its smallest member (mirrored order) is a[lo] and the largest key outside it a[lo + 1].
+    // Position and weight (lo, g) come from the caller's q as always, so the interpolation is numpy's, bit for bit.
+    const bool mirror = q < 0.5;
+    const int kneg = (negate != 0) != mirror ? 1 : 0;      // the keys are those of the negated samples
     const uint32_t tmax = static_cast<uint32_t>(Tn - 1);
     const bool padded_last = (YPS - 1) * 2 + sub >= ntracks;
     const uint32_t padmask = padded_last ? 0xFFFFFFFFu : 0u;
@@ -380,6 +385,10 @@ __device__ __forceinline__ void sorted_body(
         if (e_n > 0) {
             double v_lo = static_cast<double>(key_f32(e_alo));
             double v_hi = static_cast<double>(key_f32(e_ahi));
+            if (mirror) {                    // (the keys were those of the negated samples)
+                v_lo = -v_lo;
+                v_hi = -v_hi;
+            }
             se = e_total / static_cast<double>(e_n);
             if constexpr (PACKED) {
                 v_lo = packed_value(pk, v_lo);
@@ -452,7 +461,7 @@ __device__ __forceinline__ void sorted_body(
             // rows take the general path below, which gives the same keys)
             // (cold spells: key(-x) and -sum(x), one instruction per sample less than negating the samples)
             double din1 = 0.0;
-            if (negate) {
+            if (kneg) {
 #pragma unroll
                 for (int y = 0; y < YPS; ++y) {
                     uint32_t xb = __float_as_uint(xv[y]);
@@ -467,7 +476,6 @@ __device__ __forceinline__ void sorted_body(
                     else din = y == 0 ? dv : din + dv;
                 }
                 din += din1;
-                din = -din;
             } else {
 #pragma unroll
                 for (int y = 0; y < YPS; ++y) {
@@ -484,6 +492,7 @@ __device__ __forceinline__ void sorted_body(
                 }
                 din += din1;
             }
+            if (negate) din = -din;
             nvin = padded_last ? YPS - 1 : YPS;
             slow = __any(din != din);
             nan_mode = slow;      // (rows with NaN come in runs -- masked data: the next row goes straight to the general path)
@@ -500,7 +509,7 @@ __device__ __forceinline__ void sorted_body(
             nvin = 0;
             // (the key through the two-instruction conversion, zeroed for a NaN or absent sample; the sample itself zeroed
             // before it is widened; cold spells: key(-x) and the sum negated once)
-            if (negate) {
+            if (kneg) {
 #pragma unroll
                 for (int y = 0; y < YPS; ++y) {
                     const float xs = xv[y];
@@ -509,7 +518,6 @@ __device__ __forceinline__ void sorted_body(
                     din += static_cast<double>(ok ? xs : 0.0f);
                     nvin += ok ? 1u : 0u;
                 }
-                din = -din;
             } else {
 #pragma unroll
                 for (int y = 0; y < YPS; ++y) {
@@ -520,6 +528,7 @@ __device__ __forceinline__ void sorted_body(
                     nvin += ok ? 1u : 0u;
                 }
             }
+            if (negate) din = -din;
             if (sf & 1u) nan_mode = __any(nvin != static_cast<uint32_t>(padded_last ? YPS - 1 : YPS));
         }
 #pragma unroll
@@ -666,7 +675,7 @@ __device__ __forceinline__ void sorted_body(
         g = vi_g;
         const uint32_t lo = vi_lo;
         const bool need2 = lo + 1 < nn;
-        const uint32_t Cs = n ? n - 1u - lo : 0u;
+        const uint32_t Cs = n ? (mirror ? lo + 1u : n - 1u - lo) : 0u;
         // Direction of the cell: GROW (keys join the top set, largest first) or SHRINK (keys leave it, smallest first).
         // Shrinking cells work on NEGATED keys (2^32 - key), so that "the key that moves next" is the largest one for
         // everybody and 0 -- no key: an invalid sample, a position outside the list -- stays the lowest for both.
@@ -909,7 +918,11 @@ __device__ __forceinline__ void sorted_body(
         const uint32_t kl = cpl(TL), kn = cpl(TN);
         a_lo = grow ? kn : kl;
         a_hi = grow ? (steps0 != 0u ? kl : um) : kn;
-        a_hi = need2 ? a_hi : a_lo;
+        // (no a[lo + 1] -- lo = n - 1 --: both keys are a[lo], the key outside the top set or, mirrored, its smallest member)
+        if (!need2) {
+            if (mirror) a_lo = a_hi;
+            else a_hi = a_lo;
+        }
         if constexpr (EXT > 0) {
             // ---- 4c. the register ranks.  The select above knows the LDS ranks only: its top set is the Cs largest of THOSE
             // keys.  A register key can belong to the true top set only if its list's KL LDS keys are all inside (it is below
@@ -973,7 +986,11 @@ __device__ __forceinline__ void sorted_body(
                 pvs += swp(pvs);
                 if (fix) {
                     a_lo = vlast;
-                    a_hi = need2 ? hm : vlast;
+                    a_hi = hm;
+                    if (!need2) {
+                        if (mirror) a_lo = a_hi;
+                        else a_hi = a_lo;
+                    }
                     Ctop = Cs - pvs;
                     // both register keys of a list inside and more valid keys than the K the cell keeps: the list may hide keys
                     // above the boundary (its last kept key lies above it) -- the row goes to the recomputation
@@ -1015,7 +1032,9 @@ __device__ __forceinline__ void sorted_body(
                 fm &= fm - 1ull;
                 const int64_t cc = static_cast<int64_t>(blockIdx.x) * 32 + (L >> 1);
                 const uint32_t n_c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(n), L));
-                const uint32_t lo_c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lo), L));
+                uint32_t lo_c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lo), L));
+                // (mirrored keys: ascending index i of the keys is index n - 1 - i of the samples; wanted: a[lo + 1] and a[lo])
+                if (mirror) lo_c = lo_c + 1u < n_c ? n_c - 2u - lo_c : 0u;
                 const uint32_t guess = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(a_lo), L));
                 uint32_t key[KPL];
                 {
@@ -1047,13 +1066,15 @@ __device__ __forceinline__ void sorted_body(
                             xs = raw[i];
                         }
                         const bool ok = xs == xs && (ent[i] >> 1) >= 2u;
-                        const uint32_t kk = negate ? key_fast<true>(__float_as_uint(xs)) : key_fast<false>(__float_as_uint(xs));
+                        const uint32_t kk = kneg ? key_fast<true>(__float_as_uint(xs)) : key_fast<false>(__float_as_uint(xs));
                         key[i] = ok ? kk : 0u;
                     }
                 }
                 uint32_t r_lo = 0, r_hi = 0;
                 pool_order_stats<KPL>(key, n_c, lo_c, guess, r_lo, r_hi);
                 const bool mine = (lane >> 1) == (L >> 1);
+                // (mirror, no a[lo + 1] -- lo = n - 1 --: the one key asked for is a[lo])
+                if (mirror && !(lo_c + 1u < n_c && n_c >= 2u)) r_hi = r_lo;
                 a_lo = mine ? r_lo : a_lo;
                 a_hi = mine ? r_hi : a_hi;
                 flag = mine ? false : flag;
@@ -1074,8 +1095,8 @@ __device__ __forceinline__ void sorted_body(
             // and every second row (and at the end of the chunk) each lane finishes ITS row.
             const uint32_t eph = static_cast<uint32_t>(s - ch.begin) & 1u;
             if (static_cast<uint32_t>(sub) == eph) {
-                e_alo = a_lo;
-                e_ahi = a_hi;
+                e_alo = mirror ? a_hi : a_lo;        // a[lo]
+                e_ahi = mirror ? a_lo : a_hi;        // a[lo + 1]
                 e_n = n;
                 e_total = total;
                 e_g = g;

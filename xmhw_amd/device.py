@@ -816,7 +816,7 @@ def calc_clim_grid_device(stacked, doy, anynans, pctile, windowHalfWidth, smooth
         # decode pass.  Not with maxPadLength (interpolation needs decoded samples) nor when detect() will want the decoded
         # series next (resident).  XMHW_PACKED_DIRECT=0 turns it off.
         direct = (is_packed(stacked) and stacked.dtype.kind == "i" and stacked.dtype.itemsize == 2 and pad is None
-                  and resident is None and kernel == "auto" and pctile / 100.0 >= 0.85 and plan.layout_in_use() == LAYOUTS["sorted"]
+                  and resident is None and kernel == "auto" and (pctile / 100.0 >= 0.85 or pctile / 100.0 <= 0.15) and plan.layout_in_use() == LAYOUTS["sorted"]
                   and _os.environ.get("XMHW_PACKED_DIRECT", "1") != "0")
         recipe = packed_recipe(stacked) if direct else None
         # slab k+1 is uploaded (and decoded) by a second thread while slab k computes
