@@ -11,6 +11,15 @@ indices only), used by kernels_sorted.hip.  A comparator (i, j) leaves max at i 
   BitonicDesc<N>     sorts a BITONIC sequence of N keys (cyclic rotation of rise-then-fall) descending: half-cleaners
                      while N is even, a full network on the odd remainders.
 
+  Ins<N>             (round 6) sorts N keys descending by INSERTION with three-input instructions: a 3-sorter is v_max3 /
+                     v_med3 / v_min3 (3 instructions where 3 comparators are 6), and inserting a key x into a sorted run
+                     a[0..n) is n + 1 independent instructions: max(a0, x), med3(a[i-1], a[i], x), min(a[n-1], x).
+                     N keys cost 3 + 4 + ... + N = N (N + 1) / 2 - 3 instructions: fewer than the comparator network's
+                     2 x comparators up to N = 9 (5 keys: 12 against 18) -- used for the halves of the 10-key sorts
+                     (two Ins<5> + MergeTop<5,5,10> = 50 instructions against 58).  min / med / max commute with every
+                     monotone map, so the 0-1 principle holds for these circuits too; all 0-1 inputs AND all
+                     permutations (N <= 7) are checked.
+
 Every emitted network is verified before it is written: Desc and BitonicDesc with the 0-1 principle over all inputs of
 their class, MergeTop over all pairs of sorted 0-1 runs and on random keys with ties.
 Usage: python tools/gen_sortnet.py            (writes the header; prints the comparator counts)
@@ -264,6 +273,47 @@ def emit(out, name, nslots, net, perm, nout):
     out.append("    }")
 
 
+INSERTION = [3, 4, 5, 6, 7]
+
+
+def insertion_program(n):
+    """[(op, dst, srcs)]: a 3-sorter, then n - 3 insertions; registers are numbered, inputs 0..n-1"""
+    prog = [("max3", n, (0, 1, 2)), ("med3", n + 1, (0, 1, 2)), ("min3", n + 2, (0, 1, 2))]
+    srt = [n, n + 1, n + 2]
+    nxt = n + 3
+    for k in range(3, n):
+        new = []
+        prog.append(("max", nxt, (srt[0], k))); new.append(nxt); nxt += 1
+        for i in range(1, k):
+            prog.append(("med3", nxt, (srt[i - 1], srt[i], k))); new.append(nxt); nxt += 1
+        prog.append(("min", nxt, (srt[k - 1], k))); new.append(nxt); nxt += 1
+        srt = new
+    prog.append(("out", None, tuple(srt)))
+    return prog[:-1] + [prog[-1]]
+
+
+def verify_insertion(n, prog):
+    ops = {"max3": max, "min3": min, "max": max, "min": min, "med3": lambda *a: sorted(a)[1]}
+    def run(inp):
+        r = dict(enumerate(inp))
+        for op, dst, src in prog:
+            if op == "out":
+                return [r[i] for i in src]
+            r[dst] = ops[op](*[r[i] for i in src])
+    for bits in itertools.product((0, 1), repeat=n):
+        if run(bits) != sorted(bits, reverse=True):
+            return False
+    for perm in itertools.permutations(range(n)):
+        if run(perm) != sorted(perm, reverse=True):
+            return False
+    rng = np.random.default_rng(n)
+    for _ in range(2000):                    # (ties)
+        x = list(rng.integers(0, 3, n))
+        if run(x) != sorted(x, reverse=True):
+            return False
+    return True
+
+
 def main():
     out = []
     out.append("// sortnet_gen.h -- GENERATED by tools/gen_sortnet.py; do not edit.")
@@ -323,6 +373,41 @@ def main():
         out.append(f"// n = {n}: {len(net)} comparators, depth {depth(net)}")
         out.append(f"template <> struct BitonicDesc<{n}> {{")
         emit(out, "BitonicDesc", n, net, perm, n)
+        out.append("};")
+    # ---- insertion sorters on three-input instructions --------------------------------------------------------
+    out.append("// N keys -> descending, by insertion with three-input instructions (v_max3 / v_med3 / v_min3): see tools/gen_sortnet.py")
+    out.append("__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {")
+    out.append("    uint32_t r;")
+    out.append('    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));')
+    out.append("    return r;")
+    out.append("}")
+    out.append("__device__ __forceinline__ uint32_t max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }")
+    out.append("__device__ __forceinline__ uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }")
+    out.append("template <int N> struct Ins;")
+    for n in INSERTION:
+        prog = insertion_program(n)
+        assert verify_insertion(n, prog), n
+        report.append(f"Ins<{n}>: {len(prog) - 1} three-input instructions")
+        out.append(f"// n = {n}: {len(prog) - 1} instructions")
+        out.append(f"template <> struct Ins<{n}> {{")
+        out.append(f"    static __device__ __forceinline__ void run(uint32_t (&v)[{n}]) {{")
+        tmp = 0
+        cur = [f"v[{i}]" for i in range(n)]
+        # 3-sorter
+        out.append(f"        uint32_t s0 = max_u32(max_u32({cur[0]}, {cur[1]}), {cur[2]}), s1 = med3_u32({cur[0]}, {cur[1]}, {cur[2]}), "
+                   f"s2 = min_u32(min_u32({cur[0]}, {cur[1]}), {cur[2]});")
+        srt = ["s0", "s1", "s2"]
+        for k in range(3, n):
+            x = cur[k]
+            new = [f"t{k}_{i}" for i in range(k + 1)]
+            parts = [f"{new[0]} = max_u32({srt[0]}, {x})"]
+            for i in range(1, k):
+                parts.append(f"{new[i]} = med3_u32({srt[i - 1]}, {srt[i]}, {x})")
+            parts.append(f"{new[k]} = min_u32({srt[k - 1]}, {x})")
+            out.append("        const uint32_t " + ", ".join(parts) + ";")
+            srt = new
+        out.append("        " + " ".join(f"v[{i}] = {srt[i]};" for i in range(n)))
+        out.append("    }")
         out.append("};")
     out.append("#undef XMHW_CE")
     out.append("}  // namespace sortnet")

@@ -108,6 +108,29 @@ __device__ __forceinline__ uint32_t count_ge4(uint32_t a0, uint32_t a1, uint32_t
 }
 
 typedef uint32_t V8 __attribute__((ext_vector_type(8)));
+
+// N unsorted keys -> descending.  Up to 7 keys by insertion with three-input instructions (sortnet::Ins: a 3-sorter is
+// v_max3 / v_med3 / v_min3, an insertion into a sorted run of n is n + 1 independent instructions); 8, 10 and 12 keys as two
+// such halves + the merge network of two sorted runs (10 keys: 12 + 12 + 26 = 50 instructions against the 29-comparator
+// network's 58); 9 and 11 keys on the comparator networks.
+template <int N>
+__device__ __forceinline__ void sort_desc(uint32_t (&v)[N]) {
+    if constexpr (N >= 3 && N <= 7) {
+        sortnet::Ins<N>::run(v);
+    } else if constexpr (N == 8 || N == 10 || N == 12) {
+        constexpr int H = N / 2;
+        uint32_t a[H], b[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) { a[i] = v[i]; b[i] = v[H + i]; }
+        sortnet::Ins<H>::run(a);
+        sortnet::Ins<H>::run(b);
+#pragma unroll
+        for (int i = 0; i < H; ++i) { v[i] = a[i]; v[H + i] = b[i]; }
+        sortnet::MergeTop<H, H, N>::run(v);
+    } else {
+        sortnet::Desc<N>::run(v);
+    }
+}
 // LDS is handed out in pieces of 1,280 bytes on gfx950 (160 KB / 128; tools/ubench_ldsoob.hip: a read at the first byte
 // behind an allocation rounded up to that returns 0, the bytes between the declared size and that do not)
 constexpr int kLdsGranule = 1280;
@@ -552,8 +575,8 @@ __device__ __forceinline__ void sorted_body(
                 uint32_t h0[HH], h1[HH];
 #pragma unroll
                 for (int i = 0; i < HH; ++i) { h0[i] = k[i]; h1[i] = k[HH + i]; }
-                sortnet::Desc<HH>::run(h0);
-                sortnet::Desc<HH>::run(h1);
+                sort_desc<HH>(h0);
+                sort_desc<HH>(h1);
 #pragma unroll
                 for (int i = 0; i < HH; ++i) { ka[i] = h0[i]; ka[HH + i] = h1[i]; }
             }
