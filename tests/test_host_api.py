@@ -164,3 +164,19 @@ def test_product_path_fails_loudly_without_gpu(oisst):
         assert "hip" in type(e.value).__name__.lower() or "hip" in str(e.value).lower()
     else:
         pytest.skip("a GPU is present")
+
+
+def test_packed_recipe_ignores_a_fill_value_no_int16_code_can_equal():
+    """ADVICE r5: a NaN / infinite / fractional / out-of-range _FillValue on an int16 variable means "nothing is missing";
+    int() of a NaN or an infinity used to raise before the range check was reached"""
+    import xmhw_amd.device as dev
+
+    class View:
+        dtype = np.dtype("<i2")
+
+        def __init__(self, fill):
+            self.decode = {"scale": 0.01, "offset": 0.0, "fill": fill, "out": "float32"}
+
+    for fill, want in ((float("nan"), None), (float("inf"), None), (-float("inf"), None), (1.5, None), (40000, None),
+                       (-999, -999), (-32768.0, -32768), (None, None)):
+        assert dev.packed_recipe(View(fill))["fill"] == want, fill

@@ -516,7 +516,8 @@ def packed_recipe(stacked):
     """the CF recipe of an int16 file view as xmhw_clim_raw_i16 / xmhw_land_mask_i16 take it"""
     d = stacked.decode
     fill = d.get("fill")
-    if fill is not None and not (float(fill) == int(fill) and -32768 <= int(fill) <= 32767):
+    # (a NaN or infinite _FillValue on an int16 variable -- int() of it would raise -- equals no code either)
+    if fill is not None and not (np.isfinite(float(fill)) and float(fill) == int(fill) and -32768 <= int(fill) <= 32767):
         fill = None                                      # no int16 code equals it: nothing is missing
     big = stacked.dtype.byteorder == ">" or (stacked.dtype.byteorder == "=" and not np.little_endian)
     return dict(scale=d.get("scale"), offset=d.get("offset"), fill=None if fill is None else int(fill),
