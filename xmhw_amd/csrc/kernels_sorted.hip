@@ -108,6 +108,12 @@ __device__ __forceinline__ uint32_t count_ge4(uint32_t a0, uint32_t a1, uint32_t
 }
 
 typedef uint32_t V8 __attribute__((ext_vector_type(8)));
+// (branches most rows do not take: their blocks go behind the loop's hot path)
+#ifdef XMHW_NO_COLD
+#define XMHW_COLD(x) (x)
+#else
+#define XMHW_COLD(x) __builtin_expect(!!(x), 0)
+#endif
 
 // N unsorted keys -> descending.  Up to 7 keys by insertion with three-input instructions (sortnet::Ins: a 3-sorter is
 // v_max3 / v_med3 / v_min3, an insertion into a sorted run of n is n + 1 independent instructions); 8, 10 and 12 keys as two
@@ -520,7 +526,7 @@ __device__ __forceinline__ void sorted_body(
             slow = __any(din != din);
             nan_mode = slow;      // (rows with NaN come in runs -- masked data: the next row goes straight to the general path)
         }
-        if (slow) {
+        if (XMHW_COLD(slow)) {
             uint32_t e[YPS];
             if (sf & 1u) {
 #pragma unroll
@@ -560,7 +566,7 @@ __device__ __forceinline__ void sorted_body(
         if (ep_s >= 0) finish_rows();        // the outputs of the two rows before this one (see 5. below)
         // prefetch: the samples of step s + 1, into the same registers
         if (s + 1 < ch.end) {
-            if (sf_nxt & 2u) advance();
+            if (!XMHW_COLD(!(sf_nxt & 2u))) advance();
             else point_at(s + 1);
             request();
         }
@@ -686,7 +692,7 @@ __device__ __forceinline__ void sorted_body(
 #endif
         // (n is the same for every cell on every row of gap-free data: the float64 position is redone only when some cell's
         // count has changed)
-        if (__any(n != vi_n)) {
+        if (XMHW_COLD(__any(n != vi_n))) {
             vi_n = n;
             const uint32_t nn_ = n ? n : 1u;
             const double vi = static_cast<double>(nn_ - 1) * q;
@@ -738,7 +744,7 @@ __device__ __forceinline__ void sorted_body(
             // After a row's first round two rounds in three have at most three keys left to move in their worst cell (an
             // unsafe window, more than 15 steps): those are moved ONE BY ONE -- the largest of the 22 list heads, six reads and
             // ~70 instructions a key instead of a round's 390.
-            if (!first_round && !__any(pending && rem > kSerialMax)) {
+            if (XMHW_COLD(!first_round && !__any(pending && rem > kSerialMax))) {
                 while (__any(pending)) {
                     if constexpr (STATS) ++st_serial;
                     uint32_t hd[NL];
@@ -881,7 +887,7 @@ __device__ __forceinline__ void sorted_body(
                 pj[j] = count_ge4(a[j][0], a[j][1], a[j][2], a[j][3], th);
                 psum += pj[j];
             }
-            if (__any(tie)) {
+            if (XMHW_COLD(__any(tie))) {
                 asm volatile("" ::: "memory");          // (keep this a branch: plain rows never come here)
                 // the d-th and the (d+1)-th key are equal: of the keys equal to tl only d - #{keys above tl} move, lists in
                 // order (lane 0 first)
@@ -929,7 +935,11 @@ __device__ __forceinline__ void sorted_body(
                 pending = !(dry || (rem == 0u && !unsafe));
             }
         }
+#ifdef XMHW_COLD_TN
+        if (XMHW_COLD(__any(!tn_ok))) {
+#else
         if (__any(!tn_ok)) {
+#endif
             // the key that would move next, from the lists' heads
             uint32_t hx = 0;
 #pragma unroll
@@ -961,7 +971,7 @@ __device__ __forceinline__ void sorted_body(
                 need += pv[j];
             }
             need += swp(need);
-            if (__any(need != 0u)) {
+            if (XMHW_COLD(__any(need != 0u))) {
                 asm volatile("" ::: "memory");
                 if constexpr (STATS) ++st_ext;
                 const bool fix = need != 0u;
@@ -1029,7 +1039,7 @@ __device__ __forceinline__ void sorted_body(
 #pragma unroll
             for (int j = 0; j < NL; ++j)
                 atb |= (P[j] == static_cast<uint32_t>(K) && ((truncmask >> j) & 1u)) ? (1u << j) : 0u;     // (never the dummy: no bit)
-            if (__any(atb != 0u)) {
+            if (XMHW_COLD(__any(atb != 0u))) {
 #pragma unroll
                 for (int j = 0; j < NL; ++j) {
                     const uint32_t Uj = lds_ld(lbase[j] + static_cast<uint32_t>(K - 1) * RSTRIDE);
@@ -1046,7 +1056,7 @@ __device__ __forceinline__ void sorted_body(
         }
         if constexpr (STATS) st_flag += (sub == 0 && cell_ok && flag) ? 1u : 0u;
         tick(3);
-        if (s >= ch.begin && __any(flag)) {
+        if (XMHW_COLD(s >= ch.begin && __any(flag))) {
             // ---- 4b. the flagged cells of this row, one after the other, by the whole wave (pool_order_stats above) ---------
             constexpr int KPL = (NTP * R + 63) / 64;
             unsigned long long fm = __builtin_amdgcn_ballot_w64(flag && sub == 0 && cell_ok);
