@@ -215,6 +215,11 @@ enum {
 int xmhw_plan_set_layout(xmhw_plan *plan, int32_t layout);
 /* the layout float32 input of this plan will run on (XMHW_LAYOUT_RING1 if the round-1 / generic kernel) */
 int xmhw_plan_layout_in_use(const xmhw_plan *plan, int32_t *layout);
+/* whether the current device may run the sorted-list kernel: its rank-major lists rely on LDS reads outside a workgroup's
+ * allocation returning 0 (gfx950 does: tools/ubench_ldsoob.hip).  Probed on the device the first time it is asked for
+ * (seven allocation sizes x 2,048 workgroups, a few microseconds) and remembered per device; *holds = 1 / 0.  Plans on a
+ * device where it does not hold run on their ring layout whatever xmhw_plan_layout_in_use says (which needs no device). */
+int xmhw_sorted_device_ok(int32_t *holds);
 /* DEPRECATED names of the two entries above (rounds 2 and 3, when the numbers meant variants of the
  * second-generation kernel); also accepted: 1..7, 9, 11 = measured-and-rejected alternatives of round 2,
  * built with -DXMHW_RING2_EXPERIMENTS only; 30..32 = the round-4 key-store experiment

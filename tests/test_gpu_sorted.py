@@ -278,3 +278,8 @@ def test_low_percentiles_run_mirrored_on_the_sorted_kernel(dev, q, years, negate
     _, th, se = fast.raw_clim(xs, doy, q, 5)
     npt.assert_array_equal(tg, th)
     npt.assert_allclose(sg, se, rtol=1e-12, equal_nan=True)
+
+
+def test_the_device_answers_lds_reads_outside_the_allocation_with_zero(dev):
+    """what the rank-major lists rely on: probed by the library itself, seven allocation sizes x 2,048 workgroups"""
+    assert dev.hip().sorted_device_ok() is True

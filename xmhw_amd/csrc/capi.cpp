@@ -1212,6 +1212,13 @@ int xmhw_plan_set_layout(xmhw_plan* plan, int32_t layout) {
     plan->ring2_variant = layout;
     return XMHW_OK;
 }
+int xmhw_sorted_device_ok(int32_t* holds) {
+    if (!holds) return fail(XMHW_ERR_INVALID, "NULL argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return fail(XMHW_ERR_HIP, "no HIP device");
+    *holds = sorted_device_ok() == 1 ? 1 : 0;
+    return XMHW_OK;
+}
 int xmhw_plan_layout_in_use(const xmhw_plan* plan, int32_t* layout) {
     if (!plan || !layout) return fail(XMHW_ERR_INVALID, "NULL argument");
     if (sorted_usable(plan)) { *layout = XMHW_LAYOUT_SORTED; return XMHW_OK; }

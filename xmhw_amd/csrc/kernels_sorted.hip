@@ -1232,9 +1232,8 @@ const SortedEntry* find_sorted(int32_t yps) {
 // base.  Every such read must return 0.  Many workgroups per CU, so that the bytes behind an allocation belong to a
 // neighbour that has just written its own pattern.
 namespace {
-template <int BYTES>
-__global__ __launch_bounds__(64) void lds_outside_probe(uint32_t* __restrict__ bad) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[BYTES / 4];
+__global__ __launch_bounds__(64) void lds_outside_probe(uint32_t* __restrict__ bad, int BYTES) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];       // (BYTES of dynamic LDS: one kernel for every size)
     for (int i = threadIdx.x; i < BYTES / 4; i += 64) lds[i] = 0x80000000u | (blockIdx.x << 16) | static_cast<uint32_t>(i);
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
@@ -1263,13 +1262,8 @@ hipError_t sorted_lds_probe(uint32_t* d_bad, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     // (the allocation sizes of the instantiations: K = 6 .. 18 keys per list, each rounded up to the 1,280-byte piece)
-    hipLaunchKernelGGL(lds_outside_probe<8960>, dim3(2048), dim3(64), 0, stream, d_bad);
-    hipLaunchKernelGGL(lds_outside_probe<11520>, dim3(2048), dim3(64), 0, stream, d_bad);
-    hipLaunchKernelGGL(lds_outside_probe<14080>, dim3(2048), dim3(64), 0, stream, d_bad);
-    hipLaunchKernelGGL(lds_outside_probe<17920>, dim3(2048), dim3(64), 0, stream, d_bad);
-    hipLaunchKernelGGL(lds_outside_probe<20480>, dim3(2048), dim3(64), 0, stream, d_bad);
-    hipLaunchKernelGGL(lds_outside_probe<23040>, dim3(2048), dim3(64), 0, stream, d_bad);
-    hipLaunchKernelGGL(lds_outside_probe<25600>, dim3(2048), dim3(64), 0, stream, d_bad);
+    for (int bytes : {8960, 11520, 14080, 17920, 20480, 23040, 25600})
+        hipLaunchKernelGGL(lds_outside_probe, dim3(2048), dim3(64), static_cast<size_t>(bytes), stream, d_bad, bytes);
     return hipGetLastError();
 }
 

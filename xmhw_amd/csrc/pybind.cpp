@@ -163,6 +163,7 @@ PYBIND11_MODULE(_xmhw_hip, m) {
     m.def("debug_stats_available", []() { return xmhw_debug_stats_available() != 0; });
     m.def("plan_set_layout", [](uintptr_t p, int layout) { check(xmhw_plan_set_layout(pp(p), layout)); });
     m.def("plan_layout_in_use", [](uintptr_t p) { int32_t v = -1; check(xmhw_plan_layout_in_use(pp(p), &v)); return v; });
+    m.def("sorted_device_ok", []() { int32_t v = 0; check(xmhw_sorted_device_ok(&v)); return v != 0; });
     m.def("plan_ring2_in_use", [](uintptr_t p) { int32_t v = -1; check(xmhw_plan_ring2_in_use(pp(p), &v)); return v; });
     m.def("plan_f64_mode", [](uintptr_t p) { int32_t v = -1; check(xmhw_plan_f64_mode(pp(p), &v)); return v; });
     m.def("plan_set_ring2", [](uintptr_t p, int variant) { check(xmhw_plan_set_ring2(pp(p), variant)); });
