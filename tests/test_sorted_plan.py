@@ -87,12 +87,13 @@ def test_record_ending_on_feb_29():
     _check(_daily("1981-03-01", "2020-03-01"))
 
 
-@pytest.mark.parametrize("years,k,lds", [(20, 10, (11 * 12 + 2) * 128), (30, 12, (11 * 14 + 2) * 128), (36, 14, (11 * 14 + 4) * 128),
-                                         (40, 16, (11 * 16 + 4) * 128), (45, 18, (11 * 18 + 4) * 128)])
-def test_keys_per_list_and_lds_bytes_per_wave(years, k, lds):
-    """xmhw_plan_sorted_info: keys stored per row-list and the LDS a wave of 32 cells takes -- lists with two sentinel
-    words and a dummy list up to K = 12, bare lists and four padding rows above (23,040 bytes at K = 16: exactly what 7 waves
-    per CU leave a wave of the 160 KB, handed out in 512-byte pieces)"""
+@pytest.mark.parametrize("years,k,lds,waves", [(20, 10, 14080, 8), (30, 12, 17920, 8), (36, 14, 20480, 8), (40, 16, 20480, 8),
+                                               (45, 18, 25600, 6)])
+def test_keys_per_list_and_lds_bytes_per_wave(years, k, lds, waves):
+    """xmhw_plan_sorted_info: keys a cell keeps of every row-list and the LDS a wave of 32 cells takes -- rank-major lists,
+    11 x the ranks kept in LDS x 128 bytes, rounded up to the 1,280-byte piece LDS is handed out in on gfx950 (round 6: no
+    sentinels, no padding rows; 37..40 tracks keep 16 keys, 14 of them in LDS: 20,480 bytes = 8 waves per CU -- the
+    registers' limit, two waves per SIMD)"""
     from xmhw_amd.device import Plan
     import xmhw_amd.device as dev
     time = np.arange("1980-01-01", f"{1980 + years}-01-01", dtype="datetime64[D]")
@@ -100,7 +101,6 @@ def test_keys_per_list_and_lds_bytes_per_wave(years, k, lds):
     try:
         got_k, got_lds, pieces = dev.hip().plan_sorted_info(plan.handle, 1036800)
         assert (got_k, got_lds) == (k, lds) and pieces >= 1
-        if k == 16:
-            assert (160 * 1024) // (512 * ((got_lds + 511) // 512)) == 7
+        assert got_lds % 1280 == 0 and min(8, (160 * 1024) // got_lds) == waves
     finally:
         plan.destroy()
