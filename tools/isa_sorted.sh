@@ -26,4 +26,9 @@ for name, ins, ln in blocks:
     if v >= 15:
         print(f"{name:12s} line {ln:5d} valu {v:4d} ds {sum(1 for o in ins if o.startswith('ds_')):3d} salu {sum(1 for o in ins if o.startswith('s_') and not o.startswith('s_waitcnt') and not o.startswith('s_nop')):3d} nop {sum(1 for o in ins if o.startswith('s_nop')):2d} vmem {sum(1 for o in ins if o.startswith('global')):2d}")
 PY
+# vmcnt waits inside the row loop: the key conversion's 20 (one per sample, the last one vmcnt(0)) are what the loop needs; the
+# address rebuild of irregular steps has 20 more (a cold block).  ANY other vmcnt wait in the hot blocks (sort, bookkeeping,
+# select) sits out the requests for the next row's samples -- the prefetch is gone and the kernel 12 % slower (round 6: a
+# register shared between a cold path's load and a key made the compiler put one in front of the sort).
+echo "s_waitcnt vmcnt(0) in the row loop at lines: $(grep -n 's_waitcnt vmcnt(0)' /tmp/isa/k20.s | awk -F: '$1 > 440 && $1 < 3300 {printf "%s ", $1}') (expected: two -- the conversion's and the cold address rebuild's)"
 grep -A12 "clim_sorted_f32ILi20ELi16ELi14ELb0" /tmp/isa/res.txt | grep -E "VGPRs:|SGPRs:|Occupancy|LDS Size|Scratch" | head -6

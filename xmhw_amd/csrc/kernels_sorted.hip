@@ -114,6 +114,11 @@ typedef uint32_t V8 __attribute__((ext_vector_type(8)));
 #else
 #define XMHW_COLD(x) __builtin_expect(!!(x), 0)
 #endif
+#define XMHW_STR2(x) #x
+#define XMHW_STR(x) XMHW_STR2(x)
+#ifndef XMHW_LOOP_PAD
+#define XMHW_LOOP_PAD 0
+#endif
 
 // N unsorted keys -> descending.  Up to 7 keys by insertion with three-input instructions (sortnet::Ins: a 3-sorter is
 // v_max3 / v_med3 / v_min3, an insertion into a sorted run of n is n + 1 independent instructions); 8, 10 and 12 keys as two
@@ -441,6 +446,9 @@ __device__ __forceinline__ void sorted_body(
     int m = ((ch.warm_start % R) + R) % R;
     uint32_t sf_cur = __builtin_amdgcn_readfirstlane(sflags[ch.warm_start - step_min]);
     uint32_t sf_nxt = ch.warm_start + 1 < ch.end ? __builtin_amdgcn_readfirstlane(sflags[ch.warm_start + 1 - step_min]) : 0u;
+#ifdef XMHW_LOOP_ALIGN
+    asm volatile(".p2align " XMHW_STR(XMHW_LOOP_ALIGN) "\n\t.rept " XMHW_STR(XMHW_LOOP_PAD) "\n\ts_nop 0\n\t.endr" ::: "memory");
+#endif
     for (int32_t s = ch.warm_start; s < ch.end; ++s) {
         const uint32_t sf = sf_cur;
         // (the flags of step s + 2 are asked for a row ahead: nothing waits for them)
@@ -527,36 +535,29 @@ __device__ __forceinline__ void sorted_body(
             nan_mode = slow;      // (rows with NaN come in runs -- masked data: the next row goes straight to the general path)
         }
         if (XMHW_COLD(slow)) {
-            uint32_t e[YPS];
-            if (sf & 1u) {
-#pragma unroll
-                for (int y = 0; y < YPS; ++y) e[y] = (y == YPS - 1 && padded_last) ? 2u : 4u;
-            } else {
-                entries_of(s, e);
-            }
             din = 0.0;
             nvin = 0;
             // (the key through the two-instruction conversion, zeroed for a NaN or absent sample; the sample itself zeroed
-            // before it is widened; cold spells: key(-x) and the sum negated once)
-            if (kneg) {
-#pragma unroll
-                for (int y = 0; y < YPS; ++y) {
-                    const float xs = xv[y];
-                    const bool ok = xs == xs && (e[y] >> 1) >= 2u;
-                    k[y] = ok ? key_fast<true>(__float_as_uint(xs)) : 0u;
-                    din += static_cast<double>(ok ? xs : 0.0f);
-                    nvin += ok ? 1u : 0u;
-                }
+            // before it is widened; cold spells: key(-x) and the sum negated once.  A SIMPLE row -- every real track pushes a
+            // sample: masked data, configs[3] -- only has NaN to look for; the other rows also ask the step table)
+#define XMHW_GENERAL_ROW(NEG_, OKEXPR)                                                                  \
+    _Pragma("unroll") for (int y = 0; y < YPS; ++y) {                                                   \
+        const float xs = xv[y];                                                                          \
+        const bool ok = xs == xs && (OKEXPR);                                                            \
+        k[y] = ok ? key_fast<NEG_>(__float_as_uint(xs)) : 0u;                                            \
+        din += static_cast<double>(ok ? xs : 0.0f);                                                      \
+        nvin += ok ? 1u : 0u;                                                                            \
+    }
+            if (sf & 1u) {
+                if (kneg) { XMHW_GENERAL_ROW(true, !(y == YPS - 1 && padded_last)) }
+                else { XMHW_GENERAL_ROW(false, !(y == YPS - 1 && padded_last)) }
             } else {
-#pragma unroll
-                for (int y = 0; y < YPS; ++y) {
-                    const float xs = xv[y];
-                    const bool ok = xs == xs && (e[y] >> 1) >= 2u;
-                    k[y] = ok ? key_fast<false>(__float_as_uint(xs)) : 0u;
-                    din += static_cast<double>(ok ? xs : 0.0f);
-                    nvin += ok ? 1u : 0u;
-                }
+                uint32_t e[YPS];
+                entries_of(s, e);
+                if (kneg) { XMHW_GENERAL_ROW(true, (e[y] >> 1) >= 2u) }
+                else { XMHW_GENERAL_ROW(false, (e[y] >> 1) >= 2u) }
             }
+#undef XMHW_GENERAL_ROW
             if (negate) din = -din;
             if (sf & 1u) nan_mode = __any(nvin != static_cast<uint32_t>(padded_last ? YPS - 1 : YPS));
         }
