@@ -1,4 +1,4 @@
-// kernels_sorted.hip -- fifth-generation climatology kernel (round 5): selection on SORTED ROW-LISTS in LDS.
+// kernels_sorted.hip -- the climatology kernel of rounds 5 and 6: selection on SORTED ROW-LISTS in LDS.
 //
 // What the ring kernels (kernels_ring*.hip) keep in registers -- the R = 2w+1 last samples of every track -- is not
 // kept at all here.  The pool of a row is the union of the R last ROW-LISTS (the samples all tracks push at one step),
@@ -10,7 +10,9 @@
 //     wave (cell-minor: per-lane dynamic positions never meet on a bank).  A window that reaches past the last rank of
 //     its list -- or above rank 0: the address wraps around -- leaves the workgroup's LDS allocation, and an LDS read
 //     outside the allocation returns 0 on gfx950 (tools/ubench_ldsoob.hip; the library checks it once per device
-//     before it uses this kernel): 0 is the "no key" value, so no list needs sentinels, clamps or masks;
+//     before it uses this kernel): 0 is the "no key" value, so no list needs sentinels, clamps or masks.  The records of
+//     37..40 tracks keep TWO TIERS: 14 ranks in LDS (20,480 bytes per wave: 8 waves per CU) and ranks 14, 15 in registers
+//     of the lane that owns the list's slot; a short correction after the select lets them join the top set (4c);
 //   * per list a POINTER P_i = the number of its keys inside the TOP SET (the Cs largest keys of the pool,
 //     Cs = n - 1 - lo, lo = floor((n - 1) q)): order statistic lo of numpy's linear quantile is the largest key outside
 //     the top set (max over the lists of key[P_i]), lo + 1 the smallest inside (min of key[P_i - 1]);
@@ -22,7 +24,8 @@
 //     more than 15 keys) takes another round, or -- at most three keys left in the wave's worst cell -- is finished key
 //     by key from the 22 list heads;
 //   * `seas` = (sum of the 11 lists' float64 sums, added in slot order every row) / n: the same bits for every cut of
-//     the row axis.
+//     the row axis;
+//   * quantiles <= 0.15 run MIRRORED: keys of the negated samples, the top set = the lo + 1 smallest of the pool.
 //
 // Everything is exact.  What can fail is the capacity of a list: a list whose K stored keys are all inside the top set
 // while it holds more valid keys than K (a steep seasonal slope puts up to ~20 of a list's 40 keys among the 44
@@ -33,7 +36,13 @@
 //
 // The kernel runs on its OWN chunks and step-table rows (plan.cpp: sorted_plan): the row axis is cut wherever the set
 // of pooled tracks changes (a held step -- doy 60 --, the ends of partial years); inside a chunk every pooled track
-// pushes at every row, warms up with its R-1 last pushes before the chunk, and the other tracks push nothing.
+// pushes at every row, warms up with its R-1 last pushes before the chunk, and the other tracks push nothing.  Warm-up
+// rows only build lists; the chunk's first output row grows the top set from nothing.
+//
+// Two things about the compiled loop that cost or bought several per cent each (profiles/r6_experiments.txt): the branches
+// most rows do not take are marked XMHW_COLD so that their blocks sit behind the loop, and NO `s_waitcnt vmcnt` may appear
+// in the sort / bookkeeping / select blocks -- the requests for the next row's samples are in flight there
+// (tools/check_sorted_waits.py, tests/test_kernel_isa.py).
 //
 // Lane layout: lane = 2 * cell_in_wave + sub; a wave is 32 cells = one 128-byte line of a float32 sample row; a
 // workgroup is one wave.  Track k of the plan sits in lane sub = k % 2, slot k / 2 (the y-major table of the ring
