@@ -88,7 +88,7 @@ def test_record_ending_on_feb_29():
 
 
 @pytest.mark.parametrize("years,k,lds,waves", [(20, 10, 14080, 8), (30, 12, 17920, 8), (36, 14, 20480, 8), (40, 16, 20480, 8),
-                                               (45, 18, 25600, 6)])
+                                               (45, 18, 23040, 7)])
 def test_keys_per_list_and_lds_bytes_per_wave(years, k, lds, waves):
     """xmhw_plan_sorted_info: keys a cell keeps of every row-list and the LDS a wave of 32 cells takes -- rank-major lists,
     11 x the ranks kept in LDS x 128 bytes, rounded up to the 1,280-byte piece LDS is handed out in on gfx950 (round 6: no

@@ -295,7 +295,8 @@ __device__ __forceinline__ void sorted_body(
     // whose 14 LDS keys are all inside the top set and whose 15th key lies above the boundary is then put right by a
     // short correction (4c below): its register keys join the top set and as many of the smallest keys leave it.
     constexpr int EXT = K - KL;
-    static_assert(EXT == 0 || (EXT == 2 && KL >= KH), "two register ranks, both from lane 1's half");
+    static_assert(EXT == 0 || ((EXT == 2 || EXT == 4) && KL >= KH), "two or four register ranks, all from lane 1's half");
+    constexpr int EXN = EXT > 0 ? EXT : 1;
     static_assert(LDS_BYTES == 8960 || LDS_BYTES == 11520 || LDS_BYTES == 14080 || LDS_BYTES == 17920 || LDS_BYTES == 20480 ||
                   LDS_BYTES == 23040 || LDS_BYTES == 25600, "sorted_lds_probe() checks these allocation sizes");
     __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_BYTES / 4];
@@ -352,9 +353,9 @@ __device__ __forceinline__ void sorted_body(
     rs_lo = 0;
     rs_hi = 0;
     static_assert(KL >= 5, "a list holds a window");
-    V8 ex0, ex1;                                 // EXT: ranks KL and KL + 1 of the own lists
-    ex0 = 0;
-    ex1 = 0;
+    V8 ex[EXN];                                  // EXT: ranks KL .. K - 1 of the own lists (static indices only)
+#pragma unroll
+    for (int e_ = 0; e_ < EXN; ++e_) ex[e_] = 0;
     uint32_t truncmask = 0;
     // cell-level state, the same in both lanes
     // (B = the carried boundary: the key outside the top set.  During a chunk's warm-up rows nothing is selected -- the lists
@@ -630,7 +631,7 @@ __device__ __forceinline__ void sorted_body(
         const uint32_t base_m = lcell + static_cast<uint32_t>(m) * LSTRIDE + static_cast<uint32_t>(sub * KH) * RSTRIDE;
 #pragma unroll
         for (int i = 0; i < KH; ++i) {
-            // (EXT: lane 1's last two keys -- ranks KL, KL + 1 -- are not for LDS: the rows behind the lists stay 0)
+            // (EXT: lane 1's last keys -- ranks KL .. K - 1 -- are not for LDS: the rows behind the lists stay 0)
             if (EXT == 0 || i < KH - EXT || sub == 0) lds_st(base_m + static_cast<uint32_t>(i) * RSTRIDE, u[i]);
         }
         // what leaves: the evicted list's share of the top set, its valid keys, its sum
@@ -666,10 +667,12 @@ __device__ __forceinline__ void sorted_body(
         };
         put(P, c_new);
         if constexpr (EXT > 0) {
-            // (ranks KL and KL + 1 are lane 1's last two keys; the lane that owns slot m keeps them)
-            const uint32_t r0_ = swp(u[KH - 2]), r1_ = swp(u[KH - 1]);
-            put(ex0, sub ? u[KH - 2] : r0_);
-            put(ex1, sub ? u[KH - 1] : r1_);
+            // (ranks KL .. K - 1 are lane 1's last keys; the lane that owns slot m keeps them)
+#pragma unroll
+            for (int e_ = 0; e_ < EXT; ++e_) {
+                const uint32_t r_ = swp(u[KH - EXT + e_]);
+                put(ex[e_], sub ? u[KH - EXT + e_] : r_);
+            }
         }
         if (own_m) truncmask = (truncmask & ~(1u << mj)) | ((nvin > static_cast<uint32_t>(K) ? 1u : 0u) << mj);
         {
@@ -977,7 +980,10 @@ __device__ __forceinline__ void sorted_body(
 #pragma unroll
             for (int j = 0; j < NL; ++j) {
                 const bool sat = P[j] == static_cast<uint32_t>(KL) && !flag;
-                pv[j] = sat ? ((ex0[j] > a_lo ? 1u : 0u) + (ex1[j] > a_lo ? 1u : 0u)) : 0u;
+                uint32_t c_ = 0;
+#pragma unroll
+                for (int e_ = 0; e_ < EXT; ++e_) c_ += ex[e_][j] > a_lo ? 1u : 0u;
+                pv[j] = sat ? c_ : 0u;
                 need += pv[j];
             }
             need += swp(need);
@@ -992,7 +998,9 @@ __device__ __forceinline__ void sorted_body(
                     uint32_t hm = 0xFFFFFFFFu;
 #pragma unroll
                     for (int j = 0; j < NL; ++j) {
-                        const uint32_t ev = pv[j] == 2u ? ex1[j] : ex0[j];
+                        uint32_t ev = ex[0][j];          // (the list's smallest register key inside: rank KL + pv - 1)
+#pragma unroll
+                        for (int e_ = 1; e_ < EXT; ++e_) ev = pv[j] > static_cast<uint32_t>(e_) ? ex[e_][j] : ev;
                         hd[j] = (pv[j] != 0u ? ev : lv[j]) - 1u;
                         hm = umin(hm, hd[j]);
                     }
@@ -1035,10 +1043,10 @@ __device__ __forceinline__ void sorted_body(
                         else a_hi = a_lo;
                     }
                     Ctop = Cs - pvs;
-                    // both register keys of a list inside and more valid keys than the K the cell keeps: the list may hide keys
+                    // every register key of a list inside and more valid keys than the K the cell keeps: the list may hide keys
                     // above the boundary (its last kept key lies above it) -- the row goes to the recomputation
 #pragma unroll
-                    for (int j = 0; j < NL; ++j) flag = flag || (pv[j] == 2u && ((truncmask >> j) & 1u));
+                    for (int j = 0; j < NL; ++j) flag = flag || (pv[j] == static_cast<uint32_t>(EXT) && ((truncmask >> j) & 1u));
                 }
             }
         } else {
@@ -1213,6 +1221,10 @@ struct SortedEntry { int yps, k, kl; SortedKernel fn, fn_stats; SortedKernelI16 
 #ifndef XMHW_K40
 #define XMHW_K40 16      // (keys per list of the 37..40-track records ...
 #endif
+#ifndef XMHW_KL48
+#define XMHW_KL48 16     // (41..48 tracks keep 18 keys per list: 16 ranks in LDS = 7 waves per CU instead of 6, two in registers;
+                         //  14 + four in registers = 8 waves was measured slower: 43 tracks 14.8 against 14.55 ms, 48 tracks 17.9 / 15.6)
+#endif
 #ifndef XMHW_KL40
 #define XMHW_KL40 14     //  ... and how many of them live in LDS: 14 = 8 waves per CU, the other two in registers)
 #endif
@@ -1222,7 +1234,7 @@ const SortedEntry kSorted[] = {
 #else
     XMHW_S(5, 6),   XMHW_S(6, 6),   XMHW_S(7, 8),   XMHW_S(8, 8),   XMHW_S(9, 10),  XMHW_S(10, 10), XMHW_S(11, 10),
     XMHW_S(12, 10), XMHW_S(13, 12), XMHW_S(14, 12), XMHW_S(15, 12), XMHW_S(16, 12), XMHW_S(17, 14), XMHW_S(18, 14),
-    XMHW_S2(19, XMHW_K40, XMHW_KL40), XMHW_S2(20, XMHW_K40, XMHW_KL40), XMHW_S(21, 18), XMHW_S(22, 18), XMHW_S(23, 18), XMHW_S(24, 18),
+    XMHW_S2(19, XMHW_K40, XMHW_KL40), XMHW_S2(20, XMHW_K40, XMHW_KL40), XMHW_S2(21, 18, XMHW_KL48), XMHW_S2(22, 18, XMHW_KL48), XMHW_S2(23, 18, XMHW_KL48), XMHW_S2(24, 18, XMHW_KL48),
 #endif
 };
 #undef XMHW_S
