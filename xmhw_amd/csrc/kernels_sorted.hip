@@ -750,7 +750,7 @@ __device__ __forceinline__ void sorted_body(
 #pragma unroll
         for (int j = 0; j < NL; ++j) wbase[j] = lbase[j] - (grow ? 0u : RSTRIDE);
         uint32_t TL = 0, TN = 0;       // negated space: the last key that moved, the key that would move next
-        bool pending = true, tn_ok = true;
+        bool pending = true;
         bool st_first_done = false;
         bool first_round = true;
         while (__any(pending)) {
@@ -788,10 +788,7 @@ __device__ __forceinline__ void sorted_body(
                         Ctop = grow ? Cs - rem : Cs + rem;
                         rem = 0;
                     }
-                    if (act) {
-                        tn_ok = dry_;                                   // (the key that would move next: from the heads, below)
-                        pending = !(dry_ || rem == 0u);
-                    }
+                    if (act) pending = !(dry_ || rem == 0u);
                 }
                 break;
             }
@@ -885,13 +882,11 @@ __device__ __forceinline__ void sorted_body(
                 return z | swp(z);
             };
             const uint32_t tl = rank_of(d - 1u);               // (d == 0: rank 0xFFFFFFFF is outside: 0)
-            const uint32_t tn = rank_of(d);
             // -- how far the windows can be trusted: a key is SAFE if it is not below the largest fifth key
             F = umax(F, swp(F));
             const bool act = pending && d != 0u;
             const bool unsafe = act && tl < F;                 // move only the safe keys this round, look again
             const bool dry = act && !unsafe && tl == 0u;       // fewer than d keys left in the lists: give up
-            const bool tie = act && !unsafe && !dry && tl == tn;
             const uint32_t th = unsafe ? F : tl;
             uint32_t pj[NL];
             uint32_t psum = 0;
@@ -900,6 +895,8 @@ __device__ __forceinline__ void sorted_body(
                 pj[j] = count_ge4(a[j][0], a[j][1], a[j][2], a[j][3], th);
                 psum += pj[j];
             }
+            // (more than d keys at or above the d-th: it is tied with the keys behind it)
+            const bool tie = act && !unsafe && !dry && psum + swp(psum) > d;
             if (XMHW_COLD(__any(tie))) {
                 asm volatile("" ::: "memory");          // (keep this a branch: plain rows never come here)
                 // the d-th and the (d+1)-th key are equal: of the keys equal to tl only d - #{keys above tl} move, lists in
@@ -942,23 +939,19 @@ __device__ __forceinline__ void sorted_body(
             }
             if (pending) {
                 TL = (move && !unsafe) ? tl : TL;
-                TN = tn;
-                // (the key of rank d is the key that would move next unless a list has moved its whole window)
-                tn_ok = dry || d == 0u || tn >= F;
                 pending = !(dry || (rem == 0u && !unsafe));
             }
         }
-#ifdef XMHW_COLD_TN
-        if (XMHW_COLD(__any(!tn_ok))) {
-#else
-        if (__any(!tn_ok)) {
-#endif
-            // the key that would move next, from the lists' heads
+        {
+            // the key that would move next: the largest of the lists' heads (the d + 1-th candidate of the last round is it only
+            // where no list has used up its window -- on most rows some cell's has)
+            uint32_t hv[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) hv[j] = lds_ld(wbase[j] + P[j] * RSTRIDE);
             uint32_t hx = 0;
 #pragma unroll
-            for (int j = 0; j < NL; ++j) hx = umax(hx, cpl(lds_ld(wbase[j] + P[j] * RSTRIDE)));
-            hx = umax(hx, swp(hx));
-            TN = tn_ok ? TN : hx;
+            for (int j = 0; j < NL; ++j) hx = umax(hx, cpl(hv[j]));
+            TN = umax(hx, swp(hx));
         }
         if (!flag) Ctop = Cs;
         const uint32_t kl = cpl(TL), kn = cpl(TN);
