@@ -82,6 +82,14 @@ __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// some lane's condition holds: the ballot compared as a scalar (HIP's __any() goes through a select and a vector compare)
+__device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+// a * b + c, a and b signed 24-bit (the compiler turns a multiplication by +-1 into a negation and a select)
+__device__ __forceinline__ uint32_t mad_i24(uint32_t a, int32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
@@ -116,7 +124,7 @@ __device__ __forceinline__ uint32_t count_ge4(uint32_t a0, uint32_t a1, uint32_t
     return c;
 }
 
-typedef uint32_t V8 __attribute__((ext_vector_type(8)));
+typedef uint32_t V32 __attribute__((ext_vector_type(32)));
 // (branches most rows do not take: their blocks go behind the loop's hot path)
 #ifdef XMHW_NO_COLD
 #define XMHW_COLD(x) (x)
@@ -332,14 +340,18 @@ __device__ __forceinline__ void sorted_body(
     __builtin_amdgcn_wave_barrier();
 
     // own list slots: global slot g = sub * NL + j; P[j] = the list's keys INSIDE the top set = index of the first key outside
-    V8 P;
+    // Per own list: the pointer P (a plain array: the select works on it), and in ONE 32-element register vector TV the float64
+    // sum of its samples (two words side by side: a register pair), the register ranks and its valid keys.  Everything
+    // reads them with static indices but 3. below, which replaces the values of the slot the new list goes to:
+    // vector[wave-uniform index] is ONE v_mov through the index register (s_set_gpr_idx) for vectors of more than eight
+    // elements -- up to eight the compiler expands it into a chain of selects, six a value.
+    uint32_t P[NL];
+    V32 TV = 0;
+#define XMHW_RSLO(j) TV[2 * (j)]
+#define XMHW_RSHI(j) TV[2 * (j) + 1]
+#define XMHW_EX(e, j) TV[12 + 6 * (e) + (j)]
+#define XMHW_NVL(j) TV[24 + (j)]
     uint32_t lbase[NL];                          // address of the list's rank 0
-    // (per own list: its valid keys and the float64 sum of its samples as two words -- register tuples indexed by the
-    // wave-uniform slot number through the index register, like P)
-    // (tuple[slot] with the wave-uniform slot number: six selects under scalar conditions, written out -- pick() / put()
-    // below; an eight-element vector indexed by a variable costs the compiler seven selects a read and sixteen a masked
-    // write, and a plain array indexed that way goes to scratch memory)
-    V8 nvl, rs_lo, rs_hi;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
         const int g = sub * NL + j;
@@ -347,16 +359,8 @@ __device__ __forceinline__ void sorted_body(
         lbase[j] = g < R ? lcell + static_cast<uint32_t>(g) * LSTRIDE : 0x40000000u + lcell;
         P[j] = 0;
     }
-    P[6] = 0;
-    P[7] = 0;
-    nvl = 0;
-    rs_lo = 0;
-    rs_hi = 0;
     static_assert(KL >= 5, "a list holds a window");
-    V8 ex[EXN];                                  // EXT: ranks KL .. K - 1 of the own lists (static indices only)
-#pragma unroll
-    for (int e_ = 0; e_ < EXN; ++e_) ex[e_] = 0;
-    uint32_t truncmask = 0;
+    static_assert(NL == 6 && EXT <= 2, "the register vector holds five values of six lists");
     // cell-level state, the same in both lanes
     // (B = the carried boundary: the key outside the top set.  During a chunk's warm-up rows nothing is selected -- the lists
     // are only built --, the top set stays empty and no new key counts as above the boundary; the chunk's first output row
@@ -494,7 +498,7 @@ __device__ __forceinline__ void sorted_body(
             bool anyfill = false;
 #pragma unroll
             for (int y = 0; y < YPS; ++y) anyfill = anyfill || x_in[y] == pk.fill;
-            if (__any(anyfill)) {
+            if (wave_any(anyfill)) {
 #pragma unroll
                 for (int y = 0; y < YPS; ++y) xv[y] = x_in[y] == pk.fill ? __uint_as_float(0x7FC00000u) : xv[y];
             }
@@ -541,7 +545,7 @@ __device__ __forceinline__ void sorted_body(
             }
             if (negate) din = -din;
             nvin = padded_last ? YPS - 1 : YPS;
-            slow = __any(din != din);
+            slow = wave_any(din != din);
             nan_mode = slow;      // (rows with NaN come in runs -- masked data: the next row goes straight to the general path)
         }
         if (XMHW_COLD(slow)) {
@@ -569,7 +573,7 @@ __device__ __forceinline__ void sorted_body(
             }
 #undef XMHW_GENERAL_ROW
             if (negate) din = -din;
-            if (sf & 1u) nan_mode = __any(nvin != static_cast<uint32_t>(padded_last ? YPS - 1 : YPS));
+            if (sf & 1u) nan_mode = wave_any(nvin != static_cast<uint32_t>(padded_last ? YPS - 1 : YPS));
         }
 #pragma unroll
         for (int y = YPS; y < HE; ++y) k[y] = 0u;
@@ -611,21 +615,6 @@ __device__ __forceinline__ void sorted_body(
         // ---- 3. the new list replaces the list in slot m ----------------------------------------------------------
         const int m_sub = m >= NL ? 1 : 0;
         const int mj = __builtin_amdgcn_readfirstlane(m - m_sub * NL);
-        // (the slot's conditions once, as lane masks the selects below share; kept opaque so that the chain of selects is not
-        // turned back into a load from an array with a variable index -- which would put the tuples into scratch memory)
-        bool is_slot[NL];
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            int mj_ = mj;
-            asm volatile("" : "+s"(mj_));
-            is_slot[j] = mj_ == j;
-        }
-        auto pick = [&](const V8& t) -> uint32_t {
-            uint32_t v = t[0];
-#pragma unroll
-            for (int j = 1; j < NL; ++j) v = is_slot[j] ? t[j] : v;
-            return v;
-        };
         const bool own_m = sub == m_sub;
         // (this lane's first rank of list m: lane 0 holds ranks 0 .. K/2-1, lane 1 the rest)
         const uint32_t base_m = lcell + static_cast<uint32_t>(m) * LSTRIDE + static_cast<uint32_t>(sub * KH) * RSTRIDE;
@@ -636,9 +625,19 @@ __device__ __forceinline__ void sorted_body(
         }
         // what leaves: the evicted list's share of the top set, its valid keys, its sum
         uint32_t c_old = 0, nv_old = 0;
+        // (P[slot]: a chain of selects under scalar conditions)
+        bool is_slot[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            int mj_ = mj;
+            asm volatile("" : "+s"(mj_));
+            is_slot[j] = mj_ == j;
+        }
+        const uint32_t nvm = TV[24 + mj];
         {
-            const uint32_t Pm = pick(P);
-            const uint32_t nvm = pick(nvl);
+            uint32_t Pm = P[0];
+#pragma unroll
+            for (int j = 1; j < NL; ++j) Pm = is_slot[j] ? P[j] : Pm;
             if (own_m) {
                 c_old = Pm;
                 nv_old = nvm;
@@ -661,25 +660,25 @@ __device__ __forceinline__ void sorted_body(
         din += swp(din);
         Ctop += c_new - c_old;
         n += nvin - nv_old;
-        auto put = [&](V8& t, uint32_t x) {
 #pragma unroll
-            for (int j = 0; j < NL; ++j) t[j] = (own_m && is_slot[j]) ? x : t[j];
-        };
-        put(P, c_new);
+        for (int j = 0; j < NL; ++j) P[j] = (own_m && is_slot[j]) ? c_new : P[j];
+        // (the lanes that do not own slot m write back what they hold)
+        TV[24 + mj] = own_m ? nvin : nvm;
         if constexpr (EXT > 0) {
             // (ranks KL .. K - 1 are lane 1's last keys; the lane that owns slot m keeps them)
 #pragma unroll
             for (int e_ = 0; e_ < EXT; ++e_) {
                 const uint32_t r_ = swp(u[KH - EXT + e_]);
-                put(ex[e_], sub ? u[KH - EXT + e_] : r_);
+                const uint32_t mine = sub ? u[KH - EXT + e_] : r_;
+                const uint32_t old_ = TV[12 + 6 * e_ + mj];
+                TV[12 + 6 * e_ + mj] = own_m ? mine : old_;
             }
         }
-        if (own_m) truncmask = (truncmask & ~(1u << mj)) | ((nvin > static_cast<uint32_t>(K) ? 1u : 0u) << mj);
         {
             const uint64_t db = static_cast<uint64_t>(__double_as_longlong(din));
-            put(nvl, nvin);
-            put(rs_lo, static_cast<uint32_t>(db));
-            put(rs_hi, static_cast<uint32_t>(db >> 32));
+            const uint32_t ol_ = TV[2 * mj], oh_ = TV[2 * mj + 1];
+            TV[2 * mj] = own_m ? static_cast<uint32_t>(db) : ol_;
+            TV[2 * mj + 1] = own_m ? static_cast<uint32_t>(db >> 32) : oh_;
         }
         {
             // the pool's total: the 11 list sums added in slot order, every row (a running total would round differently
@@ -687,7 +686,7 @@ __device__ __forceinline__ void sorted_body(
             double tsum = 0.0;
 #pragma unroll
             for (int j = 0; j < NL; ++j)
-                tsum += __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(rs_hi[j]) << 32) | rs_lo[j]));
+                tsum += __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(XMHW_RSHI(j)) << 32) | XMHW_RSLO(j)));
             total = tsum + swp(tsum);
         }
         m = (m + 1 == R) ? 0 : m + 1;
@@ -705,7 +704,7 @@ __device__ __forceinline__ void sorted_body(
 #endif
         // (n is the same for every cell on every row of gap-free data: the float64 position is redone only when some cell's
         // count has changed)
-        if (XMHW_COLD(__any(n != vi_n))) {
+        if (XMHW_COLD(wave_any(n != vi_n))) {
             vi_n = n;
             const uint32_t nn_ = n ? n : 1u;
             const double vi = static_cast<double>(nn_ - 1) * q;
@@ -728,6 +727,7 @@ __device__ __forceinline__ void sorted_body(
         const uint32_t cm = grow ? 0u : 0xFFFFFFFFu;
         const uint32_t cneg = grow ? 0u : 1u;
         auto cpl = [&](uint32_t v) -> uint32_t { return (v ^ cm) + cneg; };      // (its own inverse)
+        const int psign = grow ? 1 : -1;
         const int32_t dstep = grow ? static_cast<int32_t>(RSTRIDE) : -static_cast<int32_t>(RSTRIDE);
         // min over the lists of the smallest key INSIDE the top set (the cells that move nowhere need both sides)
         uint32_t um = 0xFFFFFFFFu;
@@ -750,15 +750,17 @@ __device__ __forceinline__ void sorted_body(
 #pragma unroll
         for (int j = 0; j < NL; ++j) wbase[j] = lbase[j] - (grow ? 0u : RSTRIDE);
         uint32_t TL = 0, TN = 0;       // negated space: the last key that moved, the key that would move next
-        bool pending = true;
+        // (prem = the keys the cell still has to move, 0 once it has given up: what the loop conditions look at)
+        uint32_t prem = rem;
+        uint32_t st_iter_row = 0;
         bool st_first_done = false;
         bool first_round = true;
-        while (__any(pending)) {
+        while (wave_any(prem != 0u)) {
             // After a row's first round two rounds in three have at most three keys left to move in their worst cell (an
             // unsafe window, more than 15 steps): those are moved ONE BY ONE -- the largest of the 22 list heads, six reads and
             // ~70 instructions a key instead of a round's 390.
-            if (XMHW_COLD(!first_round && !__any(pending && rem > kSerialMax))) {
-                while (__any(pending)) {
+            if (XMHW_COLD(!first_round && !wave_any(prem > kSerialMax))) {
+                while (wave_any(prem != 0u)) {
                     if constexpr (STATS) ++st_serial;
                     uint32_t hd[NL];
                     uint32_t hm = 0;
@@ -769,41 +771,47 @@ __device__ __forceinline__ void sorted_body(
                     }
                     const uint32_t ho = swp(hm);
                     const uint32_t cmax = umax(hm, ho);
-                    const bool act = pending;                           // (a pending cell has keys left to move)
+                    const bool act = prem != 0u;                        // (the cell has keys left to move)
                     const bool dry_ = act && cmax == 0u;                // nothing left in the lists: give up (flag)
                     const bool win = act && !dry_ && hm == cmax && (sub == 0 || ho != cmax);     // lane 0 first on a tie
                     bool found = false;
 #pragma unroll
                     for (int j = 0; j < NL; ++j) {
                         const bool sel = win && !found && hd[j] == cmax;
-                        P[j] = sel ? (grow ? P[j] + 1u : P[j] - 1u) : P[j];
+                        P[j] += sel ? static_cast<uint32_t>(psign) : 0u;
                         found = found || sel;
                     }
                     if (act && !dry_) {
                         TL = cmax;
                         rem -= 1u;
                     }
-                    if (dry_) {
-                        flag = true;
-                        Ctop = grow ? Cs - rem : Cs + rem;
-                        rem = 0;
-                    }
-                    if (act) pending = !(dry_ || rem == 0u);
+                    flag = flag | dry_;
+                    prem = flag ? 0u : rem;
                 }
                 break;
             }
             first_round = false;
             if constexpr (STATS) {
                 ++st_iter;
+#if defined(XMHW_HIST_W3)
+                if (false) {
+#elif defined(XMHW_HIST_FIRST)      // (experiment: the histogram is of the row's FIRST round instead -- thresholds XMHW_H1 / XMHW_H2)
+                if (!st_first_done) {
+#else
                 if (st_first_done) {
-                    uint32_t r_ = pending ? rem : 0u;
+#endif
+                    uint32_t r_ = prem;
 #pragma unroll
                     for (int off = 32; off >= 1; off >>= 1) r_ = umax(r_, static_cast<uint32_t>(__shfl_xor(static_cast<int>(r_), off, 64)));
+                    #ifdef XMHW_HIST_FIRST
+                    ++st_more[r_ <= XMHW_H1 ? 1 : r_ <= XMHW_H2 ? 2 : 3];
+#else
                     ++st_more[r_ <= 2u ? 0 : r_ <= 4u ? 1 : r_ <= 8u ? 2 : 3];
+#endif
                 }
                 st_first_done = true;
             }
-            const uint32_t d = umin(rem, 15u);
+            const uint32_t d = umin(prem, 15u);
             // -- the W = 4 next keys of every own list, in the order they would move.  A position past the last rank of
             //    the list, or above rank 0, is outside the allocation and reads 0 -- the LOWEST key in the cell's own order
             uint32_t a[NL][4];
@@ -884,10 +892,25 @@ __device__ __forceinline__ void sorted_body(
             const uint32_t tl = rank_of(d - 1u);               // (d == 0: rank 0xFFFFFFFF is outside: 0)
             // -- how far the windows can be trusted: a key is SAFE if it is not below the largest fifth key
             F = umax(F, swp(F));
-            const bool act = pending && d != 0u;
+            const bool act = d != 0u;
             const bool unsafe = act && tl < F;                 // move only the safe keys this round, look again
             const bool dry = act && !unsafe && tl == 0u;       // fewer than d keys left in the lists: give up
-            const uint32_t th = unsafe ? F : tl;
+            // (a cell that moves nothing this round -- settled, or dry -- counts against a threshold no key reaches: its counts are
+            // 0 and the pointer updates below need no condition)
+            const bool move = act && !dry;
+            const uint32_t th = move ? (unsafe ? F : tl) : 0xFFFFFFFFu;
+#ifdef XMHW_HIST_W3      // (experiment: would windows of THREE keys have been safe in this row's first round?)
+            if constexpr (STATS) {
+                if (st_iter_row == 0) {
+                    uint32_t f3 = 0;
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) f3 = umax(f3, a[j][3]);
+                    f3 = umax(f3, swp(f3));
+                    ++st_more[wave_any(act && tl < f3) ? 2 : 1];
+                }
+                ++st_iter_row;
+            }
+#endif
             uint32_t pj[NL];
             uint32_t psum = 0;
 #pragma unroll
@@ -896,8 +919,9 @@ __device__ __forceinline__ void sorted_body(
                 psum += pj[j];
             }
             // (more than d keys at or above the d-th: it is tied with the keys behind it)
-            const bool tie = act && !unsafe && !dry && psum + swp(psum) > d;
-            if (XMHW_COLD(__any(tie))) {
+            uint32_t moved = psum + swp(psum);
+            const bool tie = move & !unsafe & (moved > d);
+            if (XMHW_COLD(wave_any(tie))) {
                 asm volatile("" ::: "memory");          // (keep this a branch: plain rows never come here)
                 // the d-th and the (d+1)-th key are equal: of the keys equal to tl only d - #{keys above tl} move, lists in
                 // order (lane 0 first)
@@ -924,23 +948,16 @@ __device__ __forceinline__ void sorted_body(
                     ps2 += pt;
                 }
                 psum = tie ? ps2 : psum;
+                moved = psum + swp(psum);
             }
-            const bool move = act && !dry;
-            uint32_t moved = move ? psum : 0u;
-            moved += swp(moved);
 #pragma unroll
-            for (int j = 0; j < NL; ++j)
-                P[j] = move ? (grow ? P[j] + pj[j] : P[j] - pj[j]) : P[j];
+            for (int j = 0; j < NL; ++j) P[j] = mad_i24(pj[j], psign, P[j]);      // (one multiply-add: P +- the list's count)
             rem -= moved;
-            if (dry) {
-                flag = true;
-                Ctop = grow ? Cs - rem : Cs + rem;
-                rem = 0;
-            }
-            if (pending) {
-                TL = (move && !unsafe) ? tl : TL;
-                pending = !(dry || (rem == 0u && !unsafe));
-            }
+            // (a dry cell gives up: the row goes to the recomputation, what it could not move stays in `rem`.  An unsafe round
+            // leaves keys to move, so "keys left" is all the loop has to ask)
+            flag = flag | dry;
+            TL = (move & !unsafe) ? tl : TL;
+            prem = flag ? 0u : rem;
         }
         {
             // the key that would move next: the largest of the lists' heads (the d + 1-th candidate of the last round is it only
@@ -953,7 +970,7 @@ __device__ __forceinline__ void sorted_body(
             for (int j = 0; j < NL; ++j) hx = umax(hx, cpl(hv[j]));
             TN = umax(hx, swp(hx));
         }
-        if (!flag) Ctop = Cs;
+        Ctop = mad_i24(rem, -psign, Cs);      // (Cs, or -- a cell that gave up -- what its pointers hold: Cs -+ the keys not moved)
         const uint32_t kl = cpl(TL), kn = cpl(TN);
         a_lo = grow ? kn : kl;
         a_hi = grow ? (steps0 != 0u ? kl : um) : kn;
@@ -968,20 +985,25 @@ __device__ __forceinline__ void sorted_body(
             // them) and it lies above the boundary.  Such keys join (pv[j] of list j, largest first) and as many keys -- the
             // smallest of the enlarged set, one by one: LDS heads or register keys -- leave.  Ctop keeps counting LDS keys
             // only, so the next row starts from the same kind of state.
-            uint32_t pv[NL];
-            uint32_t need = 0;
+            // (what every row pays: is some saturated list's first register key above the boundary? -- twelve compares and
+            // scalar logic, no branch per list)
+            bool anyx = false;
 #pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                const bool sat = P[j] == static_cast<uint32_t>(KL) && !flag;
-                uint32_t c_ = 0;
-#pragma unroll
-                for (int e_ = 0; e_ < EXT; ++e_) c_ += ex[e_][j] > a_lo ? 1u : 0u;
-                pv[j] = sat ? c_ : 0u;
-                need += pv[j];
-            }
-            need += swp(need);
-            if (XMHW_COLD(__any(need != 0u))) {
+            for (int j = 0; j < NL; ++j) anyx = anyx | ((P[j] == static_cast<uint32_t>(KL)) & (XMHW_EX(0, j) > a_lo));
+            if (XMHW_COLD(wave_any(anyx & !flag))) {
                 asm volatile("" ::: "memory");
+                uint32_t pv[NL];
+                uint32_t need = 0;
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+                    const bool sat = (P[j] == static_cast<uint32_t>(KL)) & !flag;
+                    uint32_t c_ = 0;
+#pragma unroll
+                    for (int e_ = 0; e_ < EXT; ++e_) c_ += XMHW_EX(e_, j) > a_lo ? 1u : 0u;
+                    pv[j] = sat ? c_ : 0u;
+                    need += pv[j];
+                }
+                need += swp(need);
                 if constexpr (STATS) ++st_ext;
                 const bool fix = need != 0u;
                 auto heads = [&](uint32_t (&hd)[NL]) -> uint32_t {     // own lists' smallest inside keys - 1 (none: all ones), their minimum
@@ -991,16 +1013,16 @@ __device__ __forceinline__ void sorted_body(
                     uint32_t hm = 0xFFFFFFFFu;
 #pragma unroll
                     for (int j = 0; j < NL; ++j) {
-                        uint32_t ev = ex[0][j];          // (the list's smallest register key inside: rank KL + pv - 1)
+                        uint32_t ev = XMHW_EX(0, j);          // (the list's smallest register key inside: rank KL + pv - 1)
 #pragma unroll
-                        for (int e_ = 1; e_ < EXT; ++e_) ev = pv[j] > static_cast<uint32_t>(e_) ? ex[e_][j] : ev;
+                        for (int e_ = 1; e_ < EXT; ++e_) ev = pv[j] > static_cast<uint32_t>(e_) ? XMHW_EX(e_, j) : ev;
                         hd[j] = (pv[j] != 0u ? ev : lv[j]) - 1u;
                         hm = umin(hm, hd[j]);
                     }
                     return hm;
                 };
                 uint32_t vlast = a_lo;
-                while (__any(need != 0u)) {
+                while (wave_any(need != 0u)) {
                     uint32_t hd[NL];
                     const uint32_t hm = heads(hd);
                     const uint32_t ho = swp(hm);
@@ -1039,7 +1061,7 @@ __device__ __forceinline__ void sorted_body(
                     // every register key of a list inside and more valid keys than the K the cell keeps: the list may hide keys
                     // above the boundary (its last kept key lies above it) -- the row goes to the recomputation
 #pragma unroll
-                    for (int j = 0; j < NL; ++j) flag = flag || (pv[j] == static_cast<uint32_t>(EXT) && ((truncmask >> j) & 1u));
+                    for (int j = 0; j < NL; ++j) flag = flag || (pv[j] == static_cast<uint32_t>(EXT) && XMHW_NVL(j) > static_cast<uint32_t>(K));
                 }
             }
         } else {
@@ -1049,8 +1071,8 @@ __device__ __forceinline__ void sorted_body(
             uint32_t atb = 0;
 #pragma unroll
             for (int j = 0; j < NL; ++j)
-                atb |= (P[j] == static_cast<uint32_t>(K) && ((truncmask >> j) & 1u)) ? (1u << j) : 0u;     // (never the dummy: no bit)
-            if (XMHW_COLD(__any(atb != 0u))) {
+                atb |= (P[j] == static_cast<uint32_t>(K) && XMHW_NVL(j) > static_cast<uint32_t>(K)) ? (1u << j) : 0u;     // (never the dummy: no bit)
+            if (XMHW_COLD(wave_any(atb != 0u))) {
 #pragma unroll
                 for (int j = 0; j < NL; ++j) {
                     const uint32_t Uj = lds_ld(lbase[j] + static_cast<uint32_t>(K - 1) * RSTRIDE);
@@ -1067,7 +1089,7 @@ __device__ __forceinline__ void sorted_body(
         }
         if constexpr (STATS) st_flag += (sub == 0 && cell_ok && flag) ? 1u : 0u;
         tick(3);
-        if (XMHW_COLD(s >= ch.begin && __any(flag))) {
+        if (XMHW_COLD(s >= ch.begin && wave_any(flag))) {
             // ---- 4b. the flagged cells of this row, one after the other, by the whole wave (pool_order_stats above) ---------
             constexpr int KPL = (NTP * R + 63) / 64;
             unsigned long long fm = __builtin_amdgcn_ballot_w64(flag && sub == 0 && cell_ok);
