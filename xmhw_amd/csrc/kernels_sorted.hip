@@ -84,6 +84,12 @@ __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
 }
 // some lane's condition holds: the ballot compared as a scalar (HIP's __any() goes through a select and a vector compare)
 __device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+// a * b + c, a and b unsigned 24-bit: one full-rate instruction (left to the compiler `base + P * stride` is a 64-bit v_mad_u64_u32)
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
 // a * b + c, a and b signed 24-bit (the compiler turns a multiplication by +-1 into a negation and a select)
 __device__ __forceinline__ uint32_t mad_i24(uint32_t a, int32_t b, uint32_t c) {
     uint32_t r;
@@ -729,27 +735,10 @@ __device__ __forceinline__ void sorted_body(
         auto cpl = [&](uint32_t v) -> uint32_t { return (v ^ cm) + cneg; };      // (its own inverse)
         const int psign = grow ? 1 : -1;
         const int32_t dstep = grow ? static_cast<int32_t>(RSTRIDE) : -static_cast<int32_t>(RSTRIDE);
-        // min over the lists of the smallest key INSIDE the top set (the cells that move nowhere need both sides)
-        uint32_t um = 0xFFFFFFFFu;
-        {
-            // (addresses, then the six reads back to back, then one wait -- as for the windows below)
-            uint32_t ua[NL], uv[NL];
-#pragma unroll
-            for (int j = 0; j < NL; ++j) ua[j] = lbase[j] + (P[j] - 1u) * RSTRIDE;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < NL; ++j) uv[j] = lds_ld(ua[j]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < NL; ++j)      // (P == 0: nothing inside, the read left the allocation: 0 - 1 = the largest word)
-                um = umin(um, uv[j] - 1u);
-        }
-        um = umin(um, swp(um)) + 1u;
         // (per list, for this row's direction: the address the window starts from when the pointer is 0)
         uint32_t wbase[NL];
 #pragma unroll
         for (int j = 0; j < NL; ++j) wbase[j] = lbase[j] - (grow ? 0u : RSTRIDE);
-        uint32_t TL = 0, TN = 0;       // negated space: the last key that moved, the key that would move next
         // (prem = the keys the cell still has to move, 0 once it has given up: what the loop conditions look at)
         uint32_t prem = rem;
         uint32_t st_iter_row = 0;
@@ -766,7 +755,7 @@ __device__ __forceinline__ void sorted_body(
                     uint32_t hm = 0;
 #pragma unroll
                     for (int j = 0; j < NL; ++j) {
-                        hd[j] = cpl(lds_ld(wbase[j] + P[j] * RSTRIDE));
+                        hd[j] = cpl(lds_ld(mad_u24(P[j], RSTRIDE, wbase[j])));
                         hm = umax(hm, hd[j]);
                     }
                     const uint32_t ho = swp(hm);
@@ -781,10 +770,7 @@ __device__ __forceinline__ void sorted_body(
                         P[j] += sel ? static_cast<uint32_t>(psign) : 0u;
                         found = found || sel;
                     }
-                    if (act && !dry_) {
-                        TL = cmax;
-                        rem -= 1u;
-                    }
+                    rem -= (act && !dry_) ? 1u : 0u;
                     flag = flag | dry_;
                     prem = flag ? 0u : rem;
                 }
@@ -822,7 +808,7 @@ __device__ __forceinline__ void sorted_body(
                 uint32_t ad[NL][5];
 #pragma unroll
                 for (int j = 0; j < NL; ++j) {
-                    ad[j][0] = wbase[j] + P[j] * RSTRIDE;
+                    ad[j][0] = mad_u24(P[j], RSTRIDE, wbase[j]);
 #pragma unroll
                     for (int i = 1; i < 5; ++i) ad[j][i] = ad[j][i - 1] + static_cast<uint32_t>(dstep);
                 }
@@ -875,21 +861,25 @@ __device__ __forceinline__ void sorted_body(
                 const uint32_t lb = sub ? 0u : 0xFFFFFFFFu;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) u8[i] = med3u(t16[i], t16[i + 8], lb);
-                sortnet::BitonicDesc<8>::run(u8);
             }
-            auto rank_of = [&](uint32_t r) -> uint32_t {       // the cell's key of rank r (0..15), 0 outside
-                const uint32_t idx = r - (sub ? 8u : 0u);
-                const uint32_t x01 = (idx & 1u) ? u8[1] : u8[0];
-                const uint32_t x23 = (idx & 1u) ? u8[3] : u8[2];
-                const uint32_t x45 = (idx & 1u) ? u8[5] : u8[4];
-                const uint32_t x67 = (idx & 1u) ? u8[7] : u8[6];
-                const uint32_t y0 = (idx & 2u) ? x23 : x01;
-                const uint32_t y1 = (idx & 2u) ? x67 : x45;
-                uint32_t z = (idx & 4u) ? y1 : y0;
+            // -- the cell's key of rank d - 1 (0 if d == 0): u8 is a bitonic sequence -- the bitonic sorter PRUNED to the one
+            // output asked for: a stage keeps the half the rank lies in, and "the larger or the smaller of a pair, by a bit of
+            // the rank" is one v_med3 against a per-lane bound (all ones: the larger; 0: the smaller).  15 instructions
+            // instead of the sorter's 24 and a 12-instruction pick
+            uint32_t tl;
+            {
+                const uint32_t idx = (d - 1u) - (sub ? 8u : 0u);      // (rank inside this lane's half; >= 8: not here)
+                const int32_t nidx = static_cast<int32_t>(~idx);
+                const uint32_t b4 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(nidx, 2, 1));
+                const uint32_t b2 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(nidx, 1, 1));
+                const uint32_t b1 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(nidx, 0, 1));
+                const uint32_t c0 = med3u(u8[0], u8[4], b4), c1 = med3u(u8[1], u8[5], b4);
+                const uint32_t c2 = med3u(u8[2], u8[6], b4), c3 = med3u(u8[3], u8[7], b4);
+                const uint32_t e0 = med3u(c0, c2, b2), e1 = med3u(c1, c3, b2);
+                uint32_t z = med3u(e0, e1, b1);
                 z = idx < 8u ? z : 0u;
-                return z | swp(z);
-            };
-            const uint32_t tl = rank_of(d - 1u);               // (d == 0: rank 0xFFFFFFFF is outside: 0)
+                tl = z | swp(z);
+            }
             // -- how far the windows can be trusted: a key is SAFE if it is not below the largest fifth key
             F = umax(F, swp(F));
             const bool act = d != 0u;
@@ -956,24 +946,37 @@ __device__ __forceinline__ void sorted_body(
             // (a dry cell gives up: the row goes to the recomputation, what it could not move stays in `rem`.  An unsafe round
             // leaves keys to move, so "keys left" is all the loop has to ask)
             flag = flag | dry;
-            TL = (move & !unsafe) ? tl : TL;
             prem = flag ? 0u : rem;
         }
         {
-            // the key that would move next: the largest of the lists' heads (the d + 1-th candidate of the last round is it only
-            // where no list has used up its window -- on most rows some cell's has)
-            uint32_t hv[NL];
+            // The two keys at the boundary of the top set, from the lists' pointers: a[lo] = the largest key OUTSIDE (max over
+            // the lists of key[P]), a[lo + 1] = the smallest INSIDE (min of key[P - 1]).  Twelve reads and ~30 instructions
+            // once a row, for every cell alike -- whichever way it moved, or not at all -- instead of tracking the last key
+            // that moved through the rounds and reading one side before the select and the other after it.
+            // (P == 0: nothing inside, the read leaves the allocation: 0 - 1 = the largest word; no key outside: 0)
+            uint32_t ao[NL], ai[NL], ho[NL], hi_[NL];
 #pragma unroll
-            for (int j = 0; j < NL; ++j) hv[j] = lds_ld(wbase[j] + P[j] * RSTRIDE);
-            uint32_t hx = 0;
+            for (int j = 0; j < NL; ++j) {
+                ao[j] = mad_u24(P[j], RSTRIDE, lbase[j]);
+                ai[j] = ao[j] - RSTRIDE;
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < NL; ++j) hx = umax(hx, cpl(hv[j]));
-            TN = umax(hx, swp(hx));
+            for (int j = 0; j < NL; ++j) {
+                ho[j] = lds_ld(ao[j]);
+                hi_[j] = lds_ld(ai[j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t mx = 0, mn = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                mx = umax(mx, ho[j]);
+                mn = umin(mn, hi_[j] - 1u);
+            }
+            a_lo = umax(mx, swp(mx));
+            a_hi = umin(mn, swp(mn)) + 1u;
         }
         Ctop = mad_i24(rem, -psign, Cs);      // (Cs, or -- a cell that gave up -- what its pointers hold: Cs -+ the keys not moved)
-        const uint32_t kl = cpl(TL), kn = cpl(TN);
-        a_lo = grow ? kn : kl;
-        a_hi = grow ? (steps0 != 0u ? kl : um) : kn;
         // (no a[lo + 1] -- lo = n - 1 --: both keys are a[lo], the key outside the top set or, mirrored, its smallest member)
         if (!need2) {
             if (mirror) a_lo = a_hi;
