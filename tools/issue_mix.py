@@ -4,9 +4,9 @@ per-instruction costs measured on MI355X (tools/ubench_valu2.hip; profiles/r6_ub
 table: cycles per wave64 instruction and SIMD):
 
     class A  2.75 cycles at >= 2 waves per SIMD (5.7 for a wave alone)   v_add / v_sub / v_and / v_or / v_xor / v_mov / v_lshrrev /
-                                                                         v_ashrrev / v_add_f32 / v_mul_f32 / v_fmac / v_cndmask
+                                                                         v_ashrrev / v_add_f32 / v_mul_f32 / v_fmac / v_bitop3
     class B  4.4 cycles at >= 2 waves per SIMD (5.7 for a wave alone)    v_min / v_max / v_med3 / v_cmp / v_addc / v_subb / v_mad /
-                                                                         v_lshl_add / v_bfe / v_bitop3 / v_xad / VOP3-only integer,
+                                                                         v_lshl_add / v_bfe / v_xad / VOP3-only integer,
                                                                          every float64 instruction, conversions, DPP forms
 
 How: clim_sorted_f32<20, 16, 14, false> is compiled to ISA (hipcc -S, no GPU needed); its hot basic blocks are found by their
@@ -30,7 +30,8 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLASS_A = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_mov_b32", "v_mov_b64",
            "v_lshrrev_b32", "v_ashrrev_i32", "v_add_f32", "v_sub_f32", "v_mul_f32", "v_fmac_f32", "v_not_b32",
-           "v_accvgpr", "v_readlane", "v_writelane", "v_readfirstlane", "v_nop")
+           "v_accvgpr", "v_readlane", "v_writelane", "v_readfirstlane", "v_nop",
+           "v_bitop3_b32")     # (v_bitop3: 3.4 cycles at two waves per SIMD -- profiles/r6_ubench_valu3.txt)
 COST = {"A": (2.75, 5.7), "B": (4.4, 5.7)}
 
 
