@@ -1215,9 +1215,16 @@ __device__ __forceinline__ void sorted_body(
     }
 }
 
-// (registers: LDS holds 6 waves per CU at K = 16 and more for shorter lists: two waves per SIMD is what the body is asked to fit)
+// (registers: LDS holds 8 waves per CU at K = 16: two waves per SIMD is what the body is asked to fit.  The shortest records --
+// up to 8 tracks per lane, 8 keys per list: 11,520 bytes of LDS a wave -- are asked to fit THREE (168 registers, 20..60 bytes
+// of scratch): 12- and 16-year records -4 % and -5.6 %; 9..12 tracks per lane would need 100..164 bytes of scratch and run
+// 1.5 x slower that way -- profiles/r6_experiments.txt)
+#ifndef XMHW_WAVES3_MAX_YPS
+#define XMHW_WAVES3_MAX_YPS 8
+#endif
+#define XMHW_WAVES_PER_SIMD(Y) ((Y) <= XMHW_WAVES3_MAX_YPS ? 3 : 2)
 template <int YPS, int K, int KL, bool STATS>
-__global__ __launch_bounds__(64, 2) void clim_sorted_f32(
+__global__ __launch_bounds__(64, XMHW_WAVES_PER_SIMD(YPS)) void clim_sorted_f32(
     const float* __restrict__ ts, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, const DevSortedChunk* __restrict__ chunks, double q, int negate,
     int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo,
@@ -1227,7 +1234,7 @@ __global__ __launch_bounds__(64, 2) void clim_sorted_f32(
 }
 // the same on int16 codes (no counter twin)
 template <int YPS, int K, int KL>
-__global__ __launch_bounds__(64, 2) void clim_sorted_i16(
+__global__ __launch_bounds__(64, XMHW_WAVES_PER_SIMD(YPS)) void clim_sorted_i16(
     const int16_t* __restrict__ codes, PackedI16 pk, int64_t C, int64_t ld, int64_t Tn, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ sflags, const DevSortedChunk* __restrict__ chunks, double q, int negate,
     int32_t ntracks, double* __restrict__ thresh, double* __restrict__ seas, int64_t ldo) {
