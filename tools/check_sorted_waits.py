@@ -18,7 +18,14 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def check(extra_flags=()):
+_CACHE = {}
+
+
+def kernels(extra_flags=()):
+    """[(mangled name, [(block label, [instructions])])] of every clim_sorted_* kernel, compiled once per flag set"""
+    key = tuple(extra_flags)
+    if key in _CACHE:
+        return _CACHE[key]
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "k.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
@@ -26,7 +33,7 @@ def check(extra_flags=()):
                                os.path.join(ROOT, "xmhw_amd", "csrc", "kernels_sorted.hip")], stderr=subprocess.DEVNULL)
         txt = open(out).read()
     funcs = re.split(r"\n(?=_ZN4xmhw15clim_sorted_[a-z0-9]+I[^\n]*:\s*;\s*@)", txt)[1:]
-    bad = []
+    res = []
     for f in funcs:
         name = f.split(":")[0]
         body = f[:f.index(".Lfunc_end")] if ".Lfunc_end" in f else f
@@ -39,6 +46,32 @@ def check(extra_flags=()):
                 blocks.append(cur)
             elif re.match(r"^\s+(v_|s_|ds_|global_|scratch_)", line):
                 cur[1].append(line.strip())
+        res.append((name, blocks))
+    _CACHE[key] = res
+    return res
+
+
+def check_branches(extra_flags=()):
+    """Divergent mini-branches.  Round 6: `move ? (grow ? P + c : P - c) : P` had become 36 branches per select round, each an
+    s_and_saveexec + s_cbranch_execz + s_or around ONE vector instruction -- 4.8 % of the kernel with hardly an instruction in
+    them (profiles/r6_experiments.txt).  A kernel fails if a select round (a block with >= 20 LDS reads) has more than two
+    exec-mask branches in the blocks right behind it, or more than 24 in all (15 today: the epilogue's, the cold paths')."""
+    bad = []
+    for name, blocks in kernels(extra_flags):
+        total = sum(1 for _, ins in blocks for o in ins if o.startswith("s_cbranch_exec"))
+        near = 0
+        for i, (_, ins) in enumerate(blocks):
+            if sum(1 for o in ins if o.startswith("ds_read")) >= 20:
+                near = max(near, sum(1 for _, i2 in blocks[i:i + 14] for o in i2 if o.startswith("s_cbranch_exec")))
+        if near > 2 or total > 24:
+            bad.append((name, near, total))
+    return len(kernels(extra_flags)), bad
+
+
+def check(extra_flags=()):
+    bad = []
+    funcs = kernels(extra_flags)
+    for name, blocks in funcs:
         for nm, ins in blocks:
             ncmp = sum(1 for o in ins if o.startswith(("v_max_u32", "v_min_u32", "v_med3_u32")))
             if ncmp >= 40 and not any(o.startswith("global_load") for o in ins):
@@ -53,4 +86,8 @@ if __name__ == "__main__":
     for name, nm, w in bad:
         print(f"{name}: block {nm}: {w}")
     print(f"{n} clim_sorted_* kernels checked, {len(bad)} comparator blocks with a vmcnt wait")
-    sys.exit(1 if bad or n == 0 else 0)
+    _, badb = check_branches(sys.argv[1:])
+    for name, near, total in badb:
+        print(f"{name}: {near} exec-mask branches behind a select round, {total} in all")
+    print(f"{len(badb)} kernels with divergent mini-branches in or behind a select round")
+    sys.exit(1 if bad or badb or n == 0 else 0)
