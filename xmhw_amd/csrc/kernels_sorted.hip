@@ -478,6 +478,7 @@ __device__ __forceinline__ void sorted_body(
         double din = 0.0;
         uint32_t nvin = 0;
         float xv[YPS];
+        bool packed_fill = false;      // (PACKED, wave-uniform) some lane of the wave holds a fill code this row
         if constexpr (STATS) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             tick(5);
@@ -504,7 +505,8 @@ __device__ __forceinline__ void sorted_body(
             bool anyfill = false;
 #pragma unroll
             for (int y = 0; y < YPS; ++y) anyfill = anyfill || x_in[y] == pk.fill;
-            if (wave_any(anyfill)) {
+            packed_fill = wave_any(anyfill);
+            if (packed_fill) {
 #pragma unroll
                 for (int y = 0; y < YPS; ++y) xv[y] = x_in[y] == pk.fill ? __uint_as_float(0x7FC00000u) : xv[y];
             }
@@ -517,37 +519,46 @@ __device__ __forceinline__ void sorted_body(
             // a plain row: every real track pushes a sample; NaN shows in the sum (so does +inf next to -inf: those
             // rows take the general path below, which gives the same keys)
             // (cold spells: key(-x) and -sum(x), one instruction per sample less than negating the samples)
-            double din1 = 0.0;
-            if (kneg) {
+            // (keys and -- SUM -- the float64 sum of a plain row; NEG: key(-x))
+            auto plain_row = [&](auto negc, auto sumc) {
+                constexpr bool NEG = decltype(negc)::value, SUM = decltype(sumc)::value;
+                double din1 = 0.0;
 #pragma unroll
                 for (int y = 0; y < YPS; ++y) {
                     uint32_t xb = __float_as_uint(xv[y]);
-                    uint32_t ky = key_fast<true>(xb);
+                    uint32_t ky = key_fast<NEG>(xb);
                     if (y == YPS - 1) {
                         xb &= ~padmask;
                         ky &= ~padmask;
                     }
                     k[y] = ky;
-                    const double dv = static_cast<double>(__uint_as_float(xb));
-                    if (y & 1) din1 = y == 1 ? dv : din1 + dv;      // (two chains: a float64 add waits for the one before it)
-                    else din = y == 0 ? dv : din + dv;
+                    if constexpr (SUM) {
+                        const double dv = static_cast<double>(__uint_as_float(xb));
+                        if (y & 1) din1 = y == 1 ? dv : din1 + dv;      // (two chains: a float64 add waits for the one before it)
+                        else din = y == 0 ? dv : din + dv;
+                    }
                 }
-                din += din1;
+                if constexpr (SUM) din += din1;
+            };
+            bool int_sum = false;
+            if constexpr (PACKED) int_sum = pk.mode != 1;
+            if (int_sum) {
+                // (codes that stand for themselves -- modes 2 and 3: the sum of a row is the sum of its codes, exact in 32-bit
+                // integers: 20 fast-class adds instead of 20 conversions to float64 and 20 float64 adds; a fill code is
+                // what sends the row to the general path, not a NaN in the sum)
+                if constexpr (PACKED) {
+                    int32_t isum = 0;
+#pragma unroll
+                    for (int y = 0; y < YPS; ++y)
+                        isum += (y == YPS - 1) ? (x_in[y] & static_cast<int32_t>(~padmask)) : x_in[y];
+                    if (kneg) plain_row(std::true_type{}, std::false_type{});
+                    else plain_row(std::false_type{}, std::false_type{});
+                    din = packed_fill ? make_nan() : static_cast<double>(isum);
+                }
+            } else if (kneg) {
+                plain_row(std::true_type{}, std::true_type{});
             } else {
-#pragma unroll
-                for (int y = 0; y < YPS; ++y) {
-                    uint32_t xb = __float_as_uint(xv[y]);
-                    uint32_t ky = key_fast<false>(xb);
-                    if (y == YPS - 1) {
-                        xb &= ~padmask;
-                        ky &= ~padmask;
-                    }
-                    k[y] = ky;
-                    const double dv = static_cast<double>(__uint_as_float(xb));
-                    if (y & 1) din1 = y == 1 ? dv : din1 + dv;      // (two chains: a float64 add waits for the one before it)
-                    else din = y == 0 ? dv : din + dv;
-                }
-                din += din1;
+                plain_row(std::false_type{}, std::true_type{});
             }
             if (negate) din = -din;
             nvin = padded_last ? YPS - 1 : YPS;
